@@ -1,0 +1,181 @@
+/*
+ * awsem_hip.h -- C ABI of libawsem_hip.so, the MI355X (gfx950) AWSEM force + Langevin engine.
+ *
+ * This is the drop-in boundary for the openawsem hot path.  The reference (epochbio/openawsem) has no
+ * native/FFI interface of its own: every term factory builds an OpenMM Force object and OpenMM's Context
+ * evaluates it.  Each entry point below therefore cites the reference *call site* whose OpenMM object it
+ * replaces (paths relative to the reference checkout).  All arguments are plain pointers and sizes; the caller
+ * owns every host buffer; the library owns all device memory behind the opaque handle.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative AWSEM_E* code on failure; awsem_last_error() returns a
+ *     thread-local, human readable message for the last failure on the calling thread.
+ *   - units: nm, ps, amu, kJ/mol, K (OpenMM's unit system).
+ *   - atom indices are 0-based into the natoms particles of the system; a handle carries `n_replicas`
+ *     independent copies of the coordinates/velocities (one trajectory each) sharing one set of terms.
+ *   - a handle is bound to one HIP device and is not thread-safe.
+ *   - `group` is the OpenMM force group (0..31) the factory assigned (Force.setForceGroup); energy/force
+ *     queries take a 32-bit mask of groups, as Context.getState(groups=...) does.
+ *   - precision: AWSEM_FP32 runs the production kernels (fp32 arithmetic, 64-bit fixed-point force
+ *     accumulation); AWSEM_FP64 runs the same kernels instantiated in double (the "check mode").
+ */
+#ifndef AWSEM_HIP_H
+#define AWSEM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct awsem_context* awsem_handle;
+
+enum { AWSEM_FP32 = 0, AWSEM_FP64 = 1 };
+
+enum {
+    AWSEM_OK = 0,
+    AWSEM_EINVAL = -1,   /* bad argument (index out of range, null pointer, wrong size ...) */
+    AWSEM_ESTATE = -2,   /* call made in the wrong phase (e.g. add_* after finalize) */
+    AWSEM_EDEVICE = -3,  /* HIP runtime error or no usable gfx950 device */
+    AWSEM_ELIMIT = -4,   /* system too large for the replica-resident (LDS) path */
+    AWSEM_ENOMEM = -5
+};
+
+const char* awsem_last_error(void);
+/* version string "awsem_hip <major>.<minor> gfx950" */
+const char* awsem_version(void);
+
+/* ---- system construction --------------------------------------------------------------------------------
+ * Replaces openmm.System creation in OpenMMAWSEMSystem.__init__ (openawsem/openAWSEM.py:820-914):
+ * ForceField(awsem.xml).createSystem(topology) -> per-particle masses (topology/awsem.xml:4-9; mass 0 marks
+ * the virtual N/H/C sites). */
+int awsem_create(int natoms, int n_replicas, int device, int precision, awsem_handle* out);
+void awsem_destroy(awsem_handle h);
+int awsem_set_masses(awsem_handle h, const double* mass_amu, int natoms);
+
+/* ThreeParticleAverageSite(p1,p2,p3,w1,w2,w3) per virtual atom -- setup_virtual_sites, openAWSEM.py:666-696.
+ * parents[3*i..] and weights[3*i..] belong to site[i]. */
+int awsem_set_virtual_sites(awsem_handle h, int n, const int32_t* site, const int32_t* parents,
+                            const double* weights);
+
+/* ---- terms (one call per reference factory product) ----------------------------------------------------- */
+
+/* HarmonicBondForce: E = 1/2 k (r-r0)^2.  con_term basicTerms.py:24-58, chain_term basicTerms.py:61-95. */
+int awsem_add_harmonic_bonds(awsem_handle h, int group, int n, const int32_t* pairs, const double* r0,
+                             const double* k);
+
+/* chi_term basicTerms.py:98-138: E = k_chi (chi - chi0)^2 over atoms (CA, C, N, CB). */
+int awsem_add_chi(awsem_handle h, int group, int n, const int32_t* atoms4, double k_chi, double chi0);
+
+/* rama_term / rama_proline_term / rama_ssweight_term basicTerms.py:266-440.
+ * atoms5 = (C_{i-1}, N_i, CA_i, C_i, N_{i+1}); well_params = nwell rows of
+ * (w, sigma, omega_phi, phi0, omega_psi, psi0); bond_well_weight is n*nwell (row per bond; the ssweight(well,res)
+ * factor) or NULL for all ones.  E = -k sum_w weight*w*exp(-sigma(omega_phi(cos(phi-phi0)-1)^2+omega_psi(cos(psi-psi0)-1)^2)) */
+int awsem_add_rama(awsem_handle h, int group, int n, const int32_t* atoms5, int nwell,
+                   const double* well_params, const double* bond_well_weight, double k);
+
+/* excl_term basicTerms.py:141-191 (CustomNonbondedForce, CutoffNonPeriodic, interaction groups).
+ * Sites of equal class interact (class 0 = CA and CB, class 1 = O); excl_pairs are atom-index pairs that
+ * createExclusionsFromBonds(oa.bonds, 1) removes.  E = k (r - r_excl)^2 for r < r_excl. */
+int awsem_add_excl(awsem_handle h, int group, int nsites, const int32_t* atom, const int32_t* cls,
+                   int nexcl, const int32_t* excl_pairs, double k, double r_excl);
+
+/* contact_term contactTerms.py:99-375 (CustomGBForce: density rho, direct + mediated pair energy, burial)
+ * and burial_term contactTerms.py:1772-1840 (flags & AWSEM_CONTACT_BURIAL_ONLY).
+ * Sites are the nres "CB, or CA for glycine" atoms.  gamma is [env 0..1][kind 0=direct,1=protein,2=water][20][20],
+ * burial_gamma is [20][3] or NULL (burialPartOn=False).  dparams: see awsem_contact_dparam below. */
+enum {
+    AWSEM_CONTACT_ZDEP = 1,         /* z_dependent=True: blend env 0 / env 1 with alphaMembrane(z) */
+    AWSEM_CONTACT_BURIAL_ONLY = 2,  /* standalone burial_term: no pair energy */
+    AWSEM_CONTACT_NOCUTOFF = 4      /* burial_term never calls setNonbondedMethod -> NoCutoff */
+};
+enum awsem_contact_dparam {
+    AWSEM_CP_K = 0, AWSEM_CP_RMIN, AWSEM_CP_RMAX, AWSEM_CP_RMINII, AWSEM_CP_RMAXII, AWSEM_CP_ETA,
+    AWSEM_CP_ETA_SIGMA, AWSEM_CP_RHO0, AWSEM_CP_CUTOFF, AWSEM_CP_BURIAL_KAPPA,
+    AWSEM_CP_BURIAL_RHO_MIN0, AWSEM_CP_BURIAL_RHO_MIN1, AWSEM_CP_BURIAL_RHO_MIN2,
+    AWSEM_CP_BURIAL_RHO_MAX0, AWSEM_CP_BURIAL_RHO_MAX1, AWSEM_CP_BURIAL_RHO_MAX2,
+    AWSEM_CP_ETA_SWITCH, AWSEM_CP_Z_M, AWSEM_CP_MEMBRANE_CENTER, AWSEM_CP_K_BURIAL,
+    AWSEM_CP_COUNT
+};
+int awsem_add_contact(awsem_handle h, int group, int nsites, const int32_t* atom, const int32_t* restype,
+                      const int32_t* resid, const int32_t* chain, int env, int min_seq_sep, int flags,
+                      const double* dparams, const double* gamma, const double* burial_gamma);
+
+/* beta_term_1/2/3 hydrogenBondTerms.py:418-611 (CustomHbondForce, CutoffNonPeriodic on distance(a1,d1)).
+ * acc_atoms = 3 per acceptor (a1,a2,a3), don_atoms = 3 per donor (d1,d2,d3); -1 marks unused slots.
+ *   theta(x;y,z) = exp(-(|x-y|-r_ON)^2/(2 s_NO^2) - (|x-z|-r_OH)^2/(2 s_HO^2))
+ *   two_theta==0:  E = -k lambda[don_res][acc_res] theta(a1;d1,d2)                        (beta_1)
+ *   two_theta==1:  E = -k lambda[don_res][acc_res] theta(a1;d1,d2) theta(d3;a2,a3)        (beta_2, beta_3)
+ * lambda is the dense nres x nres table the factory builds (row = donor residue). */
+int awsem_add_hbond_beta(awsem_handle h, int group, int two_theta, int nacc, const int32_t* acc_atoms,
+                         const int32_t* acc_res, int ndon, const int32_t* don_atoms, const int32_t* don_res,
+                         int nres, const double* lambda, double k, double r_ON, double sigma_NO, double r_OH,
+                         double sigma_HO, double cutoff);
+
+/* pap_term_1/2 hydrogenBondTerms.py:614-761.  acc_atoms = (a1,a2) = (CA_i, CA_{i+4}); don_atoms = (d1,d2).
+ *   E = -k gamma[don_res][acc_res] 1/2(1+tanh(eta(r0-|a1-d1|))) 1/2(1+tanh(eta(r0-|a2-d2|))) 1/2(1+tanh(eta(|a1-a2|-d_i4))) */
+int awsem_add_hbond_pap(awsem_handle h, int group, int nacc, const int32_t* acc_atoms, const int32_t* acc_res,
+                        int ndon, const int32_t* don_atoms, const int32_t* don_res, int nres,
+                        const double* gamma, double k, double eta, double r0, double d_i4, double cutoff);
+
+/* helical_term hydrogenBondTerms.py:790-832: E = -coef theta(O_i; N_{i+4}, H_{i+4}), coef = k(fa_i + fa_{i+4}). */
+int awsem_add_helical(awsem_handle h, int group, int n, const int32_t* atoms3, const double* coef, double r_ON,
+                      double sigma_NO, double r_OH, double sigma_HO);
+
+/* fragment_memory_term templateTerms.py:122-294 (CustomCompoundBondForce(2) + Discrete2DFunction):
+ * E = -k_fm lerp(table[b][i], table[b][i+1]) with i = min(ntab-2, floor(r/dr)); table is nbonds x ntab, row major. */
+int awsem_add_fragment_memory(awsem_handle h, int group, int nbonds, const int32_t* pairs, int ntab,
+                              const double* table, double k_fm, double dr);
+
+/* membrane_term membraneTerms.py:12-54 and membrane_preassigned_term membraneTerms.py:115-156
+ * (CustomExternalForce): E = k scale (1/2 tanh(k_m((z-c)+z_m)) + 1/2 tanh(k_m(z_m-(z-c)))). */
+int awsem_add_membrane(awsem_handle h, int group, int n, const int32_t* atoms, const double* scale, double k,
+                       double k_m, double z_m, double center);
+
+/* debye_huckel_term debyeHuckelTerms.py:10-76 (CustomBondForce): E = k_dh qq / r exp(-r/screening_length). */
+int awsem_add_debye_huckel(awsem_handle h, int group, int n, const int32_t* pairs, const double* qq,
+                           double k_dh, double screening_length);
+
+/* Uploads tables and index arrays to the device; no add_* / set_masses / set_virtual_sites afterwards.
+ * Replaces Simulation(topology, system, integrator, platform) -> Context creation (scripts/mm_run.py:148). */
+int awsem_finalize(awsem_handle h);
+
+/* ---- state ---------------------------------------------------------------------------------------------
+ * context.setPositions scripts/mm_run.py:150, scripts/mm_analyze.py:163.  xyz is natoms x 3 (AoS, nm);
+ * replica == -1 writes the same coordinates to every replica.  Stored coordinates of virtual sites are used
+ * as given (OpenMM does not re-derive them on setPositions); awsem_compute_virtual_sites re-derives them. */
+int awsem_set_positions(awsem_handle h, int replica, const double* xyz, int natoms);
+int awsem_get_positions(awsem_handle h, int replica, double* xyz, int natoms);
+int awsem_set_velocities(awsem_handle h, int replica, const double* vxyz, int natoms);
+int awsem_get_velocities(awsem_handle h, int replica, double* vxyz, int natoms);
+int awsem_compute_virtual_sites(awsem_handle h);
+/* context.setVelocitiesToTemperature scripts/mm_run.py:151; T is per replica (n_replicas). */
+int awsem_set_velocities_to_temperature(awsem_handle h, const double* T_kelvin, uint64_t seed);
+
+/* ---- evaluation ----------------------------------------------------------------------------------------
+ * context.getState(getEnergy=True, groups=...) scripts/mm_analyze.py:165-178, tests/test_energies.py:119.
+ * awsem_energy: one potential energy per replica for the masked groups.
+ * awsem_energy_by_group: n_replicas x 32 energies in one pass.
+ * awsem_forces: n_replicas x natoms x 3; redistribute != 0 folds virtual-site forces onto their parents
+ * (what getState(getForces=True) reports), 0 returns the raw per-atom gradient. */
+int awsem_energy(awsem_handle h, uint32_t group_mask, double* e_per_replica);
+int awsem_energy_by_group(awsem_handle h, double* e_replica_by_group);
+int awsem_forces(awsem_handle h, uint32_t group_mask, int redistribute, double* f);
+
+/* simulation.step(n) with LangevinIntegrator(T, friction, dt) scripts/mm_run.py:145,171-175.
+ * T_kelvin is per replica (integrator.setTemperature); all terms (every group) drive the dynamics. */
+int awsem_step(awsem_handle h, int nsteps, const double* T_kelvin, double dt_ps, double friction_per_ps,
+               uint64_t seed);
+int64_t awsem_step_count(awsem_handle h);
+int awsem_set_step_count(awsem_handle h, int64_t step);
+
+/* Wall time of the last awsem_step / awsem_energy* / awsem_forces kernel launch measured with HIP events on
+ * the handle's stream (ms); used by bench.py for the roofline line. */
+int awsem_last_kernel_ms(awsem_handle h, double* ms);
+int awsem_synchronize(awsem_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AWSEM_HIP_H */

@@ -1,0 +1,290 @@
+"""ctypes binding of the C ABI declared in include/awsem_hip.h.
+
+`CApi(lib, prefix)` binds every entry point of the header under a symbol prefix: the product binds
+``awsem_`` from libawsem_hip.so (see `load_hip_library`); the test oracle exports the same signatures under
+``awsem_oracle_`` and is bound by oracle/awsem_oracle.py with this same class, so that one set of term
+descriptors can be uploaded to either.  Nothing in this module imports or loads the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIBRARY_PATH = os.path.join(_HERE, "csrc", "libawsem_hip.so")
+
+c_int_p = C.POINTER(C.c_int32)
+c_dbl_p = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); 'H' marks the handle
+_SIGNATURES = {
+    "create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "destroy": (None, ["H"]),
+    "set_masses": (C.c_int, ["H", c_dbl_p, C.c_int]),
+    "set_virtual_sites": (C.c_int, ["H", C.c_int, c_int_p, c_int_p, c_dbl_p]),
+    "add_harmonic_bonds": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, c_dbl_p]),
+    "add_chi": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, C.c_double, C.c_double]),
+    "add_rama": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, C.c_int, c_dbl_p, c_dbl_p, C.c_double]),
+    "add_excl": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, C.c_double, C.c_double]),
+    "add_contact": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p, C.c_int, C.c_int, C.c_int,
+                              c_dbl_p, c_dbl_p, c_dbl_p]),
+    "add_hbond_beta": (C.c_int, ["H", C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int,
+                                 c_dbl_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "add_hbond_pap": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int, c_dbl_p,
+                                C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "add_helical": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "add_fragment_memory": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, C.c_int, c_dbl_p, C.c_double, C.c_double]),
+    "add_membrane": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "add_debye_huckel": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double]),
+    "finalize": (C.c_int, ["H"]),
+    "set_positions": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_int]),
+    "get_positions": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_int]),
+    "set_velocities": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_int]),
+    "get_velocities": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_int]),
+    "compute_virtual_sites": (C.c_int, ["H"]),
+    "set_velocities_to_temperature": (C.c_int, ["H", c_dbl_p, C.c_uint64]),
+    "energy": (C.c_int, ["H", C.c_uint32, c_dbl_p]),
+    "energy_by_group": (C.c_int, ["H", c_dbl_p]),
+    "forces": (C.c_int, ["H", C.c_uint32, C.c_int, c_dbl_p]),
+    "step": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_double, C.c_double, C.c_uint64]),
+    "step_count": (C.c_int64, ["H"]),
+    "set_step_count": (C.c_int, ["H", C.c_int64]),
+    "last_kernel_ms": (C.c_int, ["H", c_dbl_p]),
+    "synchronize": (C.c_int, ["H"]),
+    "last_error": (C.c_char_p, []),
+    "version": (C.c_char_p, []),
+}
+# entry points that exist only in libawsem_hip.so (declared in include/awsem_hip.h, no oracle counterpart)
+_HIP_ONLY = {}
+
+EXPORTED_SYMBOLS = tuple("awsem_" + n for n in list(_SIGNATURES) + list(_HIP_ONLY))
+
+
+class AwsemError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"[awsem error {code}] {message}")
+        self.code = code
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_dbl_p)
+
+
+class CApi:
+    """Typed access to one library implementing the include/awsem_hip.h ABI under `prefix`."""
+
+    def __init__(self, lib, prefix="awsem_", extra=None):
+        self.lib = lib
+        self.prefix = prefix
+        self.fn = {}
+        sigs = dict(_SIGNATURES)
+        if extra:
+            sigs.update(extra)
+        for name, (res, args) in sigs.items():
+            f = getattr(lib, prefix + name)
+            f.restype = res
+            f.argtypes = [C.c_void_p if a == "H" else a for a in args]
+            self.fn[name] = f
+
+    def check(self, code):
+        if code != 0:
+            msg = self.fn["last_error"]()
+            raise AwsemError(code, msg.decode() if msg else "unknown error")
+
+    def version(self):
+        return self.fn["version"]().decode()
+
+
+class Context:
+    """One engine handle: a system of `natoms` particles x `n_replicas` trajectories."""
+
+    def __init__(self, api: CApi, natoms: int, n_replicas: int = 1, device: int = 0, precision: int = 0):
+        self.api = api
+        self.natoms = int(natoms)
+        self.n_replicas = int(n_replicas)
+        self.precision = precision
+        h = C.c_void_p()
+        api.check(api.fn["create"](self.natoms, self.n_replicas, int(device), int(precision), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.api.fn["destroy"](self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        self.api.check(self.api.fn[name](self.h, *args))
+
+    # ---- construction
+    def set_masses(self, mass):
+        m = _f64(mass)
+        self._call("set_masses", _dp(m), len(m))
+
+    def set_virtual_sites(self, site, parents, weights):
+        s, p, w = _i32(site), _i32(parents).reshape(-1), _f64(weights).reshape(-1)
+        self._call("set_virtual_sites", len(s), _ip(s), _ip(p), _dp(w))
+
+    def add_harmonic_bonds(self, group, pairs, r0, k):
+        p, r0, k = _i32(pairs).reshape(-1), _f64(r0), _f64(k)
+        self._call("add_harmonic_bonds", group, len(r0), _ip(p), _dp(r0), _dp(k))
+
+    def add_chi(self, group, atoms4, k_chi, chi0):
+        a = _i32(atoms4).reshape(-1)
+        self._call("add_chi", group, len(a) // 4, _ip(a), float(k_chi), float(chi0))
+
+    def add_rama(self, group, atoms5, well_params, bond_well_weight, k):
+        a = _i32(atoms5).reshape(-1)
+        wp = _f64(well_params).reshape(-1, 6)
+        bw = None if bond_well_weight is None else _f64(bond_well_weight).reshape(-1)
+        self._call("add_rama", group, len(a) // 5, _ip(a), wp.shape[0], _dp(wp), _dp(bw), float(k))
+
+    def add_excl(self, group, atom, cls, excl_pairs, k, r_excl):
+        a, c, e = _i32(atom), _i32(cls), _i32(excl_pairs).reshape(-1)
+        self._call("add_excl", group, len(a), _ip(a), _ip(c), len(e) // 2, _ip(e), float(k), float(r_excl))
+
+    def add_contact(self, group, atom, restype, resid, chain, env, min_seq_sep, flags, dparams, gamma, burial_gamma):
+        a, t, r, ch = _i32(atom), _i32(restype), _i32(resid), _i32(chain)
+        dp = _f64(dparams)
+        g = None if gamma is None else _f64(gamma).reshape(-1)
+        bg = None if burial_gamma is None else _f64(burial_gamma).reshape(-1)
+        assert len(dp) == 20 and (g is None or len(g) == 2400) and (bg is None or len(bg) == 60)
+        self._call("add_contact", group, len(a), _ip(a), _ip(t), _ip(r), _ip(ch), int(env), int(min_seq_sep), int(flags),
+                   _dp(dp), _dp(g), _dp(bg))
+
+    def add_hbond_beta(self, group, two_theta, acc_atoms, acc_res, don_atoms, don_res, lam, k, r_ON, sigma_NO, r_OH,
+                       sigma_HO, cutoff):
+        aa, ar = _i32(acc_atoms).reshape(-1), _i32(acc_res)
+        da, dr = _i32(don_atoms).reshape(-1), _i32(don_res)
+        lam = _f64(lam)
+        assert lam.ndim == 2 and lam.shape[0] == lam.shape[1]
+        self._call("add_hbond_beta", group, int(two_theta), len(ar), _ip(aa), _ip(ar), len(dr), _ip(da), _ip(dr),
+                   lam.shape[0], _dp(lam), float(k), float(r_ON), float(sigma_NO), float(r_OH), float(sigma_HO), float(cutoff))
+
+    def add_hbond_pap(self, group, acc_atoms, acc_res, don_atoms, don_res, gamma, k, eta, r0, d_i4, cutoff):
+        aa, ar = _i32(acc_atoms).reshape(-1), _i32(acc_res)
+        da, dr = _i32(don_atoms).reshape(-1), _i32(don_res)
+        g = _f64(gamma)
+        assert g.ndim == 2 and g.shape[0] == g.shape[1]
+        self._call("add_hbond_pap", group, len(ar), _ip(aa), _ip(ar), len(dr), _ip(da), _ip(dr), g.shape[0], _dp(g),
+                   float(k), float(eta), float(r0), float(d_i4), float(cutoff))
+
+    def add_helical(self, group, atoms3, coef, r_ON, sigma_NO, r_OH, sigma_HO):
+        a, c = _i32(atoms3).reshape(-1), _f64(coef)
+        self._call("add_helical", group, len(c), _ip(a), _dp(c), float(r_ON), float(sigma_NO), float(r_OH), float(sigma_HO))
+
+    def add_fragment_memory(self, group, pairs, table, k_fm, dr):
+        p, t = _i32(pairs).reshape(-1), _f64(table)
+        nb = len(p) // 2
+        t = t.reshape(nb, -1) if nb else t.reshape(0, max(2, t.shape[-1] if t.ndim else 2))
+        self._call("add_fragment_memory", group, nb, _ip(p), t.shape[1], _dp(t), float(k_fm), float(dr))
+
+    def add_membrane(self, group, atoms, scale, k, k_m, z_m, center):
+        a, s = _i32(atoms), _f64(scale)
+        self._call("add_membrane", group, len(a), _ip(a), _dp(s), float(k), float(k_m), float(z_m), float(center))
+
+    def add_debye_huckel(self, group, pairs, qq, k_dh, screening_length):
+        p, q = _i32(pairs).reshape(-1), _f64(qq)
+        self._call("add_debye_huckel", group, len(q), _ip(p), _dp(q), float(k_dh), float(screening_length))
+
+    def finalize(self):
+        self._call("finalize")
+
+    # ---- state
+    def set_positions(self, xyz, replica=-1):
+        x = _f64(xyz).reshape(-1, 3)
+        self._call("set_positions", int(replica), _dp(x), x.shape[0])
+
+    def get_positions(self, replica=0):
+        x = np.empty((self.natoms, 3))
+        self._call("get_positions", int(replica), _dp(x), self.natoms)
+        return x
+
+    def set_velocities(self, v, replica=-1):
+        v = _f64(v).reshape(-1, 3)
+        self._call("set_velocities", int(replica), _dp(v), v.shape[0])
+
+    def get_velocities(self, replica=0):
+        v = np.empty((self.natoms, 3))
+        self._call("get_velocities", int(replica), _dp(v), self.natoms)
+        return v
+
+    def compute_virtual_sites(self):
+        self._call("compute_virtual_sites")
+
+    def set_velocities_to_temperature(self, T, seed):
+        T = np.broadcast_to(_f64(T), (self.n_replicas,)).copy()
+        self._call("set_velocities_to_temperature", _dp(T), C.c_uint64(int(seed)))
+
+    # ---- evaluation
+    def energy(self, group_mask=0xFFFFFFFF):
+        e = np.empty(self.n_replicas)
+        self._call("energy", C.c_uint32(group_mask & 0xFFFFFFFF), _dp(e))
+        return e
+
+    def energy_by_group(self):
+        e = np.empty((self.n_replicas, 32))
+        self._call("energy_by_group", _dp(e))
+        return e
+
+    def forces(self, group_mask=0xFFFFFFFF, redistribute=True):
+        f = np.empty((self.n_replicas, self.natoms, 3))
+        self._call("forces", C.c_uint32(group_mask & 0xFFFFFFFF), int(bool(redistribute)), _dp(f))
+        return f
+
+    def step(self, nsteps, T, dt_ps, friction_per_ps, seed):
+        T = np.broadcast_to(_f64(T), (self.n_replicas,)).copy()
+        self._call("step", int(nsteps), _dp(T), float(dt_ps), float(friction_per_ps), C.c_uint64(int(seed)))
+
+    @property
+    def step_count(self):
+        return int(self.api.fn["step_count"](self.h))
+
+    @step_count.setter
+    def step_count(self, v):
+        self._call("set_step_count", C.c_int64(int(v)))
+
+    def last_kernel_ms(self):
+        ms = C.c_double()
+        self.api.check(self.api.fn["last_kernel_ms"](self.h, C.byref(ms)))
+        return ms.value
+
+    def synchronize(self):
+        self._call("synchronize")
+
+
+_hip_api = None
+
+
+def load_hip_library(path: str | None = None) -> CApi:
+    """Load libawsem_hip.so (built in-tree by __graft_entry__.build()).  Fails loudly when it is missing:
+    there is no CPU fallback in the product path."""
+    global _hip_api
+    if _hip_api is not None and path is None:
+        return _hip_api
+    p = path or HIP_LIBRARY_PATH
+    if not os.path.exists(p):
+        raise ImportError(f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')")
+    api = CApi(C.CDLL(p), "awsem_", extra=_HIP_ONLY)
+    if path is None:
+        _hip_api = api
+    return api

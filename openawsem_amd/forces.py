@@ -1,0 +1,330 @@
+"""Typed term descriptors: what the openawsem-compatible factories return instead of ``openmm.Force`` objects.
+
+The reference factories build OpenMM Custom*Force objects out of expression strings
+(openawsem/functionTerms/*.py).  This engine supports the fixed AWSEM term set only, so a factory's product is a
+plain record of index arrays and parameter tables plus the two Force methods the drivers rely on
+(``setForceGroup``/``getForceGroup``: openawsem/openAWSEM.py:918-928, openawsem/scripts/mm_analyze.py:119-178).
+``_upload(ctx)`` hands the arrays to a `_capi.Context` (include/awsem_hip.h).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class Force:
+    kind = "force"
+
+    def __init__(self, group=0):
+        self._group = int(group)
+
+    def setForceGroup(self, group):
+        group = int(group)
+        if not 0 <= group < 32:
+            raise ValueError("Force group must be between 0 and 31")
+        self._group = group
+
+    def getForceGroup(self):
+        return self._group
+
+    # OpenMM Force API bits a user script may touch; harmless here.
+    def setUsesPeriodicBoundaryConditions(self, flag):
+        if flag:
+            raise NotImplementedError("periodic boundary conditions are not supported by the MI355X AWSEM engine")
+
+    def usesPeriodicBoundaryConditions(self):
+        return False
+
+    def _upload(self, ctx):
+        raise NotImplementedError
+
+
+class HarmonicBondForce(Force):
+    kind = "harmonic"
+
+    def __init__(self, group=0):
+        super().__init__(group)
+        self.pairs, self.r0, self.k = [], [], []
+
+    def addBond(self, i, j, r0, k):
+        self.pairs.append((int(i), int(j)))
+        self.r0.append(float(r0))
+        self.k.append(float(k))
+        return len(self.r0) - 1
+
+    def getNumBonds(self):
+        return len(self.r0)
+
+    def _upload(self, ctx):
+        ctx.add_harmonic_bonds(self._group, np.array(self.pairs, dtype=np.int32).reshape(-1, 2), self.r0, self.k)
+
+
+class ChiForce(Force):
+    kind = "chi"
+
+    def __init__(self, k_chi, chi0, group=0):
+        super().__init__(group)
+        self.k_chi, self.chi0, self.atoms = float(k_chi), float(chi0), []
+
+    def addBond(self, atoms):
+        self.atoms.append(tuple(int(a) for a in atoms))
+
+    def getNumBonds(self):
+        return len(self.atoms)
+
+    def _upload(self, ctx):
+        ctx.add_chi(self._group, np.array(self.atoms, dtype=np.int32).reshape(-1, 4), self.k_chi, self.chi0)
+
+
+class RamaForce(Force):
+    """-k sum_w weight_w(bond) w_w exp(-sigma_w(omega_phi_w (cos(phi-phi0_w)-1)^2 + omega_psi_w (cos(psi-psi0_w)-1)^2))"""
+    kind = "rama"
+
+    def __init__(self, k, w, sigma, omega_phi, phi0, omega_psi, psi0, group=0):
+        super().__init__(group)
+        self.k = float(k)
+        self.well_params = np.stack([np.asarray(x, dtype=float) for x in (w, sigma, omega_phi, phi0, omega_psi, psi0)], axis=1)
+        self.atoms, self.weights = [], []
+
+    def addBond(self, atoms, weights=None):
+        self.atoms.append(tuple(int(a) for a in atoms))
+        nw = self.well_params.shape[0]
+        self.weights.append([1.0] * nw if weights is None else [float(x) for x in weights])
+
+    def getNumBonds(self):
+        return len(self.atoms)
+
+    def _upload(self, ctx):
+        ctx.add_rama(self._group, np.array(self.atoms, dtype=np.int32).reshape(-1, 5), self.well_params,
+                     np.array(self.weights, dtype=float).reshape(-1, self.well_params.shape[0]), self.k)
+
+
+class ExclForce(Force):
+    kind = "excl"
+
+    def __init__(self, k, r_excl, group=0):
+        super().__init__(group)
+        self.k, self.r_excl = float(k), float(r_excl)
+        self.atom, self.cls, self.excl_pairs = [], [], []
+
+    def _upload(self, ctx):
+        ctx.add_excl(self._group, self.atom, self.cls, np.array(self.excl_pairs, dtype=np.int32).reshape(-1, 2), self.k, self.r_excl)
+
+    def getCutoffDistance(self):
+        return self.r_excl
+
+
+CONTACT_ZDEP, CONTACT_BURIAL_ONLY, CONTACT_NOCUTOFF = 1, 2, 4
+
+
+class ContactForce(Force):
+    kind = "contact"
+
+    def __init__(self, group=0):
+        super().__init__(group)
+        self.atom = self.restype = self.resid = self.chain = None
+        self.env, self.min_seq_sep, self.flags = 0, 10, 0
+        self.dparams = np.zeros(20)
+        self.gamma = None          # [2][3][20][20]: env x (direct, protein, water)
+        self.burial_gamma = None   # [20][3]
+        self.cutoff = 1.0
+
+    def getCutoffDistance(self):
+        return self.cutoff
+
+    def getNonbondedMethod(self):
+        return 0 if self.flags & CONTACT_NOCUTOFF else 1   # NoCutoff / CutoffNonPeriodic
+
+    def _upload(self, ctx):
+        ctx.add_contact(self._group, self.atom, self.restype, self.resid, self.chain, self.env, self.min_seq_sep, self.flags,
+                        self.dparams, self.gamma, self.burial_gamma)
+
+
+class HbondBetaForce(Force):
+    kind = "beta"
+
+    def __init__(self, two_theta, k, lam, r_ON=.298, sigma_NO=.068, r_OH=.206, sigma_HO=.076, cutoff=1.0, group=0):
+        super().__init__(group)
+        self.two_theta, self.k, self.lam = int(two_theta), float(k), np.asarray(lam, dtype=float)
+        self.r_ON, self.sigma_NO, self.r_OH, self.sigma_HO, self.cutoff = r_ON, sigma_NO, r_OH, sigma_HO, cutoff
+        self.acc_atoms, self.acc_res, self.don_atoms, self.don_res = [], [], [], []
+
+    def addAcceptor(self, a1, a2, a3, params):
+        self.acc_atoms.append((int(a1), int(a2), int(a3)))
+        self.acc_res.append(int(params[0]))
+
+    def addDonor(self, d1, d2, d3, params):
+        self.don_atoms.append((int(d1), int(d2), int(d3)))
+        self.don_res.append(int(params[0]))
+
+    def getNumAcceptors(self):
+        return len(self.acc_res)
+
+    def getNumDonors(self):
+        return len(self.don_res)
+
+    def getCutoffDistance(self):
+        return self.cutoff
+
+    def _upload(self, ctx):
+        ctx.add_hbond_beta(self._group, self.two_theta, np.array(self.acc_atoms, dtype=np.int32).reshape(-1, 3), self.acc_res,
+                           np.array(self.don_atoms, dtype=np.int32).reshape(-1, 3), self.don_res, self.lam, self.k,
+                           self.r_ON, self.sigma_NO, self.r_OH, self.sigma_HO, self.cutoff)
+
+
+class HbondPapForce(Force):
+    kind = "pap"
+
+    def __init__(self, k, gamma, eta=70.0, r0=0.8, d_i4=1.2, cutoff=1.0, group=0):
+        super().__init__(group)
+        self.k, self.gamma = float(k), np.asarray(gamma, dtype=float)
+        self.eta, self.r0, self.d_i4, self.cutoff = float(eta), float(r0), float(d_i4), float(cutoff)
+        self.acc_atoms, self.acc_res, self.don_atoms, self.don_res = [], [], [], []
+
+    def addAcceptor(self, a1, a2, a3, params):
+        self.acc_atoms.append((int(a1), int(a2)))
+        self.acc_res.append(int(params[0]))
+
+    def addDonor(self, d1, d2, d3, params):
+        self.don_atoms.append((int(d1), int(d2)))
+        self.don_res.append(int(params[0]))
+
+    def getNumAcceptors(self):
+        return len(self.acc_res)
+
+    def getNumDonors(self):
+        return len(self.don_res)
+
+    def getCutoffDistance(self):
+        return self.cutoff
+
+    def _upload(self, ctx):
+        ctx.add_hbond_pap(self._group, np.array(self.acc_atoms, dtype=np.int32).reshape(-1, 2), self.acc_res,
+                          np.array(self.don_atoms, dtype=np.int32).reshape(-1, 2), self.don_res, self.gamma, self.k,
+                          self.eta, self.r0, self.d_i4, self.cutoff)
+
+
+class HelicalForce(Force):
+    kind = "helical"
+
+    def __init__(self, r_ON=.298, sigma_NO=.068, r_OH=.206, sigma_HO=.076, group=0):
+        super().__init__(group)
+        self.r_ON, self.sigma_NO, self.r_OH, self.sigma_HO = r_ON, sigma_NO, r_OH, sigma_HO
+        self.atoms, self.coef = [], []
+
+    def addBond(self, atoms, coef):
+        self.atoms.append(tuple(int(a) for a in atoms))
+        self.coef.append(float(coef))
+
+    def getNumBonds(self):
+        return len(self.coef)
+
+    def _upload(self, ctx):
+        ctx.add_helical(self._group, np.array(self.atoms, dtype=np.int32).reshape(-1, 3), self.coef, self.r_ON, self.sigma_NO,
+                        self.r_OH, self.sigma_HO)
+
+
+class FragmentMemoryForce(Force):
+    kind = "fragment_memory"
+
+    def __init__(self, k_fm, pairs, table, dr, group=0):
+        super().__init__(group)
+        self.k_fm, self.dr = float(k_fm), float(dr)
+        self.pairs = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+        self.table = np.asarray(table, dtype=float)
+
+    def getNumBonds(self):
+        return len(self.pairs)
+
+    def _upload(self, ctx):
+        ctx.add_fragment_memory(self._group, self.pairs, self.table, self.k_fm, self.dr)
+
+
+class MembraneForce(Force):
+    kind = "membrane"
+
+    def __init__(self, k, k_m, z_m, center, group=0):
+        super().__init__(group)
+        self.k, self.k_m, self.z_m, self.center = float(k), float(k_m), float(z_m), float(center)
+        self.atoms, self.scale = [], []
+
+    def addParticle(self, atom, params):
+        self.atoms.append(int(atom))
+        self.scale.append(float(params[0]))
+
+    def _upload(self, ctx):
+        ctx.add_membrane(self._group, self.atoms, self.scale, self.k, self.k_m, self.z_m, self.center)
+
+
+class DebyeHuckelForce(Force):
+    kind = "debye_huckel"
+
+    def __init__(self, k_dh, screening_length, group=0):
+        super().__init__(group)
+        self.k_dh, self.screening_length = float(k_dh), float(screening_length)
+        self.pairs, self.qq = [], []
+
+    def addBond(self, i, j, params):
+        self.pairs.append((int(i), int(j)))
+        self.qq.append(float(params[0]) * float(params[1]))
+
+    def getNumBonds(self):
+        return len(self.qq)
+
+    def _upload(self, ctx):
+        ctx.add_debye_huckel(self._group, np.array(self.pairs, dtype=np.int32).reshape(-1, 2), self.qq, self.k_dh,
+                             self.screening_length)
+
+
+class System:
+    """Light stand-in for openmm.System: particle masses, virtual sites and the list of forces."""
+
+    def __init__(self, masses):
+        self.masses = np.asarray(masses, dtype=float)
+        self.virtual_sites = {}   # site atom -> (p1, p2, p3, w1, w2, w3)
+        self.forces = []
+
+    def getNumParticles(self):
+        return len(self.masses)
+
+    def getParticleMass(self, i):
+        return self.masses[i]
+
+    def setVirtualSite(self, index, site):
+        self.virtual_sites[int(index)] = site
+        self.masses[int(index)] = 0.0
+
+    def isVirtualSite(self, index):
+        return int(index) in self.virtual_sites
+
+    def addForce(self, force):
+        if not isinstance(force, Force):
+            raise TypeError(f"unsupported force object {type(force).__name__}: the MI355X AWSEM engine accepts only the "
+                            "term descriptors returned by openawsem_amd.functionTerms")
+        self.forces.append(force)
+        return len(self.forces) - 1
+
+    def getNumForces(self):
+        return len(self.forces)
+
+    def getForce(self, i):
+        return self.forces[i]
+
+    def getForces(self):
+        return list(self.forces)
+
+    def upload(self, ctx):
+        """Push masses, virtual sites and every force to a fresh `_capi.Context`, then finalize it."""
+        ctx.set_masses(self.masses)
+        if self.virtual_sites:
+            sites = sorted(self.virtual_sites)
+            par = [self.virtual_sites[s][:3] for s in sites]
+            w = [self.virtual_sites[s][3:] for s in sites]
+            ctx.set_virtual_sites(sites, par, w)
+        for f in self.forces:
+            f._upload(ctx)
+        ctx.finalize()
+        return ctx
+
+
+def ThreeParticleAverageSite(p1, p2, p3, w1, w2, w3):
+    return (int(p1), int(p2), int(p3), float(w1), float(w2), float(w3))

@@ -1,0 +1,126 @@
+"""Fragment (associative) memory term.
+
+Mirrors fragment_memory_term of openawsem/functionTerms/templateTerms.py:122-294: per target atom pair a 500-point
+table of weighted Gaussians summed over the memories, evaluated with linear interpolation.  The product is a
+FragmentMemoryForce descriptor; the HIP engine gathers the two neighbouring table entries per bond.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from ..forces import FragmentMemoryForce
+
+
+def read_memory_list(frag_file_list_file):
+    """Rows of a .mem file after its 4 header lines: (gro path, target_start, fragment_start, frag_len, weight)
+    (reference templateTerms.py:183)."""
+    rows = []
+    with open(frag_file_list_file) as fh:
+        lines = fh.readlines()[4:]
+    for line in lines:
+        t = line.split()
+        if len(t) < 5:
+            continue
+        rows.append((t[0], int(t[1]), int(t[2]), int(t[3]), float(t[4])))
+    return rows
+
+
+def read_gro_ca_cb(frag_name, fragment_start, frag_len):
+    """CA/CB atoms of residues [fragment_start, fragment_start+frag_len) from a .gro file: skip 2 lines, whitespace
+    columns (Res_id, Res, Type, i, x, y, z) in nm (reference templateTerms.py:192-193)."""
+    out = []
+    with open(frag_name) as fh:
+        lines = fh.readlines()[2:]
+    for line in lines:
+        t = line.split()
+        if len(t) < 7 or t[2] not in ("CA", "CB"):
+            continue
+        try:
+            res_id = int(t[0])
+        except ValueError:
+            continue
+        if fragment_start <= res_id < fragment_start + frag_len:
+            out.append((res_id, t[2], float(t[4]), float(t[5]), float(t[6])))
+    return out
+
+
+def build_fragment_table(oa, frag_file_list_file, min_seq_sep=3, max_seq_sep=9, fm_well_width=0.1,
+                         frag_table_rmin=0, frag_table_rmax=5, frag_table_dr=0.01):
+    """(pairs[nbonds,2], table[nbonds,500]) restating reference templateTerms.py:154-244."""
+    r_array = np.arange(frag_table_rmin, frag_table_rmax, frag_table_dr)
+    data_dic = {}
+    ca_set, cb_set = set(oa.ca), set(oa.cb)
+    for i in range(oa.natoms):
+        if i in ca_set:
+            data_dic[("CA", 1 + int(oa.resi[i]))] = i      # .mem target residue ids are 1-based and global
+        if i in cb_set:
+            data_dic[("CB", 1 + int(oa.resi[i]))] = i
+    frag_location_pre = os.path.dirname(str(frag_file_list_file))
+    tables = {}
+    for location, target_start, fragment_start, frag_len, weight in read_memory_list(frag_file_list_file):
+        frag = read_gro_ca_cb(os.path.join(frag_location_pre, location), fragment_start, frag_len)
+        for i in range(len(frag)):
+            res_i, type_i, xi, yi, zi = frag[i]
+            for j in range(i, len(frag)):
+                res_j, type_j, xj, yj, zj = frag[j]
+                seq_sep = res_j - res_i
+                if seq_sep > max_seq_sep or seq_sep < min_seq_sep:
+                    continue
+                ti = data_dic.get((type_i, res_i - fragment_start + target_start))
+                tj = data_dic.get((type_j, res_j - fragment_start + target_start))
+                if ti is None or tj is None:     # e.g. a CB of the memory facing a glycine of the target
+                    continue
+                sigma_ij = fm_well_width * seq_sep ** 0.15
+                rm = ((xi - xj) ** 2 + (yi - yj) ** 2 + (zi - zj) ** 2) ** 0.5
+                if tj - ti <= 0:
+                    raise AssertionError("fragment memory pair is not in increasing atom order")
+                g = weight * 1 * np.exp((r_array - rm) ** 2 / (-2.0 * sigma_ij ** 2))
+                key = (ti, tj)
+                if key in tables:
+                    tables[key] += g
+                else:
+                    tables[key] = g
+    pairs = sorted(tables)
+    table = np.array([tables[p] for p in pairs], dtype=np.float64).reshape(len(pairs), len(r_array))
+    return np.array(pairs, dtype=np.int32).reshape(-1, 2), table
+
+
+def fragment_memory_term(oa, k_fm=0.04184, frag_file_list_file="./frag.mem", npy_frag_table="./frag_table.npy",
+                         min_seq_sep=3, max_seq_sep=9, fm_well_width=0.1, UseSavedFragTable=True, caOnly=False,
+                         forceGroup=23):
+    """E = -k_fm * lerp(table[bond], r / 0.01) with the index clamped to 498 (reference templateTerms.py:122-294).
+
+    The reference caches (table, pair set, dict) as a *pickle* under `npy_frag_table`; this engine never unpickles:
+    its cache is a plain ``numpy.savez`` archive under the same name, and a file it cannot read that way is
+    ignored and rebuilt from the .mem/.gro files."""
+    k_fm *= oa.k_awsem
+    frag_table_dr = 0.01
+    frag_table_file = str(npy_frag_table)
+    pairs = table = None
+    if os.path.isfile(frag_table_file) and UseSavedFragTable:
+        try:
+            with np.load(frag_table_file, allow_pickle=False) as z:
+                pairs, table = z["pairs"], z["table"]
+            print(f"Reading Fragment table from {frag_table_file}.")
+            print(f"Fragment table loaded, number of bonds: {len(pairs)}")
+        except Exception:
+            print(f"{frag_table_file} is not a numpy archive written by this engine (the reference writes a pickle, "
+                  "which is never loaded here); rebuilding the table from the memory files.")
+    if pairs is None:
+        print("Loading Fragment files(Gro files)")
+        pairs, table = build_fragment_table(oa, frag_file_list_file, min_seq_sep, max_seq_sep, fm_well_width,
+                                            frag_table_dr=frag_table_dr)
+        try:
+            with open(frag_table_file, "wb") as fh:
+                np.savez(fh, pairs=pairs, table=table)
+        except OSError:
+            pass
+    if caOnly:
+        ca = set(oa.ca)
+        keep = [b for b, (i, j) in enumerate(pairs) if i in ca and j in ca]
+        pairs, table = pairs[keep], table[keep]
+    fm = FragmentMemoryForce(k_fm, pairs, table, frag_table_dr)
+    fm.setForceGroup(forceGroup)
+    return fm

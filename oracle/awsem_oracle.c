@@ -1,0 +1,753 @@
+/*
+ * awsem_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C fp64 CPU restatement of the AWSEM force field as the reference (epochbio/openawsem) configures it on
+ * top of OpenMM, plus OpenMM's LangevinIntegrator update.  It is the checker for the HIP library
+ * (libawsem_hip.so): only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * The arithmetic of the reference's hot path runs inside OpenMM (third-party, un-vendored, version unpinned in
+ * the reference's requirements.txt:5 / setup.py:52), which is not available here; the formulas below are the
+ * algebraic expressions the reference's term factories hand to OpenMM, restated with analytic gradients.
+ * Parity is PINNED by the reference's own golden vectors tests/data/{1brs,1mbn,1ubq,2lyz,2lzm}_energies.csv
+ * (OpenMM Reference platform, 12 frames x 7 non-zero columns each; see tests/test_oracle_golden.py).
+ * Forces, Debye-Hueckel, membrane, standalone burial, z-dependent contact and the Langevin step have no
+ * reference fixture ("parity unpinned"): forces are checked by central finite differences of these energies.
+ *
+ * The exported functions mirror include/awsem_hip.h one to one with the prefix awsem_oracle_.
+ * All paths cited are relative to the reference checkout.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NGROUPS 32
+#define KB 0.00831446261815324 /* kJ/mol/K, OpenMM's BOLTZ */
+
+typedef struct { int group, n; int *pairs; double *r0, *k; } harm_t;
+typedef struct { int group, n; int *atoms; double k, chi0; } chi_t;
+typedef struct { int group, n, nwell; int *atoms; double *wp, *bw; double k; } rama_t;
+typedef struct { int group, nsites, nexcl; int *atom, *cls, *excl; double k, r0; } excl_t;
+typedef struct {
+    int group, nsites, env, min_seq_sep, flags, has_burial;
+    int *atom, *restype, *resid, *chain;
+    double p[32];
+    double gamma[2 * 3 * 400];
+    double bgamma[60];
+} contact_t;
+typedef struct {
+    int group, two_theta, nacc, ndon, nres;
+    int *acc_atoms, *acc_res, *don_atoms, *don_res;
+    double *lambda;
+    double k, r_ON, s_NO, r_OH, s_HO, cutoff;
+} beta_t;
+typedef struct {
+    int group, nacc, ndon, nres;
+    int *acc_atoms, *acc_res, *don_atoms, *don_res;
+    double *gamma;
+    double k, eta, r0, d_i4, cutoff;
+} pap_t;
+typedef struct { int group, n; int *atoms; double *coef; double r_ON, s_NO, r_OH, s_HO; } helical_t;
+typedef struct { int group, n, ntab; int *pairs; double *table; double k, dr; } fm_t;
+typedef struct { int group, n; int *atoms; double *scale; double k, k_m, z_m, center; } memb_t;
+typedef struct { int group, n; int *pairs; double *qq; double k, lam; } dh_t;
+
+enum { T_HARM, T_CHI, T_RAMA, T_EXCL, T_CONTACT, T_BETA, T_PAP, T_HELICAL, T_FM, T_MEMB, T_DH };
+typedef struct { int kind; void* p; } term_t;
+
+typedef struct awsem_oracle_ctx {
+    int natoms, nrep, finalized;
+    double* mass;
+    int nvs; int* vs_site; int* vs_par; double* vs_w;
+    int nterms, cap; term_t* terms;
+    double* pos; /* [rep][natoms][3] */
+    double* vel;
+    int64_t step;
+    int nthreads;
+} ctx_t;
+
+static __thread char g_err[512];
+static int fail(int code, const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); return code; }
+const char* awsem_oracle_last_error(void) { return g_err; }
+const char* awsem_oracle_version(void) { return "awsem_oracle 0.1 fp64-cpu"; }
+
+static void* dup_mem(const void* src, size_t bytes) {
+    void* p = malloc(bytes ? bytes : 1);
+    if (src && bytes) memcpy(p, src, bytes);
+    return p;
+}
+static int check_atoms(ctx_t* c, const int* idx, int n, int allow_neg) {
+    for (int i = 0; i < n; i++) {
+        if (idx[i] < 0) { if (!allow_neg || idx[i] != -1) return 0; }
+        else if (idx[i] >= c->natoms) return 0;
+    }
+    return 1;
+}
+static int add_term(ctx_t* c, int kind, void* p) {
+    if (c->nterms == c->cap) { c->cap = c->cap ? 2 * c->cap : 16; c->terms = realloc(c->terms, c->cap * sizeof(term_t)); }
+    c->terms[c->nterms].kind = kind; c->terms[c->nterms].p = p; c->nterms++;
+    return 0;
+}
+#define CHECK_BUILD(c, group) \
+    if (!(c)) return fail(-1, "null handle"); \
+    if ((c)->finalized) return fail(-2, "system already finalized"); \
+    if ((group) < 0 || (group) >= NGROUPS) return fail(-1, "force group out of range 0..31");
+
+int awsem_oracle_create(int natoms, int nrep, int device, int precision, ctx_t** out) {
+    (void)device; (void)precision;
+    if (natoms <= 0 || nrep <= 0 || !out) return fail(-1, "awsem_create: natoms and n_replicas must be positive");
+    ctx_t* c = calloc(1, sizeof(ctx_t));
+    c->natoms = natoms; c->nrep = nrep;
+    c->mass = calloc(natoms, sizeof(double));
+    for (int i = 0; i < natoms; i++) c->mass[i] = 1.0;
+    c->pos = calloc((size_t)nrep * natoms * 3, sizeof(double));
+    c->vel = calloc((size_t)nrep * natoms * 3, sizeof(double));
+    c->nthreads = 1;
+    *out = c;
+    return 0;
+}
+
+static void free_term(term_t* t) {
+    void* p = t->p;
+    switch (t->kind) {
+    case T_HARM: { harm_t* x = p; free(x->pairs); free(x->r0); free(x->k); } break;
+    case T_CHI: { chi_t* x = p; free(x->atoms); } break;
+    case T_RAMA: { rama_t* x = p; free(x->atoms); free(x->wp); free(x->bw); } break;
+    case T_EXCL: { excl_t* x = p; free(x->atom); free(x->cls); free(x->excl); } break;
+    case T_CONTACT: { contact_t* x = p; free(x->atom); free(x->restype); free(x->resid); free(x->chain); } break;
+    case T_BETA: { beta_t* x = p; free(x->acc_atoms); free(x->acc_res); free(x->don_atoms); free(x->don_res); free(x->lambda); } break;
+    case T_PAP: { pap_t* x = p; free(x->acc_atoms); free(x->acc_res); free(x->don_atoms); free(x->don_res); free(x->gamma); } break;
+    case T_HELICAL: { helical_t* x = p; free(x->atoms); free(x->coef); } break;
+    case T_FM: { fm_t* x = p; free(x->pairs); free(x->table); } break;
+    case T_MEMB: { memb_t* x = p; free(x->atoms); free(x->scale); } break;
+    case T_DH: { dh_t* x = p; free(x->pairs); free(x->qq); } break;
+    }
+    free(p);
+}
+void awsem_oracle_destroy(ctx_t* c) {
+    if (!c) return;
+    for (int i = 0; i < c->nterms; i++) free_term(&c->terms[i]);
+    free(c->terms); free(c->mass); free(c->vs_site); free(c->vs_par); free(c->vs_w); free(c->pos); free(c->vel);
+    free(c);
+}
+int awsem_oracle_set_threads(ctx_t* c, int n) { if (!c || n < 1) return fail(-1, "bad thread count"); c->nthreads = n; return 0; }
+
+int awsem_oracle_set_masses(ctx_t* c, const double* m, int natoms) {
+    CHECK_BUILD(c, 0);
+    if (!m || natoms != c->natoms) return fail(-1, "set_masses: natoms mismatch");
+    for (int i = 0; i < natoms; i++) { if (!(m[i] >= 0)) return fail(-1, "set_masses: negative mass"); c->mass[i] = m[i]; }
+    return 0;
+}
+int awsem_oracle_set_virtual_sites(ctx_t* c, int n, const int* site, const int* par, const double* w) {
+    CHECK_BUILD(c, 0);
+    if (n < 0 || (n && (!site || !par || !w))) return fail(-1, "set_virtual_sites: bad arguments");
+    if (!check_atoms(c, site, n, 0) || !check_atoms(c, par, 3 * n, 0)) return fail(-1, "set_virtual_sites: atom index out of range");
+    free(c->vs_site); free(c->vs_par); free(c->vs_w);
+    c->nvs = n; c->vs_site = dup_mem(site, n * sizeof(int)); c->vs_par = dup_mem(par, 3 * n * sizeof(int));
+    c->vs_w = dup_mem(w, 3 * n * sizeof(double));
+    return 0;
+}
+
+int awsem_oracle_add_harmonic_bonds(ctx_t* c, int group, int n, const int* pairs, const double* r0, const double* k) {
+    CHECK_BUILD(c, group);
+    if (n < 0 || (n && (!pairs || !r0 || !k)) || !check_atoms(c, pairs, 2 * n, 0)) return fail(-1, "add_harmonic_bonds: bad arguments");
+    harm_t* t = calloc(1, sizeof *t); t->group = group; t->n = n;
+    t->pairs = dup_mem(pairs, 2 * n * sizeof(int)); t->r0 = dup_mem(r0, n * sizeof(double)); t->k = dup_mem(k, n * sizeof(double));
+    return add_term(c, T_HARM, t);
+}
+int awsem_oracle_add_chi(ctx_t* c, int group, int n, const int* atoms, double k, double chi0) {
+    CHECK_BUILD(c, group);
+    if (n < 0 || (n && !atoms) || !check_atoms(c, atoms, 4 * n, 0)) return fail(-1, "add_chi: bad arguments");
+    chi_t* t = calloc(1, sizeof *t); t->group = group; t->n = n; t->atoms = dup_mem(atoms, 4 * n * sizeof(int)); t->k = k; t->chi0 = chi0;
+    return add_term(c, T_CHI, t);
+}
+int awsem_oracle_add_rama(ctx_t* c, int group, int n, const int* atoms, int nwell, const double* wp, const double* bw, double k) {
+    CHECK_BUILD(c, group);
+    if (n < 0 || nwell < 1 || nwell > 8 || !wp || (n && !atoms) || !check_atoms(c, atoms, 5 * n, 0)) return fail(-1, "add_rama: bad arguments");
+    rama_t* t = calloc(1, sizeof *t); t->group = group; t->n = n; t->nwell = nwell; t->k = k;
+    t->atoms = dup_mem(atoms, 5 * n * sizeof(int)); t->wp = dup_mem(wp, 6 * nwell * sizeof(double));
+    t->bw = malloc(((size_t)n * nwell + 1) * sizeof(double));
+    for (int i = 0; i < n * nwell; i++) t->bw[i] = bw ? bw[i] : 1.0;
+    return add_term(c, T_RAMA, t);
+}
+int awsem_oracle_add_excl(ctx_t* c, int group, int nsites, const int* atom, const int* cls, int nexcl, const int* excl, double k, double r0) {
+    CHECK_BUILD(c, group);
+    if (nsites < 0 || nexcl < 0 || (nsites && (!atom || !cls)) || (nexcl && !excl) || !check_atoms(c, atom, nsites, 0) || !check_atoms(c, excl, 2 * nexcl, 0))
+        return fail(-1, "add_excl: bad arguments");
+    excl_t* t = calloc(1, sizeof *t); t->group = group; t->nsites = nsites; t->nexcl = nexcl; t->k = k; t->r0 = r0;
+    t->atom = dup_mem(atom, nsites * sizeof(int)); t->cls = dup_mem(cls, nsites * sizeof(int)); t->excl = dup_mem(excl, 2 * nexcl * sizeof(int));
+    return add_term(c, T_EXCL, t);
+}
+int awsem_oracle_add_contact(ctx_t* c, int group, int nsites, const int* atom, const int* restype, const int* resid, const int* chain,
+                             int env, int min_seq_sep, int flags, const double* dparams, const double* gamma, const double* bgamma) {
+    CHECK_BUILD(c, group);
+    if (nsites < 0 || !dparams || (nsites && (!atom || !restype || !resid || !chain)) || !check_atoms(c, atom, nsites, 0) || env < 0 || env > 1)
+        return fail(-1, "add_contact: bad arguments");
+    if (!(flags & 2) && !gamma) return fail(-1, "add_contact: gamma table required");
+    for (int i = 0; i < nsites; i++) if (restype[i] < 0 || restype[i] >= 20) return fail(-1, "add_contact: residue type out of range 0..19");
+    contact_t* t = calloc(1, sizeof *t); t->group = group; t->nsites = nsites; t->env = env; t->min_seq_sep = min_seq_sep; t->flags = flags;
+    t->atom = dup_mem(atom, nsites * sizeof(int)); t->restype = dup_mem(restype, nsites * sizeof(int));
+    t->resid = dup_mem(resid, nsites * sizeof(int)); t->chain = dup_mem(chain, nsites * sizeof(int));
+    memcpy(t->p, dparams, 20 * sizeof(double));
+    if (gamma) memcpy(t->gamma, gamma, sizeof t->gamma);
+    t->has_burial = bgamma != NULL;
+    if (bgamma) memcpy(t->bgamma, bgamma, sizeof t->bgamma);
+    return add_term(c, T_CONTACT, t);
+}
+int awsem_oracle_add_hbond_beta(ctx_t* c, int group, int two_theta, int nacc, const int* acc_atoms, const int* acc_res, int ndon,
+                                const int* don_atoms, const int* don_res, int nres, const double* lambda, double k, double r_ON,
+                                double s_NO, double r_OH, double s_HO, double cutoff) {
+    CHECK_BUILD(c, group);
+    if (nacc < 0 || ndon < 0 || nres <= 0 || !lambda || (nacc && (!acc_atoms || !acc_res)) || (ndon && (!don_atoms || !don_res)))
+        return fail(-1, "add_hbond_beta: bad arguments");
+    if (!check_atoms(c, acc_atoms, 3 * nacc, 1) || !check_atoms(c, don_atoms, 3 * ndon, 1)) return fail(-1, "add_hbond_beta: atom index out of range");
+    for (int i = 0; i < nacc; i++) {
+        if (acc_res[i] < 0 || acc_res[i] >= nres || acc_atoms[3 * i] < 0) return fail(-1, "add_hbond_beta: bad acceptor");
+        if (two_theta && (acc_atoms[3 * i + 1] < 0 || acc_atoms[3 * i + 2] < 0)) return fail(-1, "add_hbond_beta: acceptor needs a2,a3");
+    }
+    for (int i = 0; i < ndon; i++) {
+        if (don_res[i] < 0 || don_res[i] >= nres || don_atoms[3 * i] < 0 || don_atoms[3 * i + 1] < 0) return fail(-1, "add_hbond_beta: bad donor");
+        if (two_theta && don_atoms[3 * i + 2] < 0) return fail(-1, "add_hbond_beta: donor needs d3");
+    }
+    beta_t* t = calloc(1, sizeof *t); t->group = group; t->two_theta = two_theta; t->nacc = nacc; t->ndon = ndon; t->nres = nres;
+    t->acc_atoms = dup_mem(acc_atoms, 3 * nacc * sizeof(int)); t->acc_res = dup_mem(acc_res, nacc * sizeof(int));
+    t->don_atoms = dup_mem(don_atoms, 3 * ndon * sizeof(int)); t->don_res = dup_mem(don_res, ndon * sizeof(int));
+    t->lambda = dup_mem(lambda, (size_t)nres * nres * sizeof(double));
+    t->k = k; t->r_ON = r_ON; t->s_NO = s_NO; t->r_OH = r_OH; t->s_HO = s_HO; t->cutoff = cutoff;
+    return add_term(c, T_BETA, t);
+}
+int awsem_oracle_add_hbond_pap(ctx_t* c, int group, int nacc, const int* acc_atoms, const int* acc_res, int ndon, const int* don_atoms,
+                               const int* don_res, int nres, const double* gamma, double k, double eta, double r0, double d_i4, double cutoff) {
+    CHECK_BUILD(c, group);
+    if (nacc < 0 || ndon < 0 || nres <= 0 || !gamma || (nacc && (!acc_atoms || !acc_res)) || (ndon && (!don_atoms || !don_res)))
+        return fail(-1, "add_hbond_pap: bad arguments");
+    if (!check_atoms(c, acc_atoms, 2 * nacc, 0) || !check_atoms(c, don_atoms, 2 * ndon, 0)) return fail(-1, "add_hbond_pap: atom index out of range");
+    for (int i = 0; i < nacc; i++) if (acc_res[i] < 0 || acc_res[i] >= nres) return fail(-1, "add_hbond_pap: bad acceptor residue");
+    for (int i = 0; i < ndon; i++) if (don_res[i] < 0 || don_res[i] >= nres) return fail(-1, "add_hbond_pap: bad donor residue");
+    pap_t* t = calloc(1, sizeof *t); t->group = group; t->nacc = nacc; t->ndon = ndon; t->nres = nres;
+    t->acc_atoms = dup_mem(acc_atoms, 2 * nacc * sizeof(int)); t->acc_res = dup_mem(acc_res, nacc * sizeof(int));
+    t->don_atoms = dup_mem(don_atoms, 2 * ndon * sizeof(int)); t->don_res = dup_mem(don_res, ndon * sizeof(int));
+    t->gamma = dup_mem(gamma, (size_t)nres * nres * sizeof(double));
+    t->k = k; t->eta = eta; t->r0 = r0; t->d_i4 = d_i4; t->cutoff = cutoff;
+    return add_term(c, T_PAP, t);
+}
+int awsem_oracle_add_helical(ctx_t* c, int group, int n, const int* atoms, const double* coef, double r_ON, double s_NO, double r_OH, double s_HO) {
+    CHECK_BUILD(c, group);
+    if (n < 0 || (n && (!atoms || !coef)) || !check_atoms(c, atoms, 3 * n, 0)) return fail(-1, "add_helical: bad arguments");
+    helical_t* t = calloc(1, sizeof *t); t->group = group; t->n = n; t->atoms = dup_mem(atoms, 3 * n * sizeof(int));
+    t->coef = dup_mem(coef, n * sizeof(double)); t->r_ON = r_ON; t->s_NO = s_NO; t->r_OH = r_OH; t->s_HO = s_HO;
+    return add_term(c, T_HELICAL, t);
+}
+int awsem_oracle_add_fragment_memory(ctx_t* c, int group, int nb, const int* pairs, int ntab, const double* table, double k, double dr) {
+    CHECK_BUILD(c, group);
+    if (nb < 0 || ntab < 2 || !(dr > 0) || (nb && (!pairs || !table)) || !check_atoms(c, pairs, 2 * nb, 0)) return fail(-1, "add_fragment_memory: bad arguments");
+    fm_t* t = calloc(1, sizeof *t); t->group = group; t->n = nb; t->ntab = ntab; t->k = k; t->dr = dr;
+    t->pairs = dup_mem(pairs, 2 * nb * sizeof(int)); t->table = dup_mem(table, (size_t)nb * ntab * sizeof(double));
+    return add_term(c, T_FM, t);
+}
+int awsem_oracle_add_membrane(ctx_t* c, int group, int n, const int* atoms, const double* scale, double k, double k_m, double z_m, double center) {
+    CHECK_BUILD(c, group);
+    if (n < 0 || (n && (!atoms || !scale)) || !check_atoms(c, atoms, n, 0)) return fail(-1, "add_membrane: bad arguments");
+    memb_t* t = calloc(1, sizeof *t); t->group = group; t->n = n; t->atoms = dup_mem(atoms, n * sizeof(int)); t->scale = dup_mem(scale, n * sizeof(double));
+    t->k = k; t->k_m = k_m; t->z_m = z_m; t->center = center;
+    return add_term(c, T_MEMB, t);
+}
+int awsem_oracle_add_debye_huckel(ctx_t* c, int group, int n, const int* pairs, const double* qq, double k, double lam) {
+    CHECK_BUILD(c, group);
+    if (n < 0 || !(lam > 0) || (n && (!pairs || !qq)) || !check_atoms(c, pairs, 2 * n, 0)) return fail(-1, "add_debye_huckel: bad arguments");
+    dh_t* t = calloc(1, sizeof *t); t->group = group; t->n = n; t->pairs = dup_mem(pairs, 2 * n * sizeof(int)); t->qq = dup_mem(qq, n * sizeof(double));
+    t->k = k; t->lam = lam;
+    return add_term(c, T_DH, t);
+}
+int awsem_oracle_finalize(ctx_t* c) { if (!c) return fail(-1, "null handle"); c->finalized = 1; return 0; }
+
+/* ------------------------------------------------------------------ state */
+#define CHECK_RUN(c) if (!(c)) return fail(-1, "null handle"); if (!(c)->finalized) return fail(-2, "system not finalized");
+int awsem_oracle_set_positions(ctx_t* c, int rep, const double* xyz, int natoms) {
+    CHECK_RUN(c);
+    if (!xyz || natoms != c->natoms || rep < -1 || rep >= c->nrep) return fail(-1, "set_positions: bad arguments");
+    size_t n = (size_t)natoms * 3;
+    if (rep >= 0) memcpy(c->pos + rep * n, xyz, n * sizeof(double));
+    else for (int r = 0; r < c->nrep; r++) memcpy(c->pos + r * n, xyz, n * sizeof(double));
+    return 0;
+}
+int awsem_oracle_get_positions(ctx_t* c, int rep, double* xyz, int natoms) {
+    CHECK_RUN(c);
+    if (!xyz || natoms != c->natoms || rep < 0 || rep >= c->nrep) return fail(-1, "get_positions: bad arguments");
+    memcpy(xyz, c->pos + (size_t)rep * natoms * 3, (size_t)natoms * 3 * sizeof(double));
+    return 0;
+}
+int awsem_oracle_set_velocities(ctx_t* c, int rep, const double* v, int natoms) {
+    CHECK_RUN(c);
+    if (!v || natoms != c->natoms || rep < -1 || rep >= c->nrep) return fail(-1, "set_velocities: bad arguments");
+    size_t n = (size_t)natoms * 3;
+    if (rep >= 0) memcpy(c->vel + rep * n, v, n * sizeof(double));
+    else for (int r = 0; r < c->nrep; r++) memcpy(c->vel + r * n, v, n * sizeof(double));
+    return 0;
+}
+int awsem_oracle_get_velocities(ctx_t* c, int rep, double* v, int natoms) {
+    CHECK_RUN(c);
+    if (!v || natoms != c->natoms || rep < 0 || rep >= c->nrep) return fail(-1, "get_velocities: bad arguments");
+    memcpy(v, c->vel + (size_t)rep * natoms * 3, (size_t)natoms * 3 * sizeof(double));
+    return 0;
+}
+/* ThreeParticleAverageSite: x = w1 x1 + w2 x2 + w3 x3 (openAWSEM.py:685-696) */
+static void virtual_sites(const ctx_t* c, double* x) {
+    for (int i = 0; i < c->nvs; i++) {
+        const int* p = c->vs_par + 3 * i; const double* w = c->vs_w + 3 * i; double* s = x + 3 * c->vs_site[i];
+        for (int d = 0; d < 3; d++) s[d] = w[0] * x[3 * p[0] + d] + w[1] * x[3 * p[1] + d] + w[2] * x[3 * p[2] + d];
+    }
+}
+int awsem_oracle_compute_virtual_sites(ctx_t* c) {
+    CHECK_RUN(c);
+    for (int r = 0; r < c->nrep; r++) virtual_sites(c, c->pos + (size_t)r * c->natoms * 3);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ math helpers */
+static inline void sub3(const double* a, const double* b, double* o) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
+static inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cross3(const double* a, const double* b, double* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static inline double dist(const double* x, int i, int j, double* d) { sub3(x + 3 * i, x + 3 * j, d); return sqrt(dot3(d, d)); }
+/* adds the force of a pair potential with derivative dEdr along d = x_i - x_j (|d| = r) */
+static inline void pair_force(double* f, int i, int j, const double* d, double r, double dEdr) {
+    if (!f) return;
+    double s = -dEdr / r;
+    for (int k = 0; k < 3; k++) { f[3 * i + k] += s * d[k]; f[3 * j + k] -= s * d[k]; }
+}
+static inline double sech2(double x) { double t = tanh(x); return 1.0 - t * t; }
+
+/* IUPAC dihedral of p1..p4 and its gradient (OpenMM's dihedral(p1,p2,p3,p4): basicTerms.py:300-301). */
+static double dihedral(const double* x, const int* a, double g[4][3]) {
+    double F[3], G[3], H[3], A[3], B[3];
+    sub3(x + 3 * a[0], x + 3 * a[1], F); sub3(x + 3 * a[1], x + 3 * a[2], G); sub3(x + 3 * a[3], x + 3 * a[2], H);
+    cross3(F, G, A); cross3(H, G, B);
+    double A2 = dot3(A, A), B2 = dot3(B, B), Gn = sqrt(dot3(G, G));
+    double cosphi = dot3(A, B) / sqrt(A2 * B2);
+    double C[3]; cross3(B, A, C);
+    double sinphi = dot3(C, G) / (sqrt(A2 * B2) * Gn);
+    double phi = atan2(sinphi, cosphi);
+    (void)cosphi;
+    if (g) {
+        double FG = dot3(F, G), HG = dot3(H, G);
+        for (int k = 0; k < 3; k++) {
+            double dA = -Gn / A2 * A[k], dB = Gn / B2 * B[k];
+            double t = FG / (A2 * Gn) * A[k] - HG / (B2 * Gn) * B[k];
+            g[0][k] = dA; g[3][k] = dB; g[1][k] = -dA + t; g[2][k] = -dB - t;
+        }
+    }
+    return phi;
+}
+
+/* ------------------------------------------------------------------ term evaluation */
+static double eval_harm(const harm_t* t, const double* x, double* f) {
+    double e = 0, d[3];
+    for (int b = 0; b < t->n; b++) {
+        int i = t->pairs[2 * b], j = t->pairs[2 * b + 1];
+        double r = dist(x, i, j, d), dr = r - t->r0[b];
+        e += 0.5 * t->k[b] * dr * dr;            /* OpenMM HarmonicBondForce */
+        pair_force(f, i, j, d, r, t->k[b] * dr);
+    }
+    return e;
+}
+/* basicTerms.py:119-129 */
+static double eval_chi(const chi_t* t, const double* x, double* f) {
+    double e = 0;
+    for (int b = 0; b < t->n; b++) {
+        const int* a = t->atoms + 4 * b;
+        double u[3], v[3], w[3], uv[3], vw[3], wu[3];
+        sub3(x + 3 * a[0], x + 3 * a[1], u); sub3(x + 3 * a[2], x + 3 * a[0], v); sub3(x + 3 * a[0], x + 3 * a[3], w);
+        cross3(u, v, uv);
+        double u2 = dot3(u, u), v2 = dot3(v, v), w2 = dot3(w, w);
+        double norm = 1.0 / sqrt(u2 * v2 * w2);
+        double chi = dot3(uv, w) * norm;
+        double dchi = chi - t->chi0;
+        e += t->k * dchi * dchi;
+        if (f) {
+            cross3(v, w, vw); cross3(w, u, wu);
+            double c = -2.0 * t->k * dchi;
+            for (int k = 0; k < 3; k++) {
+                double gu = vw[k] * norm - chi * u[k] / u2, gv = wu[k] * norm - chi * v[k] / v2, gw = uv[k] * norm - chi * w[k] / w2;
+                f[3 * a[0] + k] += c * (gu - gv + gw); f[3 * a[1] + k] += c * (-gu); f[3 * a[2] + k] += c * gv; f[3 * a[3] + k] += c * (-gw);
+            }
+        }
+    }
+    return e;
+}
+/* basicTerms.py:297-303 (rama), 355-361 (proline), 414-420 (ssweight) */
+static double eval_rama(const rama_t* t, const double* x, double* f) {
+    double e = 0, g1[4][3], g2[4][3];
+    for (int b = 0; b < t->n; b++) {
+        const int* a = t->atoms + 5 * b;
+        double phi = dihedral(x, a, f ? g1 : NULL), psi = dihedral(x, a + 1, f ? g2 : NULL);
+        double dEdphi = 0, dEdpsi = 0;
+        for (int w = 0; w < t->nwell; w++) {
+            const double* p = t->wp + 6 * w;
+            double W = p[0] * t->bw[(size_t)b * t->nwell + w];
+            double cp = cos(phi - p[3]) - 1, cs = cos(psi - p[5]) - 1;
+            double ex = exp(-p[1] * (p[2] * cp * cp + p[4] * cs * cs));
+            e += -t->k * W * ex;
+            dEdphi += -t->k * W * ex * 2 * p[1] * p[2] * cp * sin(phi - p[3]);
+            dEdpsi += -t->k * W * ex * 2 * p[1] * p[4] * cs * sin(psi - p[5]);
+        }
+        if (f) for (int m = 0; m < 4; m++) for (int k = 0; k < 3; k++) {
+            f[3 * a[m] + k] -= dEdphi * g1[m][k];
+            f[3 * a[m + 1] + k] -= dEdpsi * g2[m][k];
+        }
+    }
+    return e;
+}
+/* basicTerms.py:168-190 */
+static double eval_excl(const excl_t* t, const double* x, double* f) {
+    double e = 0, d[3];
+    for (int i = 0; i < t->nsites; i++) for (int j = i + 1; j < t->nsites; j++) {
+        if (t->cls[i] != t->cls[j]) continue;
+        int a = t->atom[i], b = t->atom[j];
+        if (a == b) continue;
+        double r = dist(x, a, b, d);
+        if (r >= t->r0) continue;
+        int ex = 0;
+        for (int q = 0; q < t->nexcl; q++) {
+            int p0 = t->excl[2 * q], p1 = t->excl[2 * q + 1];
+            if ((p0 == a && p1 == b) || (p0 == b && p1 == a)) { ex = 1; break; }
+        }
+        if (ex) continue;
+        e += t->k * (r - t->r0) * (r - t->r0);
+        pair_force(f, a, b, d, r, 2 * t->k * (r - t->r0));
+    }
+    return e;
+}
+/* theta(r;a,b) = 1/4 (1+tanh(eta(r-a)))(1+tanh(eta(b-r))) and d/dr  (contactTerms.py:255,322-323) */
+static inline double theta_sw(double r, double a, double b, double eta, double* dth) {
+    double t1 = tanh(eta * (r - a)), t2 = tanh(eta * (b - r));
+    if (dth) *dth = 0.25 * eta * ((1 - t1 * t1) * (1 + t2) - (1 + t1) * (1 - t2 * t2));
+    return 0.25 * (1 + t1) * (1 + t2);
+}
+/* contactTerms.py:245-351 (CustomGBForce: rho pass, pair energy, burial single-particle energy) */
+static double eval_contact(const contact_t* t, const double* x, double* f) {
+    const double* p = t->p;
+    const double kc = p[0], rmin = p[1], rmax = p[2], rminII = p[3], rmaxII = p[4], eta = p[5], eta_s = p[6], rho0 = p[7];
+    const double cutoff = (t->flags & 4) ? 1e300 : p[8], kappa = p[9], eta_sw = p[16], z_m = p[17], zc = p[18], kb = p[19];
+    const int n = t->nsites, zdep = t->flags & 1, burial_only = t->flags & 2;
+    double* rho = calloc(n, sizeof(double)); double* dEdrho = calloc(n, sizeof(double));
+    double* alpha = calloc(n, sizeof(double)); double* dalpha = calloc(n, sizeof(double));
+    double e = 0, d[3];
+    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) {
+        if (abs(t->resid[i] - t->resid[j]) < 2) continue;      /* step(abs(resId1-resId2)-2) */
+        double r = dist(x, t->atom[i], t->atom[j], d);
+        if (r >= cutoff) continue;
+        double th = theta_sw(r, rmin, rmax, eta, NULL);
+        rho[i] += th; rho[j] += th;
+    }
+    if (zdep) for (int i = 0; i < n; i++) {
+        double z = x[3 * t->atom[i] + 2] - zc;
+        alpha[i] = 0.5 * tanh(eta_sw * (z + z_m)) + 0.5 * tanh(eta_sw * (z_m - z));
+        dalpha[i] = 0.5 * eta_sw * (sech2(eta_sw * (z + z_m)) - sech2(eta_sw * (z_m - z)));
+    }
+    if (!burial_only) for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) {
+        int same = t->chain[i] == t->chain[j];
+        if (same && abs(t->resid[i] - t->resid[j]) < t->min_seq_sep) continue;   /* res_table */
+        double r = dist(x, t->atom[i], t->atom[j], d);
+        if (r >= cutoff) continue;
+        double dth1, dth2;
+        double th1 = theta_sw(r, rmin, rmax, eta, &dth1), th2 = theta_sw(r, rminII, rmaxII, eta, &dth2);
+        double ti = tanh(eta_s * (rho[i] - rho0)), tj = tanh(eta_s * (rho[j] - rho0));
+        double si = 0.5 * (1 - ti), sj = 0.5 * (1 - tj), sw = si * sj;
+        double dsi = -0.5 * eta_s * (1 - ti * ti), dsj = -0.5 * eta_s * (1 - tj * tj);
+        int ty = t->restype[i] * 20 + t->restype[j];
+        double E = 0, dEdr = 0, dEdsw = 0;
+        if (!zdep) {
+            const double* g = t->gamma + t->env * 1200;
+            double gd = g[ty], gp = g[400 + ty], gw = g[800 + ty];
+            E = -kc * (gd * th1 + th2 * (sw * gw + (1 - sw) * gp));
+            dEdr = -kc * (gd * dth1 + dth2 * (sw * gw + (1 - sw) * gp));
+            dEdsw = -kc * th2 * (gw - gp);
+        } else {
+            const double *g0 = t->gamma, *g1 = t->gamma + 1200;
+            double W = -kc * (g0[ty] * th1 + th2 * (sw * g0[800 + ty] + (1 - sw) * g0[400 + ty]));
+            double M = -kc * (g1[ty] * th1 + th2 * (sw * g1[800 + ty] + (1 - sw) * g1[400 + ty]));
+            double dW = -kc * (g0[ty] * dth1 + dth2 * (sw * g0[800 + ty] + (1 - sw) * g0[400 + ty]));
+            double dM = -kc * (g1[ty] * dth1 + dth2 * (sw * g1[800 + ty] + (1 - sw) * g1[400 + ty]));
+            double aa = alpha[i] * alpha[j];
+            E = (1 - aa) * W + aa * M;
+            dEdr = (1 - aa) * dW + aa * dM;
+            dEdsw = (1 - aa) * (-kc * th2 * (g0[800 + ty] - g0[400 + ty])) + aa * (-kc * th2 * (g1[800 + ty] - g1[400 + ty]));
+            if (f) {
+                f[3 * t->atom[i] + 2] -= (M - W) * dalpha[i] * alpha[j];
+                f[3 * t->atom[j] + 2] -= (M - W) * alpha[i] * dalpha[j];
+            }
+        }
+        e += E;
+        dEdrho[i] += dEdsw * dsi * sj; dEdrho[j] += dEdsw * si * dsj;
+        pair_force(f, t->atom[i], t->atom[j], d, r, dEdr);
+    }
+    if (t->has_burial) for (int i = 0; i < n; i++) for (int m = 0; m < 3; m++) {   /* contactTerms.py:343-351 */
+        double gb = t->bgamma[t->restype[i] * 3 + m], lo = p[10 + m], hi = p[13 + m];
+        double ta = tanh(kappa * (rho[i] - lo)), tb = tanh(kappa * (hi - rho[i]));
+        e += -0.5 * kb * gb * (ta + tb);
+        dEdrho[i] += -0.5 * kb * gb * kappa * ((1 - ta * ta) - (1 - tb * tb));
+    }
+    if (f) for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) {           /* chain rule through rho */
+        if (abs(t->resid[i] - t->resid[j]) < 2) continue;
+        double r = dist(x, t->atom[i], t->atom[j], d);
+        if (r >= cutoff) continue;
+        double dth; theta_sw(r, rmin, rmax, eta, &dth);
+        pair_force(f, t->atom[i], t->atom[j], d, r, (dEdrho[i] + dEdrho[j]) * dth);
+    }
+    free(rho); free(dEdrho); free(alpha); free(dalpha);
+    return e;
+}
+/* theta(x;y,z) of hydrogenBondTerms.py:447 with gradient coefficients wrt the two distances */
+static inline double hb_theta(double r1, double r2, double r_ON, double s_NO, double r_OH, double s_HO, double* d1, double* d2) {
+    double th = exp(-(r1 - r_ON) * (r1 - r_ON) / (2 * s_NO * s_NO) - (r2 - r_OH) * (r2 - r_OH) / (2 * s_HO * s_HO));
+    *d1 = -th * (r1 - r_ON) / (s_NO * s_NO); *d2 = -th * (r2 - r_OH) / (s_HO * s_HO);
+    return th;
+}
+/* hydrogenBondTerms.py:456-473 (beta_1), 522-536 (beta_2), 588-606 (beta_3) */
+static double eval_beta(const beta_t* t, const double* x, double* f) {
+    double e = 0, dON[3], dOH[3], d2N[3], d2H[3];
+    for (int ia = 0; ia < t->nacc; ia++) for (int id = 0; id < t->ndon; id++) {
+        const int* A = t->acc_atoms + 3 * ia; const int* D = t->don_atoms + 3 * id;
+        double rON = dist(x, A[0], D[0], dON);
+        if (rON >= t->cutoff) continue;
+        double lam = t->lambda[(size_t)t->don_res[id] * t->nres + t->acc_res[ia]];
+        if (lam == 0.0) continue;
+        double rOH = dist(x, A[0], D[1], dOH), g1, g2, h1 = 0, h2 = 0, r2N = 0, r2H = 0;
+        double th1 = hb_theta(rON, rOH, t->r_ON, t->s_NO, t->r_OH, t->s_HO, &g1, &g2), th2 = 1.0;
+        if (t->two_theta) {
+            r2N = dist(x, D[2], A[1], d2N); r2H = dist(x, D[2], A[2], d2H);
+            th2 = hb_theta(r2N, r2H, t->r_ON, t->s_NO, t->r_OH, t->s_HO, &h1, &h2);
+        }
+        double c = -t->k * lam;
+        e += c * th1 * th2;
+        if (f) {
+            pair_force(f, A[0], D[0], dON, rON, c * g1 * th2);
+            pair_force(f, A[0], D[1], dOH, rOH, c * g2 * th2);
+            if (t->two_theta) {
+                pair_force(f, D[2], A[1], d2N, r2N, c * th1 * h1);
+                pair_force(f, D[2], A[2], d2H, r2H, c * th1 * h2);
+            }
+        }
+    }
+    return e;
+}
+/* hydrogenBondTerms.py:660-690 (pap_1), 739-758 (pap_2) */
+static double eval_pap(const pap_t* t, const double* x, double* f) {
+    double e = 0, d1[3], d2[3], d3[3];
+    for (int ia = 0; ia < t->nacc; ia++) for (int id = 0; id < t->ndon; id++) {
+        const int* A = t->acc_atoms + 2 * ia; const int* D = t->don_atoms + 2 * id;
+        double r1 = dist(x, A[0], D[0], d1);
+        if (r1 >= t->cutoff) continue;
+        double gam = t->gamma[(size_t)t->don_res[id] * t->nres + t->acc_res[ia]];
+        if (gam == 0.0) continue;
+        double r2 = dist(x, A[1], D[1], d2), r3 = dist(x, A[0], A[1], d3);
+        double t1 = tanh(t->eta * (t->r0 - r1)), t2 = tanh(t->eta * (t->r0 - r2)), t3 = tanh(t->eta * (r3 - t->d_i4));
+        double a1 = 0.5 * (1 + t1), a2 = 0.5 * (1 + t2), a3 = 0.5 * (1 + t3);
+        double c = -t->k * gam;
+        e += c * a1 * a2 * a3;
+        if (f) {
+            pair_force(f, A[0], D[0], d1, r1, c * (-0.5 * t->eta * (1 - t1 * t1)) * a2 * a3);
+            pair_force(f, A[1], D[1], d2, r2, c * a1 * (-0.5 * t->eta * (1 - t2 * t2)) * a3);
+            pair_force(f, A[0], A[1], d3, r3, c * a1 * a2 * (0.5 * t->eta * (1 - t3 * t3)));
+        }
+    }
+    return e;
+}
+/* hydrogenBondTerms.py:818-829 */
+static double eval_helical(const helical_t* t, const double* x, double* f) {
+    double e = 0, d1[3], d2[3];
+    for (int b = 0; b < t->n; b++) {
+        const int* a = t->atoms + 3 * b;
+        double r1 = dist(x, a[0], a[1], d1), r2 = dist(x, a[0], a[2], d2), g1, g2;
+        double th = hb_theta(r1, r2, t->r_ON, t->s_NO, t->r_OH, t->s_HO, &g1, &g2);
+        e += -t->coef[b] * th;
+        pair_force(f, a[0], a[1], d1, r1, -t->coef[b] * g1);
+        pair_force(f, a[0], a[2], d2, r2, -t->coef[b] * g2);
+    }
+    return e;
+}
+/* templateTerms.py:273-281 */
+static double eval_fm(const fm_t* t, const double* x, double* f) {
+    double e = 0, d[3];
+    for (int b = 0; b < t->n; b++) {
+        int i = t->pairs[2 * b], j = t->pairs[2 * b + 1];
+        double r = dist(x, i, j, d);
+        double fi = floor(r / t->dr);
+        int i1 = fi > t->ntab - 2 ? t->ntab - 2 : (int)fi;
+        double v1 = t->table[(size_t)b * t->ntab + i1], v2 = t->table[(size_t)b * t->ntab + i1 + 1];
+        double r1 = t->dr * i1, r2 = t->dr * (i1 + 1);
+        e += -t->k * ((v2 - v1) * r + v1 * r2 - v2 * r1) / (r2 - r1);
+        pair_force(f, i, j, d, r, -t->k * (v2 - v1) / (r2 - r1));
+    }
+    return e;
+}
+/* membraneTerms.py:43-52, 144-153 */
+static double eval_memb(const memb_t* t, const double* x, double* f) {
+    double e = 0;
+    for (int b = 0; b < t->n; b++) {
+        int a = t->atoms[b];
+        double z = x[3 * a + 2] - t->center;
+        double u = t->k_m * (z + t->z_m), v = t->k_m * (t->z_m - z);
+        e += t->k * t->scale[b] * (0.5 * tanh(u) + 0.5 * tanh(v));
+        if (f) f[3 * a + 2] -= t->k * t->scale[b] * 0.5 * t->k_m * (sech2(u) - sech2(v));
+    }
+    return e;
+}
+/* debyeHuckelTerms.py:33 */
+static double eval_dh(const dh_t* t, const double* x, double* f) {
+    double e = 0, d[3];
+    for (int b = 0; b < t->n; b++) {
+        int i = t->pairs[2 * b], j = t->pairs[2 * b + 1];
+        double r = dist(x, i, j, d);
+        double E = t->k * t->qq[b] / r * exp(-r / t->lam);
+        e += E;
+        pair_force(f, i, j, d, r, -E * (1.0 / r + 1.0 / t->lam));
+    }
+    return e;
+}
+
+/* energies per group (eg[32], may be NULL) and forces f (natoms*3, may be NULL; accumulated into) */
+static void evaluate(const ctx_t* c, const double* x, uint32_t mask, double* eg, double* f) {
+    for (int i = 0; i < c->nterms; i++) {
+        const term_t* t = &c->terms[i];
+        int group = *(const int*)t->p;   /* first member of every term struct */
+        if (!((mask >> group) & 1u)) continue;
+        double e = 0;
+        switch (t->kind) {
+        case T_HARM: e = eval_harm(t->p, x, f); break;
+        case T_CHI: e = eval_chi(t->p, x, f); break;
+        case T_RAMA: e = eval_rama(t->p, x, f); break;
+        case T_EXCL: e = eval_excl(t->p, x, f); break;
+        case T_CONTACT: e = eval_contact(t->p, x, f); break;
+        case T_BETA: e = eval_beta(t->p, x, f); break;
+        case T_PAP: e = eval_pap(t->p, x, f); break;
+        case T_HELICAL: e = eval_helical(t->p, x, f); break;
+        case T_FM: e = eval_fm(t->p, x, f); break;
+        case T_MEMB: e = eval_memb(t->p, x, f); break;
+        case T_DH: e = eval_dh(t->p, x, f); break;
+        }
+        if (eg) eg[group] += e;
+    }
+}
+/* fold forces on virtual sites onto their parents (OpenMM ThreeParticleAverageSite force distribution) */
+static void redistribute(const ctx_t* c, double* f) {
+    for (int i = 0; i < c->nvs; i++) {
+        int s = c->vs_site[i]; const int* p = c->vs_par + 3 * i; const double* w = c->vs_w + 3 * i;
+        for (int k = 0; k < 3; k++) {
+            double fs = f[3 * s + k];
+            f[3 * p[0] + k] += w[0] * fs; f[3 * p[1] + k] += w[1] * fs; f[3 * p[2] + k] += w[2] * fs;
+            f[3 * s + k] = 0;
+        }
+    }
+}
+
+int awsem_oracle_energy_by_group(ctx_t* c, double* e) {
+    CHECK_RUN(c);
+    if (!e) return fail(-1, "energy_by_group: null output");
+    memset(e, 0, (size_t)c->nrep * NGROUPS * sizeof(double));
+#pragma omp parallel for num_threads(c->nthreads) schedule(dynamic)
+    for (int r = 0; r < c->nrep; r++) evaluate(c, c->pos + (size_t)r * c->natoms * 3, 0xffffffffu, e + (size_t)r * NGROUPS, NULL);
+    return 0;
+}
+int awsem_oracle_energy(ctx_t* c, uint32_t mask, double* e) {
+    CHECK_RUN(c);
+    if (!e) return fail(-1, "energy: null output");
+#pragma omp parallel for num_threads(c->nthreads) schedule(dynamic)
+    for (int r = 0; r < c->nrep; r++) {
+        double eg[NGROUPS] = {0};
+        evaluate(c, c->pos + (size_t)r * c->natoms * 3, mask, eg, NULL);
+        double s = 0; for (int g = 0; g < NGROUPS; g++) s += eg[g];
+        e[r] = s;
+    }
+    return 0;
+}
+int awsem_oracle_forces(ctx_t* c, uint32_t mask, int redist, double* f) {
+    CHECK_RUN(c);
+    if (!f) return fail(-1, "forces: null output");
+    size_t n = (size_t)c->natoms * 3;
+    memset(f, 0, c->nrep * n * sizeof(double));
+#pragma omp parallel for num_threads(c->nthreads) schedule(dynamic)
+    for (int r = 0; r < c->nrep; r++) {
+        evaluate(c, c->pos + r * n, mask, NULL, f + r * n);
+        if (redist) redistribute(c, f + r * n);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ Philox4x32-10 + Gaussian stream
+ * Counter-based RNG shared bit-for-bit with the HIP engine so the two paths can be compared step-locked:
+ * counter = (atom, step_lo, step_hi, replica), key = (seed_lo, seed_hi ^ stream); the four 32-bit outputs give
+ * uniforms u = ((x >> 8) + 0.5) / 2^24 and two Box-Muller pairs; the first three normals are used (x, y, z). */
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int i = 0; i < 10; i++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+static void gauss3(uint64_t seed, uint32_t stream, int rep, int64_t step, int atom, double g[3]) {
+    uint32_t c[4] = {(uint32_t)atom, (uint32_t)(uint64_t)step, (uint32_t)((uint64_t)step >> 32), (uint32_t)rep};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ stream);
+    double u0 = ((c[0] >> 8) + 0.5) / 16777216.0, u1 = ((c[1] >> 8) + 0.5) / 16777216.0;
+    double u2 = ((c[2] >> 8) + 0.5) / 16777216.0, u3 = ((c[3] >> 8) + 0.5) / 16777216.0;
+    double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
+    g[0] = r0 * cos(2 * M_PI * u1); g[1] = r0 * sin(2 * M_PI * u1); g[2] = r1 * cos(2 * M_PI * u3);
+}
+void awsem_oracle_gauss3(uint64_t seed, uint32_t stream, int rep, int64_t step, int atom, double* g) { gauss3(seed, stream, rep, step, atom, g); }
+
+/* context.setVelocitiesToTemperature (scripts/mm_run.py:151): v = sqrt(kT/m) N(0,1) for massive particles. */
+int awsem_oracle_set_velocities_to_temperature(ctx_t* c, const double* T, uint64_t seed) {
+    CHECK_RUN(c);
+    if (!T) return fail(-1, "set_velocities_to_temperature: null temperatures");
+    for (int r = 0; r < c->nrep; r++) for (int a = 0; a < c->natoms; a++) {
+        double* v = c->vel + ((size_t)r * c->natoms + a) * 3, g[3];
+        if (c->mass[a] == 0) { v[0] = v[1] = v[2] = 0; continue; }
+        gauss3(seed, 0x56454c30u /* "VEL0" */, r, 0, a, g);
+        double s = sqrt(KB * T[r] / c->mass[a]);
+        v[0] = s * g[0]; v[1] = s * g[1]; v[2] = s * g[2];
+    }
+    return 0;
+}
+/* OpenMM LangevinIntegrator (ReferenceStochasticDynamics), as configured at scripts/mm_run.py:145:
+ *   v <- a v + (1-a)/gamma F/m + sqrt(kT(1-a^2)/m) N(0,1),  a = exp(-gamma dt);   x <- x + v dt; virtual sites re-derived.
+ * No constraints exist in the AWSEM system, so OpenMM's post-constraint v = (x'-x)/dt is the identity. */
+int awsem_oracle_step(ctx_t* c, int nsteps, const double* T, double dt, double friction, uint64_t seed) {
+    CHECK_RUN(c);
+    if (nsteps < 0 || !T || !(dt > 0) || friction < 0) return fail(-1, "step: bad arguments");
+    const int n = c->natoms;
+    const double a = exp(-friction * dt), fs = friction == 0 ? dt : (1 - a) / friction;
+    int64_t step0 = c->step;
+#pragma omp parallel for num_threads(c->nthreads) schedule(dynamic)
+    for (int r = 0; r < c->nrep; r++) {
+        double* x = c->pos + (size_t)r * n * 3; double* v = c->vel + (size_t)r * n * 3;
+        double* f = malloc((size_t)n * 3 * sizeof(double));
+        const double ns = sqrt(KB * T[r] * (1 - a * a));
+        for (int s = 0; s < nsteps; s++) {
+            virtual_sites(c, x);
+            memset(f, 0, (size_t)n * 3 * sizeof(double));
+            evaluate(c, x, 0xffffffffu, NULL, f);
+            redistribute(c, f);
+            for (int i = 0; i < n; i++) {
+                if (c->mass[i] == 0) continue;
+                double g[3], im = 1.0 / c->mass[i], sq = sqrt(im);
+                gauss3(seed, 0x4c414e47u /* "LANG" */, r, step0 + s, i, g);
+                for (int k = 0; k < 3; k++) {
+                    v[3 * i + k] = a * v[3 * i + k] + fs * im * f[3 * i + k] + ns * sq * g[k];
+                    x[3 * i + k] += dt * v[3 * i + k];
+                }
+            }
+        }
+        virtual_sites(c, x);
+        free(f);
+    }
+    c->step += nsteps;
+    return 0;
+}
+int64_t awsem_oracle_step_count(ctx_t* c) { return c ? c->step : -1; }
+int awsem_oracle_set_step_count(ctx_t* c, int64_t s) { if (!c) return fail(-1, "null handle"); c->step = s; return 0; }
+int awsem_oracle_last_kernel_ms(ctx_t* c, double* ms) { (void)c; if (ms) *ms = 0; return 0; }
+int awsem_oracle_synchronize(ctx_t* c) { (void)c; return 0; }
