@@ -1,0 +1,694 @@
+// awsem_hip.hip -- host side of libawsem_hip.so: the C ABI of include/awsem_hip.h on top of the gfx950 kernels in
+// awsem_kernels.h.  Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC (see __graft_entry__.build()).
+//
+// A handle collects term descriptors on the host (add_* calls), converts and uploads them once (finalize), and
+// then owns: one DevSys<real> (shared, read-only), SoA replica state pos/vel [R][3][natoms], and a HIP stream.
+// Precision is a template parameter of the whole engine: Engine<float> is the production path, Engine<double> the
+// check mode running the identical kernels in fp64.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/awsem_hip.h"
+#include "awsem_kernels.h"
+
+namespace {
+
+thread_local char g_err[1024] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+struct HipError { hipError_t e; const char* what; };
+#define HIP_TRY(call)                                               \
+    do {                                                            \
+        hipError_t _e = (call);                                     \
+        if (_e != hipSuccess) throw HipError{_e, #call};            \
+    } while (0)
+
+// ---- host-side (precision independent) term records -------------------------------------------------------
+struct HHarm { int group; std::vector<int> pairs; std::vector<double> r0, k; };
+struct HChi { int group; std::vector<int> atoms; double k, chi0; };
+struct HRama { int group, nwell; std::vector<int> atoms; std::vector<double> wp, bw; double k; };
+struct HExcl { int group; std::vector<int> atom, cls, excl; double k, r0; };
+struct HContact {
+    int group, env, min_seq_sep, flags; bool has_burial;
+    std::vector<int> atom, restype, resid, chain;
+    double p[AWSEM_CP_COUNT];
+    std::vector<double> gamma, bgamma;
+};
+struct HBeta { int group, two_theta, nres; std::vector<int> acc_atoms, acc_res, don_atoms, don_res; std::vector<double> lambda; double k, r_ON, s_NO, r_OH, s_HO, cutoff; };
+struct HPap { int group, nres; std::vector<int> acc_atoms, acc_res, don_atoms, don_res; std::vector<double> gamma; double k, eta, r0, d_i4, cutoff; };
+struct HHelical { int group; std::vector<int> atoms; std::vector<double> coef; double r_ON, s_NO, r_OH, s_HO; };
+struct HFm { int group, ntab; std::vector<int> pairs; std::vector<double> table; double k, dr; };
+struct HMemb { int group; std::vector<int> atoms; std::vector<double> scale; double k, k_m, z_m, center; };
+struct HDh { int group; std::vector<int> pairs; std::vector<double> qq; double k, lam; };
+
+struct HostSystem {
+    int natoms = 0;
+    std::vector<double> mass;
+    std::vector<int> vs_site, vs_par;
+    std::vector<double> vs_w;
+    std::vector<HHarm> harm; std::vector<HChi> chi; std::vector<HRama> rama; std::vector<HExcl> excl;
+    std::vector<HContact> contact; std::vector<HBeta> beta; std::vector<HPap> pap; std::vector<HHelical> helical;
+    std::vector<HFm> fm; std::vector<HMemb> memb; std::vector<HDh> dh;
+};
+
+// ---- precision-specific engine ---------------------------------------------------------------------------
+struct EngineBase {
+    virtual ~EngineBase() {}
+    virtual void finalize(const HostSystem& H) = 0;
+    virtual void set_positions(int rep, const double* xyz) = 0;
+    virtual void get_positions(int rep, double* xyz) = 0;
+    virtual void set_velocities(int rep, const double* v) = 0;
+    virtual void get_velocities(int rep, double* v) = 0;
+    virtual void compute_virtual_sites() = 0;
+    virtual void maxwell(const double* T, uint64_t seed) = 0;
+    virtual void energy_by_group(unsigned mask, double* e) = 0;
+    virtual void forces(unsigned mask, int redistribute, double* f) = 0;
+    virtual void step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) = 0;
+    virtual void synchronize() = 0;
+    double last_ms = 0.0;
+};
+
+template <class real> class Engine : public EngineBase {
+public:
+    Engine(int natoms, int nrep, int device) : natoms_(natoms), nrep_(nrep), device_(device) {
+        HIP_TRY(hipSetDevice(device_));
+        HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&ev0_));
+        HIP_TRY(hipEventCreate(&ev1_));
+    }
+    ~Engine() override {
+        (void)hipSetDevice(device_);
+        for (void* p : allocs_) (void)hipFree(p);
+        if (ev0_) (void)hipEventDestroy(ev0_);
+        if (ev1_) (void)hipEventDestroy(ev1_);
+        if (stream_) (void)hipStreamDestroy(stream_);
+    }
+
+    void finalize(const HostSystem& H) override;
+
+    void set_positions(int rep, const double* xyz) override { set_state(pos_, rep, xyz); }
+    void get_positions(int rep, double* xyz) override { get_state(pos_, rep, xyz); }
+    void set_velocities(int rep, const double* v) override { set_state(vel_, rep, v); }
+    void get_velocities(int rep, double* v) override { get_state(vel_, rep, v); }
+
+    void compute_virtual_sites() override {
+        HIP_TRY(hipSetDevice(device_));
+        hipLaunchKernelGGL(awsem_vsite_kernel<real>, dim3(nrep_), dim3(64), 0, stream_, dsys_, pos_);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream_));
+    }
+    void maxwell(const double* T, uint64_t seed) override {
+        HIP_TRY(hipSetDevice(device_));
+        upload_T(T);
+        hipLaunchKernelGGL(awsem_maxwell_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, vel_, dT_, (unsigned long long)seed);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream_));
+    }
+    void energy_by_group(unsigned mask, double* e) override {
+        HIP_TRY(hipSetDevice(device_));
+        HIP_TRY(hipEventRecord(ev0_, stream_));
+        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, dsys_, pos_, mask, 0, dE_, (double*)nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev1_, stream_));
+        HIP_TRY(hipMemcpyAsync(e, dE_, sizeof(double) * nrep_ * AWSEM_NGROUPS, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        record_ms();
+    }
+    void forces(unsigned mask, int redistribute, double* f) override {
+        HIP_TRY(hipSetDevice(device_));
+        HIP_TRY(hipEventRecord(ev0_, stream_));
+        hipLaunchKernelGGL((awsem_eval_kernel<false, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, dsys_, pos_, mask, redistribute, (double*)nullptr, dF_);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev1_, stream_));
+        HIP_TRY(hipMemcpyAsync(f, dF_, sizeof(double) * 3 * natoms_ * nrep_, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        record_ms();
+    }
+    void step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) override {
+        HIP_TRY(hipSetDevice(device_));
+        upload_T(T);
+        HIP_TRY(hipEventRecord(ev0_, stream_));
+        hipLaunchKernelGGL(awsem_step_kernel<real>, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, dT_, nsteps, dt, friction,
+                           (unsigned long long)seed, (long long)step0);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev1_, stream_));
+        timing_pending_ = true;   // asynchronous: resolved by synchronize()/last_kernel_ms
+    }
+    void synchronize() override {
+        HIP_TRY(hipSetDevice(device_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        if (timing_pending_) record_ms();
+    }
+
+private:
+    template <class T> T* dalloc(size_t n) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+        allocs_.push_back(p);
+        return (T*)p;
+    }
+    template <class T> const T* upload(const std::vector<T>& v) {
+        T* p = dalloc<T>(v.size());
+        if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return p;
+    }
+    const real* upload_real(const std::vector<double>& v, double scale = 1.0) {
+        std::vector<real> t(v.size());
+        for (size_t i = 0; i < v.size(); i++) t[i] = (real)(v[i] * scale);
+        return upload(t);
+    }
+    void upload_T(const double* T) {
+        HIP_TRY(hipMemcpyAsync(dT_, T, sizeof(double) * nrep_, hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));   // T is a caller-owned pageable buffer
+    }
+    void record_ms() {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev0_, ev1_));
+        last_ms = ms;
+        timing_pending_ = false;
+    }
+    // AoS double [natoms][3] on the host  <->  SoA real [3][natoms] per replica on the device
+    void set_state(real* dst, int rep, const double* src) {
+        HIP_TRY(hipSetDevice(device_));
+        std::vector<real> t((size_t)3 * natoms_);
+        for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++) t[(size_t)k * natoms_ + i] = (real)src[3 * i + k];
+        HIP_TRY(hipStreamSynchronize(stream_));
+        int r0 = rep < 0 ? 0 : rep, r1 = rep < 0 ? nrep_ : rep + 1;
+        for (int r = r0; r < r1; r++)
+            HIP_TRY(hipMemcpy(dst + (size_t)r * 3 * natoms_, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
+    }
+    void get_state(const real* src, int rep, double* dst) {
+        HIP_TRY(hipSetDevice(device_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        std::vector<real> t((size_t)3 * natoms_);
+        HIP_TRY(hipMemcpy(t.data(), src + (size_t)rep * 3 * natoms_, t.size() * sizeof(real), hipMemcpyDeviceToHost));
+        for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++) dst[3 * i + k] = (double)t[(size_t)k * natoms_ + i];
+    }
+
+    int natoms_, nrep_, device_;
+    int block_ = 256;
+    size_t lds_eval_ = 0, lds_step_ = 0;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    bool timing_pending_ = false;
+    std::vector<void*> allocs_;
+    DevSys<real>* dsys_ = nullptr;
+    real *pos_ = nullptr, *vel_ = nullptr;
+    double *dT_ = nullptr, *dE_ = nullptr, *dF_ = nullptr;
+};
+
+template <class real> void Engine<real>::finalize(const HostSystem& H) {
+    HIP_TRY(hipSetDevice(device_));
+    DevSys<real> S;
+    memset(&S, 0, sizeof S);
+    S.natoms = natoms_;
+    // particles
+    {
+        std::vector<real> im(natoms_), sim(natoms_);
+        for (int i = 0; i < natoms_; i++) {
+            im[i] = H.mass[i] > 0 ? (real)(1.0 / H.mass[i]) : (real)0;
+            sim[i] = H.mass[i] > 0 ? (real)std::sqrt(1.0 / H.mass[i]) : (real)0;
+        }
+        S.inv_mass = upload(im);
+        S.sqrt_inv_mass = upload(sim);
+        S.nvs = (int)H.vs_site.size();
+        std::vector<Int4> vs(S.nvs);
+        for (int i = 0; i < S.nvs; i++) vs[i] = Int4{H.vs_site[i], H.vs_par[3 * i], H.vs_par[3 * i + 1], H.vs_par[3 * i + 2]};
+        S.vs = upload(vs);
+        S.vs_w = upload_real(H.vs_w);
+    }
+    {   // harmonic
+        std::vector<HarmD<real>> D;
+        for (auto& h : H.harm) {
+            std::vector<HarmItem<real>> it(h.r0.size());
+            for (size_t b = 0; b < it.size(); b++) it[b] = HarmItem<real>{h.pairs[2 * b], h.pairs[2 * b + 1], (real)h.r0[b], (real)h.k[b]};
+            D.push_back(HarmD<real>{h.group, (int)it.size(), upload(it)});
+        }
+        S.n_harm = (int)D.size(); S.harm = upload(D);
+    }
+    {   // chi
+        std::vector<ChiD<real>> D;
+        for (auto& h : H.chi) {
+            std::vector<Int4> a(h.atoms.size() / 4);
+            for (size_t b = 0; b < a.size(); b++) a[b] = Int4{h.atoms[4 * b], h.atoms[4 * b + 1], h.atoms[4 * b + 2], h.atoms[4 * b + 3]};
+            D.push_back(ChiD<real>{h.group, (int)a.size(), upload(a), (real)h.k, (real)h.chi0});
+        }
+        S.n_chi = (int)D.size(); S.chi = upload(D);
+    }
+    {   // rama
+        std::vector<RamaD<real>> D;
+        for (auto& h : H.rama) {
+            RamaD<real> d;
+            memset(&d, 0, sizeof d);
+            d.group = h.group; d.n = (int)(h.atoms.size() / 5); d.nwell = h.nwell;
+            std::vector<Int5> a(d.n);
+            for (int b = 0; b < d.n; b++) for (int k = 0; k < 5; k++) a[b].a[k] = h.atoms[5 * b + k];
+            d.atoms = upload(a);
+            std::vector<real> bw((size_t)d.n * h.nwell);
+            for (int b = 0; b < d.n; b++) for (int w = 0; w < h.nwell; w++)
+                bw[(size_t)b * h.nwell + w] = (real)(-h.k * h.wp[6 * w] * h.bw[(size_t)b * h.nwell + w]);
+            d.bw = upload(bw);
+            for (int w = 0; w < h.nwell; w++) {
+                const double* p = &h.wp[6 * w];
+                d.sigma[w] = (real)p[1]; d.omega_phi[w] = (real)p[2]; d.omega_psi[w] = (real)p[4];
+                d.cphi0[w] = (real)std::cos(p[3]); d.sphi0[w] = (real)std::sin(p[3]);
+                d.cpsi0[w] = (real)std::cos(p[5]); d.spsi0[w] = (real)std::sin(p[5]);
+            }
+            D.push_back(d);
+        }
+        S.n_rama = (int)D.size(); S.rama = upload(D);
+    }
+    {   // excl: sort sites by class, per-site partner lists
+        std::vector<ExclD<real>> D;
+        for (auto& h : H.excl) {
+            ExclD<real> d;
+            memset(&d, 0, sizeof d);
+            d.group = h.group; d.k = (real)h.k; d.r0 = (real)h.r0;
+            int ncls = 0;
+            for (int c : h.cls) ncls = std::max(ncls, c + 1);
+            d.nclass = ncls; d.nsites = (int)h.atom.size();
+            std::vector<int> atom;
+            for (int c = 0; c < ncls; c++) {
+                d.class_start[c] = (int)atom.size();
+                for (size_t i = 0; i < h.atom.size(); i++) if (h.cls[i] == c) atom.push_back(h.atom[i]);
+            }
+            d.class_start[ncls] = (int)atom.size();
+            std::vector<Int4> partners(atom.size(), Int4{-1, -1, -1, -1});
+            std::vector<int> count(atom.size(), 0);
+            auto add_partner = [&](int a, int b) {
+                for (size_t s = 0; s < atom.size(); s++) if (atom[s] == a) {
+                    int* q = &partners[s].x;
+                    if (count[s] >= 4) throw std::string("excl: more than 4 excluded partners for one atom");
+                    q[count[s]++] = b;
+                }
+            };
+            for (size_t q = 0; q + 1 < h.excl.size(); q += 2) { add_partner(h.excl[q], h.excl[q + 1]); add_partner(h.excl[q + 1], h.excl[q]); }
+            d.atom = upload(atom); d.partners = upload(partners);
+            D.push_back(d);
+        }
+        S.n_excl = (int)D.size(); S.excl = upload(D);
+    }
+    {   // contact
+        std::vector<ContactD<real>> D;
+        for (auto& h : H.contact) {
+            ContactD<real> d;
+            memset(&d, 0, sizeof d);
+            d.group = h.group; d.nsites = (int)h.atom.size(); d.env = h.env; d.min_seq_sep = h.min_seq_sep; d.flags = h.flags;
+            d.has_burial = h.has_burial;
+            d.atom = upload(h.atom); d.restype = upload(h.restype); d.resid = upload(h.resid); d.chain = upload(h.chain);
+            d.gamma = upload_real(h.gamma); d.bgamma = upload_real(h.bgamma);
+            const double* p = h.p;
+            d.k = (real)p[AWSEM_CP_K]; d.rmin = (real)p[AWSEM_CP_RMIN]; d.rmax = (real)p[AWSEM_CP_RMAX];
+            d.rminII = (real)p[AWSEM_CP_RMINII]; d.rmaxII = (real)p[AWSEM_CP_RMAXII];
+            d.eta2 = (real)(2 * p[AWSEM_CP_ETA]); d.eta_s2 = (real)(2 * p[AWSEM_CP_ETA_SIGMA]); d.rho0 = (real)p[AWSEM_CP_RHO0];
+            double cut = (h.flags & AWSEM_CONTACT_NOCUTOFF) ? 1e15 : p[AWSEM_CP_CUTOFF];
+            d.cutoff2 = (real)(cut * cut);
+            d.kappa2 = (real)(2 * p[AWSEM_CP_BURIAL_KAPPA]);
+            for (int m = 0; m < 3; m++) { d.rho_lo[m] = (real)p[AWSEM_CP_BURIAL_RHO_MIN0 + m]; d.rho_hi[m] = (real)p[AWSEM_CP_BURIAL_RHO_MAX0 + m]; }
+            d.eta_sw2 = (real)(2 * p[AWSEM_CP_ETA_SWITCH]); d.z_m = (real)p[AWSEM_CP_Z_M]; d.zc = (real)p[AWSEM_CP_MEMBRANE_CENTER];
+            d.kb = (real)p[AWSEM_CP_K_BURIAL];
+            S.max_contact_sites = std::max(S.max_contact_sites, d.nsites);
+            if (h.flags & AWSEM_CONTACT_ZDEP) S.any_zdep = 1;
+            D.push_back(d);
+        }
+        S.n_contact = (int)D.size(); S.contact = upload(D);
+    }
+    {   // beta
+        std::vector<BetaD<real>> D;
+        for (auto& h : H.beta) {
+            BetaD<real> d;
+            memset(&d, 0, sizeof d);
+            d.group = h.group; d.two_theta = h.two_theta; d.nacc = (int)h.acc_res.size(); d.ndon = (int)h.don_res.size(); d.nres = h.nres;
+            std::vector<Int4> acc(d.nacc), don(d.ndon);
+            for (int i = 0; i < d.nacc; i++) acc[i] = Int4{h.acc_atoms[3 * i], h.acc_atoms[3 * i + 1], h.acc_atoms[3 * i + 2], h.acc_res[i]};
+            for (int i = 0; i < d.ndon; i++) don[i] = Int4{h.don_atoms[3 * i], h.don_atoms[3 * i + 1], h.don_atoms[3 * i + 2], h.don_res[i]};
+            d.acc = upload(acc); d.don = upload(don);
+            d.lambda = upload_real(h.lambda, -h.k);
+            d.r_ON = (real)h.r_ON; d.r_OH = (real)h.r_OH; d.inv_sNO2 = (real)(1.0 / (h.s_NO * h.s_NO)); d.inv_sHO2 = (real)(1.0 / (h.s_HO * h.s_HO));
+            d.cutoff2 = (real)(h.cutoff * h.cutoff);
+            D.push_back(d);
+        }
+        S.n_beta = (int)D.size(); S.beta = upload(D);
+    }
+    {   // pap
+        std::vector<PapD<real>> D;
+        for (auto& h : H.pap) {
+            PapD<real> d;
+            memset(&d, 0, sizeof d);
+            d.group = h.group; d.nacc = (int)h.acc_res.size(); d.ndon = (int)h.don_res.size(); d.nres = h.nres;
+            std::vector<Int4> acc(d.nacc), don(d.ndon);
+            for (int i = 0; i < d.nacc; i++) acc[i] = Int4{h.acc_atoms[2 * i], h.acc_atoms[2 * i + 1], h.acc_res[i], 0};
+            for (int i = 0; i < d.ndon; i++) don[i] = Int4{h.don_atoms[2 * i], h.don_atoms[2 * i + 1], h.don_res[i], 0};
+            d.acc = upload(acc); d.don = upload(don);
+            d.gamma = upload_real(h.gamma, -h.k);
+            d.eta2 = (real)(2 * h.eta); d.r0 = (real)h.r0; d.d_i4 = (real)h.d_i4; d.cutoff2 = (real)(h.cutoff * h.cutoff);
+            D.push_back(d);
+        }
+        S.n_pap = (int)D.size(); S.pap = upload(D);
+    }
+    {   // helical
+        std::vector<HelicalD<real>> D;
+        for (auto& h : H.helical) {
+            std::vector<HelicalItem<real>> it(h.coef.size());
+            for (size_t b = 0; b < it.size(); b++) it[b] = HelicalItem<real>{h.atoms[3 * b], h.atoms[3 * b + 1], h.atoms[3 * b + 2], (real)h.coef[b]};
+            D.push_back(HelicalD<real>{h.group, (int)it.size(), upload(it), (real)h.r_ON, (real)h.r_OH, (real)(1.0 / (h.s_NO * h.s_NO)), (real)(1.0 / (h.s_HO * h.s_HO))});
+        }
+        S.n_helical = (int)D.size(); S.helical = upload(D);
+    }
+    {   // fragment memory
+        std::vector<FmD<real>> D;
+        for (auto& h : H.fm)
+            D.push_back(FmD<real>{h.group, (int)(h.pairs.size() / 2), h.ntab, upload(h.pairs), upload_real(h.table), (real)h.k, (real)h.dr, (real)(1.0 / h.dr)});
+        S.n_fm = (int)D.size(); S.fm = upload(D);
+    }
+    {   // membrane
+        std::vector<MembD<real>> D;
+        for (auto& h : H.memb) {
+            std::vector<MembItem<real>> it(h.atoms.size());
+            for (size_t b = 0; b < it.size(); b++) it[b] = MembItem<real>{h.atoms[b], (real)h.scale[b]};
+            D.push_back(MembD<real>{h.group, (int)it.size(), upload(it), (real)h.k, (real)(2 * h.k_m), (real)h.z_m, (real)h.center});
+        }
+        S.n_memb = (int)D.size(); S.memb = upload(D);
+    }
+    {   // debye-hueckel
+        std::vector<DhD<real>> D;
+        for (auto& h : H.dh) {
+            std::vector<DhItem<real>> it(h.qq.size());
+            for (size_t b = 0; b < it.size(); b++) it[b] = DhItem<real>{h.pairs[2 * b], h.pairs[2 * b + 1], (real)h.qq[b], (real)0};
+            D.push_back(DhD<real>{h.group, (int)it.size(), upload(it), (real)h.k, (real)(1.0 / h.lam)});
+        }
+        S.n_dh = (int)D.size(); S.dh = upload(D);
+    }
+    dsys_ = dalloc<DevSys<real>>(1);
+    HIP_TRY(hipMemcpy(dsys_, &S, sizeof S, hipMemcpyHostToDevice));
+
+    // replica state and outputs
+    size_t nstate = (size_t)nrep_ * 3 * natoms_;
+    pos_ = dalloc<real>(nstate); vel_ = dalloc<real>(nstate);
+    HIP_TRY(hipMemset(pos_, 0, nstate * sizeof(real)));
+    HIP_TRY(hipMemset(vel_, 0, nstate * sizeof(real)));
+    dT_ = dalloc<double>(nrep_); dE_ = dalloc<double>((size_t)nrep_ * AWSEM_NGROUPS); dF_ = dalloc<double>(nstate);
+
+    // launch geometry: one workgroup per replica, LDS sized by the system
+    lds_eval_ = lds_bytes<real>(natoms_, S.max_contact_sites, false);
+    lds_step_ = lds_bytes<real>(natoms_, S.max_contact_sites, true);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_));
+    size_t lds_max = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
+    if (prop.maxSharedMemoryPerMultiProcessor > lds_max) lds_max = prop.maxSharedMemoryPerMultiProcessor;
+    if (lds_step_ > lds_max) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "system of %d atoms needs %zu bytes of LDS per replica; the replica-resident path is limited to %zu",
+                 natoms_, lds_step_, lds_max);
+        throw std::string(msg);
+    }
+    HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<true, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
+    HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<false, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
+    HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
+    block_ = natoms_ > 1024 ? 512 : 256;
+    if (const char* env = getenv("AWSEM_BLOCK")) {
+        int b = atoi(env);
+        if (b >= 64 && b <= 1024 && b % 64 == 0) block_ = b;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+struct awsem_context {
+    int natoms, nrep, device, precision;
+    bool finalized = false;
+    HostSystem H;
+    std::unique_ptr<EngineBase> eng;
+    int64_t step = 0;
+};
+
+#define GUARD_BEGIN try {
+#define GUARD_END                                                                                              \
+    }                                                                                                          \
+    catch (const HipError& e) { return fail(AWSEM_EDEVICE, "HIP error %d (%s) in %s", (int)e.e, hipGetErrorString(e.e), e.what); } \
+    catch (const std::string& s) { return fail(AWSEM_ELIMIT, "%s", s.c_str()); }                               \
+    catch (const std::bad_alloc&) { return fail(AWSEM_ENOMEM, "out of host memory"); }
+
+#define NEED_BUILD(h, group)                                                              \
+    if (!(h)) return fail(AWSEM_EINVAL, "null handle");                                   \
+    if ((h)->finalized) return fail(AWSEM_ESTATE, "system already finalized");            \
+    if ((group) < 0 || (group) >= AWSEM_NGROUPS) return fail(AWSEM_EINVAL, "force group out of range 0..31");
+#define NEED_RUN(h)                                                                       \
+    if (!(h)) return fail(AWSEM_EINVAL, "null handle");                                   \
+    if (!(h)->finalized) return fail(AWSEM_ESTATE, "system not finalized");
+
+static bool atoms_ok(awsem_handle h, const int32_t* idx, size_t n, bool allow_minus1 = false) {
+    for (size_t i = 0; i < n; i++) {
+        if (idx[i] < 0) { if (!allow_minus1 || idx[i] != -1) return false; }
+        else if (idx[i] >= h->natoms) return false;
+    }
+    return true;
+}
+template <class T> static std::vector<T> vec(const T* p, size_t n) { return p ? std::vector<T>(p, p + n) : std::vector<T>(); }
+
+extern "C" {
+
+const char* awsem_last_error(void) { return g_err; }
+const char* awsem_version(void) { return "awsem_hip 0.1 gfx950"; }
+
+int awsem_create(int natoms, int n_replicas, int device, int precision, awsem_handle* out) {
+    if (natoms <= 0 || n_replicas <= 0 || !out) return fail(AWSEM_EINVAL, "awsem_create: natoms and n_replicas must be positive");
+    if (precision != AWSEM_FP32 && precision != AWSEM_FP64) return fail(AWSEM_EINVAL, "awsem_create: precision must be AWSEM_FP32 or AWSEM_FP64");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(AWSEM_EDEVICE, "awsem_create: no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(AWSEM_EINVAL, "awsem_create: device %d out of range (%d devices)", device, ndev);
+    GUARD_BEGIN
+    awsem_context* h = new awsem_context();
+    h->natoms = natoms; h->nrep = n_replicas; h->device = device; h->precision = precision;
+    h->H.natoms = natoms;
+    h->H.mass.assign(natoms, 1.0);
+    *out = h;
+    return AWSEM_OK;
+    GUARD_END
+}
+
+void awsem_destroy(awsem_handle h) { delete h; }
+
+int awsem_set_masses(awsem_handle h, const double* m, int natoms) {
+    NEED_BUILD(h, 0);
+    if (!m || natoms != h->natoms) return fail(AWSEM_EINVAL, "set_masses: natoms mismatch");
+    for (int i = 0; i < natoms; i++) if (!(m[i] >= 0)) return fail(AWSEM_EINVAL, "set_masses: negative mass");
+    h->H.mass.assign(m, m + natoms);
+    return AWSEM_OK;
+}
+int awsem_set_virtual_sites(awsem_handle h, int n, const int32_t* site, const int32_t* par, const double* w) {
+    NEED_BUILD(h, 0);
+    if (n < 0 || (n && (!site || !par || !w))) return fail(AWSEM_EINVAL, "set_virtual_sites: bad arguments");
+    if (!atoms_ok(h, site, n) || !atoms_ok(h, par, 3 * (size_t)n)) return fail(AWSEM_EINVAL, "set_virtual_sites: atom index out of range");
+    h->H.vs_site = vec(site, n); h->H.vs_par = vec(par, 3 * (size_t)n); h->H.vs_w = vec(w, 3 * (size_t)n);
+    return AWSEM_OK;
+}
+int awsem_add_harmonic_bonds(awsem_handle h, int group, int n, const int32_t* pairs, const double* r0, const double* k) {
+    NEED_BUILD(h, group);
+    if (n < 0 || (n && (!pairs || !r0 || !k)) || !atoms_ok(h, pairs, 2 * (size_t)n)) return fail(AWSEM_EINVAL, "add_harmonic_bonds: bad arguments");
+    h->H.harm.push_back(HHarm{group, vec(pairs, 2 * (size_t)n), vec(r0, n), vec(k, n)});
+    return AWSEM_OK;
+}
+int awsem_add_chi(awsem_handle h, int group, int n, const int32_t* atoms, double k, double chi0) {
+    NEED_BUILD(h, group);
+    if (n < 0 || (n && !atoms) || !atoms_ok(h, atoms, 4 * (size_t)n)) return fail(AWSEM_EINVAL, "add_chi: bad arguments");
+    h->H.chi.push_back(HChi{group, vec(atoms, 4 * (size_t)n), k, chi0});
+    return AWSEM_OK;
+}
+int awsem_add_rama(awsem_handle h, int group, int n, const int32_t* atoms, int nwell, const double* wp, const double* bw, double k) {
+    NEED_BUILD(h, group);
+    if (n < 0 || nwell < 1 || nwell > AWSEM_MAX_WELLS || !wp || (n && !atoms) || !atoms_ok(h, atoms, 5 * (size_t)n))
+        return fail(AWSEM_EINVAL, "add_rama: bad arguments (1..%d wells)", AWSEM_MAX_WELLS);
+    HRama r{group, nwell, vec(atoms, 5 * (size_t)n), vec(wp, 6 * (size_t)nwell), {}, k};
+    r.bw = bw ? vec(bw, (size_t)n * nwell) : std::vector<double>((size_t)n * nwell, 1.0);
+    h->H.rama.push_back(std::move(r));
+    return AWSEM_OK;
+}
+int awsem_add_excl(awsem_handle h, int group, int nsites, const int32_t* atom, const int32_t* cls, int nexcl, const int32_t* excl, double k, double r0) {
+    NEED_BUILD(h, group);
+    if (nsites < 0 || nexcl < 0 || (nsites && (!atom || !cls)) || (nexcl && !excl) || !atoms_ok(h, atom, nsites) || !atoms_ok(h, excl, 2 * (size_t)nexcl))
+        return fail(AWSEM_EINVAL, "add_excl: bad arguments");
+    for (int i = 0; i < nsites; i++) if (cls[i] < 0 || cls[i] >= 8) return fail(AWSEM_EINVAL, "add_excl: class out of range 0..7");
+    h->H.excl.push_back(HExcl{group, vec(atom, nsites), vec(cls, nsites), vec(excl, 2 * (size_t)nexcl), k, r0});
+    return AWSEM_OK;
+}
+int awsem_add_contact(awsem_handle h, int group, int nsites, const int32_t* atom, const int32_t* restype, const int32_t* resid, const int32_t* chain,
+                      int env, int min_seq_sep, int flags, const double* dparams, const double* gamma, const double* bgamma) {
+    NEED_BUILD(h, group);
+    if (nsites < 0 || !dparams || (nsites && (!atom || !restype || !resid || !chain)) || !atoms_ok(h, atom, nsites) || env < 0 || env > 1)
+        return fail(AWSEM_EINVAL, "add_contact: bad arguments");
+    if (!(flags & AWSEM_CONTACT_BURIAL_ONLY) && !gamma) return fail(AWSEM_EINVAL, "add_contact: gamma table required");
+    for (int i = 0; i < nsites; i++) if (restype[i] < 0 || restype[i] >= 20) return fail(AWSEM_EINVAL, "add_contact: residue type out of range 0..19");
+    HContact c;
+    c.group = group; c.env = env; c.min_seq_sep = min_seq_sep; c.flags = flags; c.has_burial = bgamma != nullptr;
+    c.atom = vec(atom, nsites); c.restype = vec(restype, nsites); c.resid = vec(resid, nsites); c.chain = vec(chain, nsites);
+    memcpy(c.p, dparams, sizeof c.p);
+    c.gamma = gamma ? vec(gamma, 2400) : std::vector<double>(2400, 0.0);
+    c.bgamma = bgamma ? vec(bgamma, 60) : std::vector<double>(60, 0.0);
+    h->H.contact.push_back(std::move(c));
+    return AWSEM_OK;
+}
+int awsem_add_hbond_beta(awsem_handle h, int group, int two_theta, int nacc, const int32_t* acc_atoms, const int32_t* acc_res, int ndon,
+                         const int32_t* don_atoms, const int32_t* don_res, int nres, const double* lambda, double k, double r_ON, double s_NO,
+                         double r_OH, double s_HO, double cutoff) {
+    NEED_BUILD(h, group);
+    if (nacc < 0 || ndon < 0 || nres <= 0 || !lambda || (nacc && (!acc_atoms || !acc_res)) || (ndon && (!don_atoms || !don_res)))
+        return fail(AWSEM_EINVAL, "add_hbond_beta: bad arguments");
+    if (!atoms_ok(h, acc_atoms, 3 * (size_t)nacc, true) || !atoms_ok(h, don_atoms, 3 * (size_t)ndon, true))
+        return fail(AWSEM_EINVAL, "add_hbond_beta: atom index out of range");
+    for (int i = 0; i < nacc; i++) {
+        if (acc_res[i] < 0 || acc_res[i] >= nres || acc_atoms[3 * i] < 0) return fail(AWSEM_EINVAL, "add_hbond_beta: bad acceptor %d", i);
+        if (two_theta && (acc_atoms[3 * i + 1] < 0 || acc_atoms[3 * i + 2] < 0)) return fail(AWSEM_EINVAL, "add_hbond_beta: acceptor %d needs a2,a3", i);
+    }
+    for (int i = 0; i < ndon; i++) {
+        if (don_res[i] < 0 || don_res[i] >= nres || don_atoms[3 * i] < 0 || don_atoms[3 * i + 1] < 0) return fail(AWSEM_EINVAL, "add_hbond_beta: bad donor %d", i);
+        if (two_theta && don_atoms[3 * i + 2] < 0) return fail(AWSEM_EINVAL, "add_hbond_beta: donor %d needs d3", i);
+    }
+    h->H.beta.push_back(HBeta{group, two_theta ? 1 : 0, nres, vec(acc_atoms, 3 * (size_t)nacc), vec(acc_res, nacc), vec(don_atoms, 3 * (size_t)ndon),
+                              vec(don_res, ndon), vec(lambda, (size_t)nres * nres), k, r_ON, s_NO, r_OH, s_HO, cutoff});
+    return AWSEM_OK;
+}
+int awsem_add_hbond_pap(awsem_handle h, int group, int nacc, const int32_t* acc_atoms, const int32_t* acc_res, int ndon, const int32_t* don_atoms,
+                        const int32_t* don_res, int nres, const double* gamma, double k, double eta, double r0, double d_i4, double cutoff) {
+    NEED_BUILD(h, group);
+    if (nacc < 0 || ndon < 0 || nres <= 0 || !gamma || (nacc && (!acc_atoms || !acc_res)) || (ndon && (!don_atoms || !don_res)))
+        return fail(AWSEM_EINVAL, "add_hbond_pap: bad arguments");
+    if (!atoms_ok(h, acc_atoms, 2 * (size_t)nacc) || !atoms_ok(h, don_atoms, 2 * (size_t)ndon)) return fail(AWSEM_EINVAL, "add_hbond_pap: atom index out of range");
+    for (int i = 0; i < nacc; i++) if (acc_res[i] < 0 || acc_res[i] >= nres) return fail(AWSEM_EINVAL, "add_hbond_pap: bad acceptor residue");
+    for (int i = 0; i < ndon; i++) if (don_res[i] < 0 || don_res[i] >= nres) return fail(AWSEM_EINVAL, "add_hbond_pap: bad donor residue");
+    h->H.pap.push_back(HPap{group, nres, vec(acc_atoms, 2 * (size_t)nacc), vec(acc_res, nacc), vec(don_atoms, 2 * (size_t)ndon), vec(don_res, ndon),
+                            vec(gamma, (size_t)nres * nres), k, eta, r0, d_i4, cutoff});
+    return AWSEM_OK;
+}
+int awsem_add_helical(awsem_handle h, int group, int n, const int32_t* atoms, const double* coef, double r_ON, double s_NO, double r_OH, double s_HO) {
+    NEED_BUILD(h, group);
+    if (n < 0 || (n && (!atoms || !coef)) || !atoms_ok(h, atoms, 3 * (size_t)n)) return fail(AWSEM_EINVAL, "add_helical: bad arguments");
+    h->H.helical.push_back(HHelical{group, vec(atoms, 3 * (size_t)n), vec(coef, n), r_ON, s_NO, r_OH, s_HO});
+    return AWSEM_OK;
+}
+int awsem_add_fragment_memory(awsem_handle h, int group, int nb, const int32_t* pairs, int ntab, const double* table, double k, double dr) {
+    NEED_BUILD(h, group);
+    if (nb < 0 || ntab < 2 || !(dr > 0) || (nb && (!pairs || !table)) || !atoms_ok(h, pairs, 2 * (size_t)nb))
+        return fail(AWSEM_EINVAL, "add_fragment_memory: bad arguments");
+    h->H.fm.push_back(HFm{group, ntab, vec(pairs, 2 * (size_t)nb), vec(table, (size_t)nb * ntab), k, dr});
+    return AWSEM_OK;
+}
+int awsem_add_membrane(awsem_handle h, int group, int n, const int32_t* atoms, const double* scale, double k, double k_m, double z_m, double center) {
+    NEED_BUILD(h, group);
+    if (n < 0 || (n && (!atoms || !scale)) || !atoms_ok(h, atoms, n)) return fail(AWSEM_EINVAL, "add_membrane: bad arguments");
+    h->H.memb.push_back(HMemb{group, vec(atoms, n), vec(scale, n), k, k_m, z_m, center});
+    return AWSEM_OK;
+}
+int awsem_add_debye_huckel(awsem_handle h, int group, int n, const int32_t* pairs, const double* qq, double k, double lam) {
+    NEED_BUILD(h, group);
+    if (n < 0 || !(lam > 0) || (n && (!pairs || !qq)) || !atoms_ok(h, pairs, 2 * (size_t)n)) return fail(AWSEM_EINVAL, "add_debye_huckel: bad arguments");
+    h->H.dh.push_back(HDh{group, vec(pairs, 2 * (size_t)n), vec(qq, n), k, lam});
+    return AWSEM_OK;
+}
+
+int awsem_finalize(awsem_handle h) {
+    if (!h) return fail(AWSEM_EINVAL, "null handle");
+    if (h->finalized) return fail(AWSEM_ESTATE, "system already finalized");
+    GUARD_BEGIN
+    if (h->precision == AWSEM_FP64) h->eng.reset(new Engine<double>(h->natoms, h->nrep, h->device));
+    else h->eng.reset(new Engine<float>(h->natoms, h->nrep, h->device));
+    h->eng->finalize(h->H);
+    h->finalized = true;
+    return AWSEM_OK;
+    GUARD_END
+}
+
+int awsem_set_positions(awsem_handle h, int rep, const double* xyz, int natoms) {
+    NEED_RUN(h);
+    if (!xyz || natoms != h->natoms || rep < -1 || rep >= h->nrep) return fail(AWSEM_EINVAL, "set_positions: bad arguments");
+    GUARD_BEGIN h->eng->set_positions(rep, xyz); return AWSEM_OK; GUARD_END
+}
+int awsem_get_positions(awsem_handle h, int rep, double* xyz, int natoms) {
+    NEED_RUN(h);
+    if (!xyz || natoms != h->natoms || rep < 0 || rep >= h->nrep) return fail(AWSEM_EINVAL, "get_positions: bad arguments");
+    GUARD_BEGIN h->eng->get_positions(rep, xyz); return AWSEM_OK; GUARD_END
+}
+int awsem_set_velocities(awsem_handle h, int rep, const double* v, int natoms) {
+    NEED_RUN(h);
+    if (!v || natoms != h->natoms || rep < -1 || rep >= h->nrep) return fail(AWSEM_EINVAL, "set_velocities: bad arguments");
+    GUARD_BEGIN h->eng->set_velocities(rep, v); return AWSEM_OK; GUARD_END
+}
+int awsem_get_velocities(awsem_handle h, int rep, double* v, int natoms) {
+    NEED_RUN(h);
+    if (!v || natoms != h->natoms || rep < 0 || rep >= h->nrep) return fail(AWSEM_EINVAL, "get_velocities: bad arguments");
+    GUARD_BEGIN h->eng->get_velocities(rep, v); return AWSEM_OK; GUARD_END
+}
+int awsem_compute_virtual_sites(awsem_handle h) {
+    NEED_RUN(h);
+    GUARD_BEGIN h->eng->compute_virtual_sites(); return AWSEM_OK; GUARD_END
+}
+int awsem_set_velocities_to_temperature(awsem_handle h, const double* T, uint64_t seed) {
+    NEED_RUN(h);
+    if (!T) return fail(AWSEM_EINVAL, "set_velocities_to_temperature: null temperatures");
+    GUARD_BEGIN h->eng->maxwell(T, seed); return AWSEM_OK; GUARD_END
+}
+int awsem_energy_by_group(awsem_handle h, double* e) {
+    NEED_RUN(h);
+    if (!e) return fail(AWSEM_EINVAL, "energy_by_group: null output");
+    GUARD_BEGIN h->eng->energy_by_group(0xffffffffu, e); return AWSEM_OK; GUARD_END
+}
+int awsem_energy(awsem_handle h, uint32_t mask, double* e) {
+    NEED_RUN(h);
+    if (!e) return fail(AWSEM_EINVAL, "energy: null output");
+    GUARD_BEGIN
+    std::vector<double> eg((size_t)h->nrep * AWSEM_NGROUPS);
+    h->eng->energy_by_group(mask, eg.data());
+    for (int r = 0; r < h->nrep; r++) {
+        double s = 0;
+        for (int g = 0; g < AWSEM_NGROUPS; g++) if ((mask >> g) & 1u) s += eg[(size_t)r * AWSEM_NGROUPS + g];
+        e[r] = s;
+    }
+    return AWSEM_OK;
+    GUARD_END
+}
+int awsem_forces(awsem_handle h, uint32_t mask, int redistribute, double* f) {
+    NEED_RUN(h);
+    if (!f) return fail(AWSEM_EINVAL, "forces: null output");
+    GUARD_BEGIN h->eng->forces(mask, redistribute, f); return AWSEM_OK; GUARD_END
+}
+int awsem_step(awsem_handle h, int nsteps, const double* T, double dt, double friction, uint64_t seed) {
+    NEED_RUN(h);
+    if (nsteps < 0 || !T || !(dt > 0) || friction < 0) return fail(AWSEM_EINVAL, "step: bad arguments");
+    GUARD_BEGIN
+    if (nsteps > 0) h->eng->step(nsteps, T, dt, friction, seed, h->step);
+    h->step += nsteps;
+    return AWSEM_OK;
+    GUARD_END
+}
+int64_t awsem_step_count(awsem_handle h) { return h ? h->step : -1; }
+int awsem_set_step_count(awsem_handle h, int64_t s) {
+    if (!h) return fail(AWSEM_EINVAL, "null handle");
+    h->step = s;
+    return AWSEM_OK;
+}
+int awsem_last_kernel_ms(awsem_handle h, double* ms) {
+    NEED_RUN(h);
+    if (!ms) return fail(AWSEM_EINVAL, "last_kernel_ms: null output");
+    GUARD_BEGIN h->eng->synchronize(); *ms = h->eng->last_ms; return AWSEM_OK; GUARD_END
+}
+int awsem_synchronize(awsem_handle h) {
+    NEED_RUN(h);
+    GUARD_BEGIN h->eng->synchronize(); return AWSEM_OK; GUARD_END
+}
+
+}  // extern "C"

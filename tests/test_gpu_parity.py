@@ -1,0 +1,141 @@
+"""GPU parity: libawsem_hip.so (through the C ABI) against the golden energies of the reference and the fp64 CPU
+oracle, on the reference's own test inputs (5 proteins x 12 trajectory frames, all 16 test forces).
+
+Tolerances (BASELINE.json north_star): fp32 kernels -- energies <= 1e-4 relative, forces <= 1e-3 relative;
+fp64 check mode -- the reference's own atol = 1e-5 kJ/mol on the golden columns.
+"""
+import numpy as np
+import pytest
+
+from openawsem_amd import _capi
+from oracle import awsem_oracle
+from tests.common import COLUMNS, FORCE_GROUP, PROTEINS, energies_by_column, golden_system
+
+pytestmark = pytest.mark.gpu
+
+FP32, FP64 = 0, 1
+
+
+def _gpu(oa, n_replicas, precision):
+    ctx = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=n_replicas, device=0, precision=precision)
+    oa.system.upload(ctx)
+    return ctx
+
+
+@pytest.mark.parametrize("protein", PROTEINS)
+def test_fp64_mode_matches_reference_golden_energies(protein):
+    oa, traj, golden = golden_system(protein)
+    got = energies_by_column(_gpu(oa, len(traj), FP64), traj)
+    for column in COLUMNS:
+        assert np.allclose(got[column], golden[column], atol=1e-5, rtol=0), \
+            f"{protein} {column}: max |diff| = {np.abs(got[column] - golden[column]).max():.3e}"
+
+
+@pytest.mark.parametrize("protein", PROTEINS)
+def test_fp32_energies_within_1e4_relative_of_golden(protein):
+    oa, traj, golden = golden_system(protein)
+    got = energies_by_column(_gpu(oa, len(traj), FP32), traj)
+    for column in COLUMNS:
+        # relative to the column's magnitude; Backbone sums large cancelling spring energies -> small absolute floor
+        scale = np.maximum(np.abs(golden[column]), 1.0)
+        rel = np.abs(got[column] - golden[column]) / scale
+        assert rel.max() <= 1e-4, f"{protein} {column}: max rel diff {rel.max():.3e}"
+
+
+@pytest.mark.parametrize("protein", PROTEINS)
+@pytest.mark.parametrize("precision,tol", [(FP32, 1e-3), (FP64, 1e-9)])
+def test_forces_match_oracle_per_group(protein, precision, tol):
+    oa, traj, _ = golden_system(protein)
+    frames = [0, 5, 11]
+    gpu = _gpu(oa, len(frames), precision)
+    cpu = awsem_oracle.make_context(oa.system, n_replicas=len(frames), threads=3)
+    for r, f in enumerate(frames):
+        gpu.set_positions(traj[f], replica=r)
+        cpu.set_positions(traj[f], replica=r)
+    for name, g in FORCE_GROUP.items():
+        if name in ("Membrane", "ER", "TBM_Q"):
+            continue
+        fg, fc = gpu.forces(1 << g, redistribute=False), cpu.forces(1 << g, redistribute=False)
+        for r in range(len(frames)):
+            rel = np.linalg.norm(fg[r] - fc[r]) / max(np.linalg.norm(fc[r]), 1e-12)
+            assert rel <= tol, f"{protein} {name} frame {frames[r]}: relative force error {rel:.3e}"
+    # total, after virtual-site redistribution (what the integrator consumes)
+    fg, fc = gpu.forces(redistribute=True), cpu.forces(redistribute=True)
+    rel = np.linalg.norm(fg - fc) / np.linalg.norm(fc)
+    assert rel <= tol, f"{protein} total: {rel:.3e}"
+    virtual = sorted(oa.system.virtual_sites)
+    assert np.all(fg[:, virtual] == 0)
+
+
+def test_forces_are_bitwise_reproducible():
+    oa, traj, _ = golden_system("1brs")
+    gpu = _gpu(oa, 12, FP32)
+    for r in range(12):
+        gpu.set_positions(traj[r], replica=r)
+    a = gpu.forces()
+    for _ in range(3):
+        assert np.array_equal(a, gpu.forces())
+    e = gpu.energy_by_group()
+    assert np.array_equal(e, gpu.energy_by_group())
+
+
+def test_same_frame_in_every_replica_gives_identical_results():
+    oa, traj, _ = golden_system("1ubq")
+    gpu = _gpu(oa, 300, FP32)          # more workgroups than CUs
+    gpu.set_positions(traj[4], replica=-1)
+    f = gpu.forces()
+    assert np.all(f == f[0])
+    e = gpu.energy_by_group()
+    assert np.all(e == e[0])
+
+
+@pytest.mark.parametrize("precision,tol", [(FP32, 2e-5), (FP64, 1e-10)])
+def test_langevin_steps_track_oracle_with_shared_rng(precision, tol):
+    """OpenMM's LangevinIntegrator has no reference fixture (parity unpinned): the GPU integrator is compared
+    step-locked with the oracle's restatement using the shared Philox stream."""
+    oa, traj, _ = golden_system("1ubq")
+    R = 3
+    gpu = _gpu(oa, R, precision)
+    cpu = awsem_oracle.make_context(oa.system, n_replicas=R, threads=3)
+    T = np.array([300.0, 500.0, 800.0])
+    for ctx in (gpu, cpu):
+        for r in range(R):
+            ctx.set_positions(traj[r], replica=r)
+        ctx.set_velocities_to_temperature(T, 99)
+    for r in range(R):
+        assert np.allclose(gpu.get_velocities(r), cpu.get_velocities(r), atol=1e-5 if precision == FP32 else 1e-12)
+    for chunk in (1, 4, 5):
+        gpu.step(chunk, T, 0.002, 1.0, 2026)
+        cpu.step(chunk, T, 0.002, 1.0, 2026)
+    assert gpu.step_count == cpu.step_count == 10
+    for r in range(R):
+        dx = np.abs(gpu.get_positions(r) - cpu.get_positions(r)).max()
+        dv = np.abs(gpu.get_velocities(r) - cpu.get_velocities(r)).max()
+        assert dx <= tol and dv <= tol * 500, f"replica {r}: |dx|={dx:.3e} |dv|={dv:.3e}"
+
+
+def test_virtual_sites_recomputed_like_oracle():
+    oa, traj, _ = golden_system("2lyz")
+    gpu = _gpu(oa, 1, FP64)
+    cpu = awsem_oracle.make_context(oa.system)
+    x = traj[2].copy()
+    x[sorted(oa.system.virtual_sites)] += 0.05
+    for ctx in (gpu, cpu):
+        ctx.set_positions(x, replica=0)
+        ctx.compute_virtual_sites()
+    assert np.allclose(gpu.get_positions(0), cpu.get_positions(0), atol=1e-12)
+    assert np.allclose(gpu.get_positions(0), traj[2], atol=2e-3)   # the PDB/DCD stores 3-decimal Angstrom sites
+
+
+def test_bad_arguments_are_rejected_with_messages():
+    api = _capi.load_hip_library()
+    ctx = _capi.Context(api, 10, 1)
+    with pytest.raises(_capi.AwsemError, match="bad arguments"):
+        ctx.add_harmonic_bonds(20, [(0, 10)], [0.1], [1.0])      # atom index out of range
+    with pytest.raises(_capi.AwsemError, match="group"):
+        ctx.add_harmonic_bonds(32, [(0, 1)], [0.1], [1.0])
+    with pytest.raises(_capi.AwsemError, match="not finalized"):
+        ctx.energy()
+    ctx.finalize()
+    with pytest.raises(_capi.AwsemError, match="already finalized"):
+        ctx.add_harmonic_bonds(20, [(0, 1)], [0.1], [1.0])
