@@ -202,6 +202,7 @@ template <bool ENERGY, class real> __device__ void term_fm(const FmD<real>& d, c
         real dx = L.px[i] - L.px[j], dy = L.py[i] - L.py[j], dz = L.pz[i] - L.pz[j];
         real r2 = dx * dx + dy * dy + dz * dz, ir = M<real>::rsqrt(r2), r = r2 * ir;
         real fi = M<real>::floor(r * d.inv_dr);
+        fi -= (r - fi * d.dr < (real)0) ? (real)1 : (real)0;   // r*inv_dr may round up across a bin edge: keep r >= fi*dr
         int i1 = fi > (real)(d.ntab - 2) ? d.ntab - 2 : (int)fi;
         const real* row = d.table + (size_t)b * d.ntab + i1;
         real v1 = row[0], v2 = row[1];
