@@ -1,13 +1,28 @@
 // awsem_device.h -- device-side descriptors shared by the kernels (awsem_kernels.h) and the host API (awsem_hip.hip).
 //
 // One `DevSys<real>` describes a finalized AWSEM system: index arrays and parameter tables of every term, shared
-// by all replicas and read-only during evaluation.  Replica state (positions / velocities) lives in separate
-// SoA arrays and, during a launch, in the LDS of the one workgroup that owns the replica.
+// by all replicas and read-only during evaluation.  It is passed to the kernels BY VALUE: the whole descriptor
+// block lives in the kernarg segment, so every scalar parameter and table pointer is a scalar (s_load) operand in
+// the constant address space, hoisted out of the loops, and the tables behind the pointers are known-global
+// (global_load, not flat).  Replica state (positions / velocities) lives in separate SoA arrays and, during a
+// launch, in the LDS of the one workgroup that owns the replica.
 #pragma once
 #include <stdint.h>
 
 #define AWSEM_NGROUPS 32
 #define AWSEM_MAX_WELLS 4
+// instances of each term kind a system may hold (the kernarg block is limited to 4 KB)
+#define AWSEM_MAX_HARM 4
+#define AWSEM_MAX_CHI 2
+#define AWSEM_MAX_RAMA 4
+#define AWSEM_MAX_EXCL 2
+#define AWSEM_MAX_CONTACT 2
+#define AWSEM_MAX_BETA 4
+#define AWSEM_MAX_PAP 4
+#define AWSEM_MAX_HELICAL 2
+#define AWSEM_MAX_FM 2
+#define AWSEM_MAX_MEMB 2
+#define AWSEM_MAX_DH 2
 #define AWSEM_FIXED_SCALE 4294967296.0   // 2^32: forces, energies and densities are accumulated as int64 fixed point
 
 template <class real> struct HarmItem { int i, j; real r0, k; };
@@ -15,6 +30,7 @@ template <class real> struct HelicalItem { int o, n, h; real coef; };
 template <class real> struct DhItem { int i, j; real qq, pad; };
 template <class real> struct MembItem { int atom; real scale; };
 struct Int4 { int x, y, z, w; };
+template <class real> struct alignas(2 * sizeof(real)) real2_t { real x, y; };
 struct Int5 { int a[5]; };
 
 template <class real> struct HarmD { int group, n; const HarmItem<real>* items; };
@@ -35,7 +51,8 @@ template <class real> struct ExclD {
 };
 template <class real> struct ContactD {
     int group, nsites, env, min_seq_sep, flags, has_burial;
-    const int* atom; const int* restype; const int* resid; const int* chain;
+    const int* atom;
+    const int* info;                      // per site: resid (bits 0-15) | chain (16-26) | residue type (27-31)
     const real* gamma;                    // [2][3][400]
     const real* bgamma;                   // [20][3] (pre-multiplied by nothing; k_burial applied in kernel)
     real k, rmin, rmax, rminII, rmaxII, eta2, eta_s2, rho0, cutoff2, kappa2;
@@ -48,6 +65,8 @@ template <class real> struct BetaD {
     const Int4* don;                      // d1, d2, d3, residue
     const real* lambda;                   // nres x nres, row = donor residue, pre-multiplied by -k
     real r_ON, r_OH, inv_sNO2, inv_sHO2, cutoff2;   // inv_s*2 = 1/sigma^2
+    real screen2, max_expo;               // fp32 pre-screen: r_ON^2 bound and largest Gaussian exponent evaluated
+    int band_lo, band_hi;                 // lambda[q][p] == 0 whenever band_lo < q - p < band_hi (zero band around the diagonal)
 };
 template <class real> struct PapD {
     int group, nacc, ndon, nres;
@@ -55,9 +74,12 @@ template <class real> struct PapD {
     const Int4* don;                      // d1, d2, residue, -
     const real* gamma;                    // nres x nres, row = donor residue, pre-multiplied by -k
     real eta2, r0, d_i4, cutoff2;
+    real min_arg;                         // fp32 pre-screen: switches with argument below this are treated as 0
+    int band_lo, band_hi;                 // gamma[q][p] == 0 whenever band_lo < q - p < band_hi
 };
 template <class real> struct HelicalD { int group, n; const HelicalItem<real>* items; real r_ON, r_OH, inv_sNO2, inv_sHO2; };
-template <class real> struct FmD { int group, n, ntab; const int* pairs; const real* table; real k, dr, inv_dr; };
+// table2[b][i] = (t[b][i], t[b][i+1]) for i < ntab-1: the two interpolation nodes of a bin in one aligned load
+template <class real> struct FmD { int group, n, ntab; const int* pairs; const real2_t<real>* table2; real k, dr, inv_dr; };
 template <class real> struct MembD { int group, n; const MembItem<real>* items; real k, k_m2, z_m, center; };
 template <class real> struct DhD { int group, n; const DhItem<real>* items; real k, inv_lam; };
 
@@ -69,9 +91,11 @@ template <class real> struct DevSys {
     const real* inv_mass;                 // natoms (0 for massless)
     const real* sqrt_inv_mass;
     int n_harm, n_chi, n_rama, n_excl, n_contact, n_beta, n_pap, n_helical, n_fm, n_memb, n_dh;
-    const HarmD<real>* harm; const ChiD<real>* chi; const RamaD<real>* rama; const ExclD<real>* excl;
-    const ContactD<real>* contact; const BetaD<real>* beta; const PapD<real>* pap; const HelicalD<real>* helical;
-    const FmD<real>* fm; const MembD<real>* memb; const DhD<real>* dh;
+    HarmD<real> harm[AWSEM_MAX_HARM]; ChiD<real> chi[AWSEM_MAX_CHI]; RamaD<real> rama[AWSEM_MAX_RAMA];
+    ExclD<real> excl[AWSEM_MAX_EXCL]; ContactD<real> contact[AWSEM_MAX_CONTACT]; BetaD<real> beta[AWSEM_MAX_BETA];
+    PapD<real> pap[AWSEM_MAX_PAP]; HelicalD<real> helical[AWSEM_MAX_HELICAL]; FmD<real> fm[AWSEM_MAX_FM];
+    MembD<real> memb[AWSEM_MAX_MEMB]; DhD<real> dh[AWSEM_MAX_DH];
     int max_contact_sites;                // LDS scratch sizing
     int any_zdep;
 };
+static_assert(sizeof(DevSys<double>) <= 4000, "DevSys must fit the 4 KB kernarg segment");

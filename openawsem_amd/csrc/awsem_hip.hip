@@ -7,6 +7,7 @@
 // check mode running the identical kernels in fp64.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -206,10 +207,25 @@ private:
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     bool timing_pending_ = false;
     std::vector<void*> allocs_;
-    DevSys<real>* dsys_ = nullptr;
+    DevSys<real> dsys_;
     real *pos_ = nullptr, *vel_ = nullptr;
     double *dT_ = nullptr, *dE_ = nullptr, *dF_ = nullptr;
 };
+
+// Largest band of diagonals q - p around 0 on which the nres x nres table t[q][p] is identically zero:
+// t[q][p] == 0 for all lo < q - p < hi.
+static void zero_band(const std::vector<double>& t, int nres, int* lo, int* hi) {
+    auto diag_zero = [&](int dq) {
+        for (int q = std::max(0, dq); q < std::min(nres, nres + dq); q++)
+            if (t[(size_t)q * nres + (q - dq)] != 0.0) return false;
+        return true;
+    };
+    if (!diag_zero(0)) { *lo = 0; *hi = 0; return; }   // empty band: the test (dq <= 0 || dq >= 0) is always true
+    int h = 1, l = -1;
+    while (h < nres && diag_zero(h)) h++;
+    while (l > -nres && diag_zero(l)) l--;
+    *lo = l; *hi = h;
+}
 
 template <class real> void Engine<real>::finalize(const HostSystem& H) {
     HIP_TRY(hipSetDevice(device_));
@@ -238,7 +254,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             for (size_t b = 0; b < it.size(); b++) it[b] = HarmItem<real>{h.pairs[2 * b], h.pairs[2 * b + 1], (real)h.r0[b], (real)h.k[b]};
             D.push_back(HarmD<real>{h.group, (int)it.size(), upload(it)});
         }
-        S.n_harm = (int)D.size(); S.harm = upload(D);
+        if (D.size() > AWSEM_MAX_HARM) throw std::string("too many harm terms: at most " + std::to_string(AWSEM_MAX_HARM) + " per system");
+        S.n_harm = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.harm[t] = D[t];
     }
     {   // chi
         std::vector<ChiD<real>> D;
@@ -247,7 +264,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             for (size_t b = 0; b < a.size(); b++) a[b] = Int4{h.atoms[4 * b], h.atoms[4 * b + 1], h.atoms[4 * b + 2], h.atoms[4 * b + 3]};
             D.push_back(ChiD<real>{h.group, (int)a.size(), upload(a), (real)h.k, (real)h.chi0});
         }
-        S.n_chi = (int)D.size(); S.chi = upload(D);
+        if (D.size() > AWSEM_MAX_CHI) throw std::string("too many chi terms: at most " + std::to_string(AWSEM_MAX_CHI) + " per system");
+        S.n_chi = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.chi[t] = D[t];
     }
     {   // rama
         std::vector<RamaD<real>> D;
@@ -270,7 +288,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             }
             D.push_back(d);
         }
-        S.n_rama = (int)D.size(); S.rama = upload(D);
+        if (D.size() > AWSEM_MAX_RAMA) throw std::string("too many rama terms: at most " + std::to_string(AWSEM_MAX_RAMA) + " per system");
+        S.n_rama = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.rama[t] = D[t];
     }
     {   // excl: sort sites by class, per-site partner lists
         std::vector<ExclD<real>> D;
@@ -300,7 +319,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             d.atom = upload(atom); d.partners = upload(partners);
             D.push_back(d);
         }
-        S.n_excl = (int)D.size(); S.excl = upload(D);
+        if (D.size() > AWSEM_MAX_EXCL) throw std::string("too many excl terms: at most " + std::to_string(AWSEM_MAX_EXCL) + " per system");
+        S.n_excl = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.excl[t] = D[t];
     }
     {   // contact
         std::vector<ContactD<real>> D;
@@ -309,7 +329,16 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             memset(&d, 0, sizeof d);
             d.group = h.group; d.nsites = (int)h.atom.size(); d.env = h.env; d.min_seq_sep = h.min_seq_sep; d.flags = h.flags;
             d.has_burial = h.has_burial;
-            d.atom = upload(h.atom); d.restype = upload(h.restype); d.resid = upload(h.resid); d.chain = upload(h.chain);
+            d.atom = upload(h.atom);
+            {
+                std::vector<int> info(h.atom.size());
+                for (size_t i = 0; i < info.size(); i++) {
+                    if (h.resid[i] < 0 || h.resid[i] > 0xffff || h.chain[i] < 0 || h.chain[i] > 0x7ff)
+                        throw std::string("contact: residue index must be < 65536 and chain index < 2048");
+                    info[i] = h.resid[i] | (h.chain[i] << 16) | (h.restype[i] << 27);
+                }
+                d.info = upload(info);
+            }
             d.gamma = upload_real(h.gamma); d.bgamma = upload_real(h.bgamma);
             const double* p = h.p;
             d.k = (real)p[AWSEM_CP_K]; d.rmin = (real)p[AWSEM_CP_RMIN]; d.rmax = (real)p[AWSEM_CP_RMAX];
@@ -325,7 +354,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             if (h.flags & AWSEM_CONTACT_ZDEP) S.any_zdep = 1;
             D.push_back(d);
         }
-        S.n_contact = (int)D.size(); S.contact = upload(D);
+        if (D.size() > AWSEM_MAX_CONTACT) throw std::string("too many contact terms: at most " + std::to_string(AWSEM_MAX_CONTACT) + " per system");
+        S.n_contact = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.contact[t] = D[t];
     }
     {   // beta
         std::vector<BetaD<real>> D;
@@ -338,11 +368,21 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             for (int i = 0; i < d.ndon; i++) don[i] = Int4{h.don_atoms[3 * i], h.don_atoms[3 * i + 1], h.don_atoms[3 * i + 2], h.don_res[i]};
             d.acc = upload(acc); d.don = upload(don);
             d.lambda = upload_real(h.lambda, -h.k);
+            zero_band(h.lambda, h.nres, &d.band_lo, &d.band_hi);
             d.r_ON = (real)h.r_ON; d.r_OH = (real)h.r_OH; d.inv_sNO2 = (real)(1.0 / (h.s_NO * h.s_NO)); d.inv_sHO2 = (real)(1.0 / (h.s_HO * h.s_HO));
             d.cutoff2 = (real)(h.cutoff * h.cutoff);
+            if (sizeof(real) == 4) {   // conservative fp32 pre-screen: Gaussian factors below e^-30 are dropped
+                double rs = h.r_ON + std::sqrt(60.0) * h.s_NO;
+                d.screen2 = (real)std::min(h.cutoff * h.cutoff, rs * rs);
+                d.max_expo = (real)30;
+            } else {
+                d.screen2 = d.cutoff2;
+                d.max_expo = (real)1e300;
+            }
             D.push_back(d);
         }
-        S.n_beta = (int)D.size(); S.beta = upload(D);
+        if (D.size() > AWSEM_MAX_BETA) throw std::string("too many beta terms: at most " + std::to_string(AWSEM_MAX_BETA) + " per system");
+        S.n_beta = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.beta[t] = D[t];
     }
     {   // pap
         std::vector<PapD<real>> D;
@@ -355,10 +395,13 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             for (int i = 0; i < d.ndon; i++) don[i] = Int4{h.don_atoms[2 * i], h.don_atoms[2 * i + 1], h.don_res[i], 0};
             d.acc = upload(acc); d.don = upload(don);
             d.gamma = upload_real(h.gamma, -h.k);
+            zero_band(h.gamma, h.nres, &d.band_lo, &d.band_hi);
             d.eta2 = (real)(2 * h.eta); d.r0 = (real)h.r0; d.d_i4 = (real)h.d_i4; d.cutoff2 = (real)(h.cutoff * h.cutoff);
+            d.min_arg = sizeof(real) == 4 ? (real)-30 : (real)-1e300;
             D.push_back(d);
         }
-        S.n_pap = (int)D.size(); S.pap = upload(D);
+        if (D.size() > AWSEM_MAX_PAP) throw std::string("too many pap terms: at most " + std::to_string(AWSEM_MAX_PAP) + " per system");
+        S.n_pap = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.pap[t] = D[t];
     }
     {   // helical
         std::vector<HelicalD<real>> D;
@@ -367,13 +410,20 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             for (size_t b = 0; b < it.size(); b++) it[b] = HelicalItem<real>{h.atoms[3 * b], h.atoms[3 * b + 1], h.atoms[3 * b + 2], (real)h.coef[b]};
             D.push_back(HelicalD<real>{h.group, (int)it.size(), upload(it), (real)h.r_ON, (real)h.r_OH, (real)(1.0 / (h.s_NO * h.s_NO)), (real)(1.0 / (h.s_HO * h.s_HO))});
         }
-        S.n_helical = (int)D.size(); S.helical = upload(D);
+        if (D.size() > AWSEM_MAX_HELICAL) throw std::string("too many helical terms: at most " + std::to_string(AWSEM_MAX_HELICAL) + " per system");
+        S.n_helical = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.helical[t] = D[t];
     }
     {   // fragment memory
         std::vector<FmD<real>> D;
-        for (auto& h : H.fm)
-            D.push_back(FmD<real>{h.group, (int)(h.pairs.size() / 2), h.ntab, upload(h.pairs), upload_real(h.table), (real)h.k, (real)h.dr, (real)(1.0 / h.dr)});
-        S.n_fm = (int)D.size(); S.fm = upload(D);
+        for (auto& h : H.fm) {
+            const int nb = (int)(h.pairs.size() / 2);
+            std::vector<real2_t<real>> t2((size_t)nb * (h.ntab - 1));
+            for (int b = 0; b < nb; b++) for (int i = 0; i + 1 < h.ntab; i++)
+                t2[(size_t)b * (h.ntab - 1) + i] = real2_t<real>{(real)h.table[(size_t)b * h.ntab + i], (real)h.table[(size_t)b * h.ntab + i + 1]};
+            D.push_back(FmD<real>{h.group, nb, h.ntab, upload(h.pairs), upload(t2), (real)h.k, (real)h.dr, (real)(1.0 / h.dr)});
+        }
+        if (D.size() > AWSEM_MAX_FM) throw std::string("too many fm terms: at most " + std::to_string(AWSEM_MAX_FM) + " per system");
+        S.n_fm = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.fm[t] = D[t];
     }
     {   // membrane
         std::vector<MembD<real>> D;
@@ -382,7 +432,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             for (size_t b = 0; b < it.size(); b++) it[b] = MembItem<real>{h.atoms[b], (real)h.scale[b]};
             D.push_back(MembD<real>{h.group, (int)it.size(), upload(it), (real)h.k, (real)(2 * h.k_m), (real)h.z_m, (real)h.center});
         }
-        S.n_memb = (int)D.size(); S.memb = upload(D);
+        if (D.size() > AWSEM_MAX_MEMB) throw std::string("too many memb terms: at most " + std::to_string(AWSEM_MAX_MEMB) + " per system");
+        S.n_memb = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.memb[t] = D[t];
     }
     {   // debye-hueckel
         std::vector<DhD<real>> D;
@@ -391,10 +442,10 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             for (size_t b = 0; b < it.size(); b++) it[b] = DhItem<real>{h.pairs[2 * b], h.pairs[2 * b + 1], (real)h.qq[b], (real)0};
             D.push_back(DhD<real>{h.group, (int)it.size(), upload(it), (real)h.k, (real)(1.0 / h.lam)});
         }
-        S.n_dh = (int)D.size(); S.dh = upload(D);
+        if (D.size() > AWSEM_MAX_DH) throw std::string("too many dh terms: at most " + std::to_string(AWSEM_MAX_DH) + " per system");
+        S.n_dh = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.dh[t] = D[t];
     }
-    dsys_ = dalloc<DevSys<real>>(1);
-    HIP_TRY(hipMemcpy(dsys_, &S, sizeof S, hipMemcpyHostToDevice));
+    dsys_ = S;
 
     // replica state and outputs
     size_t nstate = (size_t)nrep_ * 3 * natoms_;

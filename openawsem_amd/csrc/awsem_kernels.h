@@ -64,9 +64,10 @@ template <class real> __device__ __forceinline__ void add_force(const Lds<real>&
 }
 // force of a pair potential: d = x_i - x_j, s = -dE/dr / r
 template <class real> __device__ __forceinline__ void pair_force(const Lds<real>& L, int i, int j, real dx, real dy, real dz, real s) {
-    real X = s * dx, Y = s * dy, Z = s * dz;
-    add_force(L, i, X, Y, Z);
-    add_force(L, j, -X, -Y, -Z);
+    // one fixed-point conversion per component: +F on i (ds_add_u64), -F on j (ds_sub_u64)
+    const u64 X = to_fixed(s * dx), Y = to_fixed(s * dy), Z = to_fixed(s * dz);
+    atomicAdd(&L.fx[i], X); atomicAdd(&L.fy[i], Y); atomicAdd(&L.fz[i], Z);
+    atomicSub(&L.fx[j], X); atomicSub(&L.fy[j], Y); atomicSub(&L.fz[j], Z);
 }
 
 template <bool ENERGY, class real> __device__ __forceinline__ void flush_energy(const Lds<real>& L, int group, double& e) {
@@ -195,20 +196,42 @@ template <bool ENERGY, class real> __device__ void term_helical(const HelicalD<r
     flush_energy<ENERGY>(L, d.group, e);
 }
 
+// Fragment memory: per bond two neighbouring floats of an L2-resident table row.  Four bonds are kept in flight per
+// thread so that the dependent chain (pair indices -> LDS coordinates -> table gather) overlaps across bonds.
 template <bool ENERGY, class real> __device__ void term_fm(const FmD<real>& d, const Lds<real>& L) {
     double e = 0;
-    for (int b = threadIdx.x; b < d.n; b += blockDim.x) {
-        int i = d.pairs[2 * b], j = d.pairs[2 * b + 1];
-        real dx = L.px[i] - L.px[j], dy = L.py[i] - L.py[j], dz = L.pz[i] - L.pz[j];
-        real r2 = dx * dx + dy * dy + dz * dz, ir = M<real>::rsqrt(r2), r = r2 * ir;
-        real fi = M<real>::floor(r * d.inv_dr);
-        fi -= (r - fi * d.dr < (real)0) ? (real)1 : (real)0;   // r*inv_dr may round up across a bin edge: keep r >= fi*dr
-        int i1 = fi > (real)(d.ntab - 2) ? d.ntab - 2 : (int)fi;
-        const real* row = d.table + (size_t)b * d.ntab + i1;
-        real v1 = row[0], v2 = row[1];
-        real slope = (v2 - v1) * d.inv_dr;
-        if (ENERGY) e += (double)(-d.k * (v1 + slope * (r - d.dr * (real)i1)));
-        pair_force(L, i, j, dx, dy, dz, d.k * slope * ir);
+    constexpr int U = 4;
+    const int stride = blockDim.x;
+    for (int b0 = threadIdx.x; b0 < d.n; b0 += U * stride) {
+        int ai[U], aj[U], i1[U];
+        real dx[U], dy[U], dz[U], ir[U], r[U], v1[U], v2[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int b = b0 + u * stride;
+            ok[u] = b < d.n;
+            b = ok[u] ? b : b0;
+            ai[u] = d.pairs[2 * b]; aj[u] = d.pairs[2 * b + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int b = ok[u] ? b0 + u * stride : b0;
+            dx[u] = L.px[ai[u]] - L.px[aj[u]]; dy[u] = L.py[ai[u]] - L.py[aj[u]]; dz[u] = L.pz[ai[u]] - L.pz[aj[u]];
+            real r2 = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
+            ir[u] = M<real>::rsqrt(r2); r[u] = r2 * ir[u];
+            real fi = M<real>::floor(r[u] * d.inv_dr);
+            fi -= (r[u] - fi * d.dr < (real)0) ? (real)1 : (real)0;   // r*inv_dr may round up across a bin edge: keep r >= fi*dr
+            i1[u] = fi > (real)(d.ntab - 2) ? d.ntab - 2 : (int)fi;
+            const real2_t<real> v = d.table2[(size_t)b * (d.ntab - 1) + i1[u]];   // (t[i], t[i+1]) in one load
+            v1[u] = v.x; v2[u] = v.y;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!ok[u]) continue;
+            real slope = (v2[u] - v1[u]) * d.inv_dr;
+            if (ENERGY) e += (double)(-d.k * (v1[u] + slope * (r[u] - d.dr * (real)i1[u])));
+            pair_force(L, ai[u], aj[u], dx[u], dy[u], dz[u], d.k * slope * ir[u]);
+        }
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
@@ -240,75 +263,126 @@ template <bool ENERGY, class real> __device__ void term_dh(const DhD<real>& d, c
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-// ------------------------------------------------------------------ all-pairs (triangular) scans
-// Rows of a strictly-upper-triangular n x n pair matrix are folded two by two (row s with row n-1-s) into
-// "super-rows" of exactly n-1 pairs, so that a 64-lane wave walking a super-row stays full and the row index i is
-// uniform over long lane runs (its coordinates come from LDS as a broadcast).  Waves take super-rows round-robin.
-#define TRI_FOREACH(n, I, J, ...)                                                    \
-    {                                                                                \
-        const int _n = (n), _nw = blockDim.x >> 6, _lane = threadIdx.x & 63;         \
-        const int _half = (_n + 1) >> 1;                                             \
-        for (int _s = threadIdx.x >> 6; _s < _half; _s += _nw) {                     \
-            const int _len0 = _n - 1 - _s;                                           \
-            const int _i1 = _n - 1 - _s;                                             \
-            const int _tot = (_i1 == _s) ? _len0 : _n - 1;                           \
-            for (int _l = _lane; _l < _tot; _l += 64) {                              \
-                int I, J;                                                            \
-                if (_l < _len0) { I = _s; J = _s + 1 + _l; }                         \
-                else { I = _i1; J = _i1 + 1 + (_l - _len0); }                        \
-                __VA_ARGS__                                                          \
-            }                                                                        \
-        }                                                                            \
-    }
+// ------------------------------------------------------------------ wave-level primitives for the pair scans
+// Pair scans keep the "column" entity (site j / donor) resident in the registers of lane j for a whole 64-wide
+// chunk and walk the "row" entities (site i / acceptor) with v_readlane broadcasts: no memory traffic and no
+// index loads in the inner loop.  Column-side sums stay in registers (fixed row order, so the result is
+// deterministic) and leave the wave as one conflict-free fixed-point atomic per column entity.
+__device__ __forceinline__ int bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float bcast(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ double bcast(double v, int lane) {
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Rows are walked in groups of U per wave: the U distance screens (and, when any lane of any row passes, the U
+// branch-free bodies) are independent instruction chains that the scheduler interleaves, which is what hides the
+// readlane / transcendental / LDS latencies at the 4 waves per SIMD this kernel runs at.  Bodies are predicated
+// (select, not branch) so that a group stays one basic block; a group in which no lane passes is skipped.
+#define AWSEM_ROW_GROUPS(U, nrows, k0) for (int k0 = wave * (U); k0 < (nrows); k0 += nw * (U))
 
 template <bool ENERGY, class real> __device__ void term_excl(const ExclD<real>& d, const Lds<real>& L) {
     double e = 0;
+    constexpr int U = 4;
     const real r02 = d.r0 * d.r0;
+    const int nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int c = 0; c < d.nclass; c++) {
         const int base = d.class_start[c], n = d.class_start[c + 1] - base;
-        TRI_FOREACH(n, i, j, {
-            int a = d.atom[base + i], b = d.atom[base + j];
-            real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
-            real r2 = dx * dx + dy * dy + dz * dz;
-            if (r2 < r02) {
-                Int4 p = d.partners[base + i];
-                if (p.x != b && p.y != b && p.z != b && p.w != b) {
-                    real ir = M<real>::rsqrt(r2), dr = r2 * ir - d.r0;
-                    if (ENERGY) e += (double)(d.k * dr * dr);
-                    pair_force(L, a, b, dx, dy, dz, (real)-2 * d.k * dr * ir);
+        for (int cj = 0; cj < n; cj += 64) {
+            const int j = cj + lane;
+            const bool vj = j < n;
+            const int b = d.atom[base + (vj ? j : n - 1)];
+            const Int4 pj = d.partners[base + (vj ? j : n - 1)];   // atoms excluded from interacting with b
+            const real xj = L.px[b], yj = L.py[b], zj = L.pz[b];
+            real fjx = 0, fjy = 0, fjz = 0;
+            for (int ci = 0; ci < n; ci += 64) {   // full square: lane j collects the force on its own site only
+                const int il = ci + lane;
+                const int a_l = d.atom[base + (il < n ? il : n - 1)];
+                const real xi_l = L.px[a_l], yi_l = L.py[a_l], zi_l = L.pz[a_l];
+                const int nrows = min(64, n - ci);
+                AWSEM_ROW_GROUPS(U, nrows, k0) {
+                    real dx[U], dy[U], dz[U], r2[U];
+                    bool pass[U], any = false;
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int k = min(k0 + u, nrows - 1), a = bcast(a_l, k);
+                        dx[u] = bcast(xi_l, k) - xj; dy[u] = bcast(yi_l, k) - yj; dz[u] = bcast(zi_l, k) - zj;
+                        r2[u] = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
+                        pass[u] = (k0 + u < nrows) && vj && a != b && r2[u] < r02 && pj.x != a && pj.y != a && pj.z != a && pj.w != a;
+                        any |= pass[u];
+                    }
+                    if (__ballot(any) == 0) continue;   // clashes only
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        real ir = M<real>::rsqrt(pass[u] ? r2[u] : (real)1), dr = r2[u] * ir - d.r0;
+                        if (ENERGY) e += pass[u] ? 0.5 * (double)(d.k * dr * dr) : 0.0;
+                        real fs = pass[u] ? (real)2 * d.k * dr * ir : (real)0;   // force on j = +dE/dr (x_i - x_j)/r
+                        fjx += fs * dx[u]; fjy += fs * dy[u]; fjz += fs * dz[u];
+                    }
                 }
             }
-        })
+            if (vj && (fjx != (real)0 || fjy != (real)0 || fjz != (real)0)) add_force(L, b, fjx, fjy, fjz);
+        }
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-// Contact pass 1: density rho_i = sum_j theta_I(r_ij) over |resid_i - resid_j| >= 2 inside the cutoff.
+// The three contact passes walk the FULL n x n pair square: lane j owns site j and accumulates everything that
+// belongs to j (density, dE/drho_j, force on j) in registers over all rows i != j; the mirrored contribution to i
+// is produced when the roles are swapped.  Every pair is therefore evaluated twice, but no lane is idle (a
+// triangular walk masks half of them), there is no cross-lane reduction, and the only atomics are one
+// conflict-free fixed-point add per site and wave at the end of a pass.  The pair energy is symmetric bit for bit
+// (all operands commute), so each evaluation books half of it.
+//
+// Contact pass 1: density rho_j = sum_i theta_I(r_ij) over |resid_i - resid_j| >= 2 inside the cutoff.
 template <class real> __device__ void contact_density(const ContactD<real>& d, const Lds<real>& L) {
-    TRI_FOREACH(d.nsites, i, j, {
-        int ri = d.resid[i] - d.resid[j];
-        if (ri >= 2 || ri <= -2) {
-            int a = d.atom[i], b = d.atom[j];
-            real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
-            real r2 = dx * dx + dy * dy + dz * dz;
-            if (r2 < d.cutoff2) {
-                real r = M<real>::sqrt(r2);
-                real th = sigmoid(d.eta2 * (r - d.rmin)) * sigmoid(d.eta2 * (d.rmax - r));
-                u64 f = to_fixed(th);
-                if (f) { atomicAdd(&L.rho[i], f); atomicAdd(&L.rho[j], f); }
+    constexpr int U = 4;
+    const int n = d.nsites, nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (int cj = 0; cj < n; cj += 64) {
+        const int j = cj + lane;
+        const bool vj = j < n;
+        const int jj = vj ? j : n - 1, b = d.atom[jj], rj = d.info[jj] & 0xffff;
+        const real xj = L.px[b], yj = L.py[b], zj = L.pz[b];
+        real rho_j = 0;
+        for (int ci = 0; ci < n; ci += 64) {
+            const int il = ci + lane, ii = il < n ? il : n - 1, a_l = d.atom[ii], ri_l = d.info[ii] & 0xffff;
+            const real xi_l = L.px[a_l], yi_l = L.py[a_l], zi_l = L.pz[a_l];
+            const int nrows = min(64, n - ci);
+            AWSEM_ROW_GROUPS(U, nrows, k0) {
+                real r2[U];
+                bool pass[U], any = false;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int k = min(k0 + u, nrows - 1), dres = bcast(ri_l, k) - rj;
+                    real dx = bcast(xi_l, k) - xj, dy = bcast(yi_l, k) - yj, dz = bcast(zi_l, k) - zj;
+                    r2[u] = dx * dx + dy * dy + dz * dz;
+                    pass[u] = (k0 + u < nrows) && vj && (dres >= 2 || dres <= -2) && r2[u] < d.cutoff2;
+                    any |= pass[u];
+                }
+                if (__ballot(any) == 0) continue;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    real r = M<real>::sqrt(r2[u]);
+                    real th = sigmoid(d.eta2 * (r - d.rmin)) * sigmoid(d.eta2 * (d.rmax - r));
+                    rho_j += pass[u] ? th : (real)0;
+                }
             }
         }
-    })
+        if (vj) atomicAdd(&L.rho[j], to_fixed(rho_j));
+    }
 }
-// Between pass 1 and 2: convert densities, evaluate the burial wells (single-particle energy) and seed dE/drho.
+// Between pass 1 and 2: evaluate the burial wells (single-particle energy), seed dE/drho, and precompute the
+// per-site water switch s_i = sig(-2 eta_s (rho_i - rho0)) (sigma_water_ij = s_i s_j) into L.rhov.
 template <bool ENERGY, class real> __device__ void contact_single(const ContactD<real>& d, const Lds<real>& L) {
     double e = 0;
     for (int i = threadIdx.x; i < d.nsites; i += blockDim.x) {
         real rho = (real)fixed_to_double(L.rho[i]);
-        L.rhov[i] = rho;
+        L.rhov[i] = sigmoid(-d.eta_s2 * (rho - d.rho0));
         real dE = 0;
         if (d.has_burial) {
-            int t = d.restype[i];
+            int t = (d.info[i] >> 27) & 31;
 #pragma unroll
             for (int m = 0; m < 3; m++) {
                 real gb = d.bgamma[t * 3 + m];
@@ -331,109 +405,177 @@ template <bool ENERGY, class real> __device__ void contact_single(const ContactD
 // Contact pass 2: pair energy (direct + mediated), its explicit radial force, and dE/drho through sigma_water.
 template <bool ENERGY, class real> __device__ void contact_pairs(const ContactD<real>& d, const Lds<real>& L) {
     double e = 0;
+    constexpr int U = 2;
     const bool zdep = d.flags & 1;
-    const real* g0 = L.gamma + (zdep ? 0 : 0);
-    TRI_FOREACH(d.nsites, i, j, {
-        int ri = d.resid[i] - d.resid[j];
-        bool ok = d.chain[i] != d.chain[j] || ri >= d.min_seq_sep || -ri >= d.min_seq_sep;
-        if (ok) {
-            int a = d.atom[i], b = d.atom[j];
-            real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
-            real r2 = dx * dx + dy * dy + dz * dz;
-            if (r2 < d.cutoff2) {
-                real ir = M<real>::rsqrt(r2), r = r2 * ir;
-                real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
-                real s3 = sigmoid(d.eta2 * (r - d.rminII)), s4 = sigmoid(d.eta2 * (d.rmaxII - r));
-                real th1 = s1 * s2, dth1 = d.eta2 * th1 * (s2 - s1);
-                real th2 = s3 * s4, dth2 = d.eta2 * th2 * (s4 - s3);
-                // sigma_water = 1/4 (1-tanh(eta_s(rho_i-rho0)))(1-tanh(...)) = sig(-2 eta_s (rho_i - rho0)) sig(...)
-                real si = sigmoid(-d.eta_s2 * (L.rhov[i] - d.rho0)), sj = sigmoid(-d.eta_s2 * (L.rhov[j] - d.rho0));
-                real sw = si * sj, dsi = -d.eta_s2 * si * ((real)1 - si), dsj = -d.eta_s2 * sj * ((real)1 - sj);
-                int ty = d.restype[i] * 20 + d.restype[j];
-                real E, dEdr, dEdsw;
-                if (!zdep) {
-                    real gd = g0[ty], gp = g0[400 + ty], gw = g0[800 + ty];
-                    real med = sw * gw + ((real)1 - sw) * gp;
-                    E = -d.k * (gd * th1 + th2 * med);
-                    dEdr = -d.k * (gd * dth1 + dth2 * med);
-                    dEdsw = -d.k * th2 * (gw - gp);
-                } else {
-                    const real* g1 = L.gamma + 1200;
-                    real med0 = sw * g0[800 + ty] + ((real)1 - sw) * g0[400 + ty];
-                    real med1 = sw * g1[800 + ty] + ((real)1 - sw) * g1[400 + ty];
-                    real W = -d.k * (g0[ty] * th1 + th2 * med0), Mm = -d.k * (g1[ty] * th1 + th2 * med1);
-                    real dW = -d.k * (g0[ty] * dth1 + dth2 * med0), dM = -d.k * (g1[ty] * dth1 + dth2 * med1);
-                    real ai = L.alpha[i], aj = L.alpha[j], aa = ai * aj;
-                    E = ((real)1 - aa) * W + aa * Mm;
-                    dEdr = ((real)1 - aa) * dW + aa * dM;
-                    dEdsw = -d.k * th2 * (((real)1 - aa) * (g0[800 + ty] - g0[400 + ty]) + aa * (g1[800 + ty] - g1[400 + ty]));
-                    atomicAdd(&L.fz[a], to_fixed(-(Mm - W) * L.dalpha[i] * aj));
-                    atomicAdd(&L.fz[b], to_fixed(-(Mm - W) * ai * L.dalpha[j]));
+    const real* g0 = L.gamma;
+    const real* g1 = L.gamma + 1200;
+    const int n = d.nsites, nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const real one = (real)1, zero = (real)0;
+    for (int cj = 0; cj < n; cj += 64) {
+        const int j = cj + lane;
+        const bool vj = j < n;
+        const int jj = vj ? j : n - 1, b = d.atom[jj], info_j = d.info[jj];
+        const int rj = info_j & 0xffff, chj = (info_j >> 16) & 0x7ff, tj = (info_j >> 27) & 31;
+        const real xj = L.px[b], yj = L.py[b], zj = L.pz[b], sj = L.rhov[jj];
+        const real dsj = -d.eta_s2 * sj * (one - sj);
+        const real alj = zdep ? L.alpha[jj] : zero, dalj = zdep ? L.dalpha[jj] : zero;
+        real fjx = 0, fjy = 0, fjz = 0, drho_j = 0;
+        for (int ci = 0; ci < n; ci += 64) {
+            const int il = ci + lane, ii = il < n ? il : n - 1, a_l = d.atom[ii], info_l = d.info[ii];
+            const real xi_l = L.px[a_l], yi_l = L.py[a_l], zi_l = L.pz[a_l], si_l = L.rhov[ii];
+            const real ali_l = zdep ? L.alpha[ii] : zero;
+            const int nrows = min(64, n - ci);
+            AWSEM_ROW_GROUPS(U, nrows, k0) {
+                real dx[U], dy[U], dz[U], r2[U];
+                int info_i[U], kk[U];
+                bool pass[U], any = false;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int k = min(k0 + u, nrows - 1);
+                    kk[u] = k;
+                    info_i[u] = bcast(info_l, k);
+                    const int dres = (info_i[u] & 0xffff) - rj;
+                    dx[u] = bcast(xi_l, k) - xj; dy[u] = bcast(yi_l, k) - yj; dz[u] = bcast(zi_l, k) - zj;
+                    r2[u] = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
+                    pass[u] = (k0 + u < nrows) && vj && (ci + k != j) && r2[u] < d.cutoff2 &&
+                              (((info_i[u] >> 16) & 0x7ff) != chj || dres >= d.min_seq_sep || -dres >= d.min_seq_sep);
+                    any |= pass[u];
                 }
-                if (ENERGY) e += (double)E;
-                atomicAdd(&L.drho[i], to_fixed(dEdsw * dsi * sj));
-                atomicAdd(&L.drho[j], to_fixed(dEdsw * si * dsj));
-                pair_force(L, a, b, dx, dy, dz, -dEdr * ir);
+                if (__ballot(any) == 0) continue;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    real ir = M<real>::rsqrt(pass[u] ? r2[u] : one), r = r2[u] * ir;
+                    real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
+                    real s3 = sigmoid(d.eta2 * (r - d.rminII)), s4 = sigmoid(d.eta2 * (d.rmaxII - r));
+                    real th1 = s1 * s2, dth1 = d.eta2 * th1 * (s2 - s1);
+                    real th2 = s3 * s4, dth2 = d.eta2 * th2 * (s4 - s3);
+                    real si = bcast(si_l, kk[u]), sw = si * sj;
+                    int ty = ((info_i[u] >> 27) & 31) * 20 + tj;
+                    real E, dEdr, dEdsw, fzx = zero;
+                    if (!zdep) {
+                        real gd = g0[ty], gp = g0[400 + ty], gw = g0[800 + ty];
+                        real med = sw * gw + (one - sw) * gp;
+                        E = -d.k * (gd * th1 + th2 * med);
+                        dEdr = -d.k * (gd * dth1 + dth2 * med);
+                        dEdsw = -d.k * th2 * (gw - gp);
+                    } else {
+                        real med0 = sw * g0[800 + ty] + (one - sw) * g0[400 + ty];
+                        real med1 = sw * g1[800 + ty] + (one - sw) * g1[400 + ty];
+                        real W = -d.k * (g0[ty] * th1 + th2 * med0), Mm = -d.k * (g1[ty] * th1 + th2 * med1);
+                        real dW = -d.k * (g0[ty] * dth1 + dth2 * med0), dM = -d.k * (g1[ty] * dth1 + dth2 * med1);
+                        real ai = bcast(ali_l, kk[u]), aa = ai * alj;
+                        E = (one - aa) * W + aa * Mm;
+                        dEdr = (one - aa) * dW + aa * dM;
+                        dEdsw = -d.k * th2 * ((one - aa) * (g0[800 + ty] - g0[400 + ty]) + aa * (g1[800 + ty] - g1[400 + ty]));
+                        fzx = -(Mm - W) * ai * dalj;
+                    }
+                    if (ENERGY) e += pass[u] ? 0.5 * (double)E : 0.0;
+                    drho_j += pass[u] ? dEdsw * si * dsj : zero;
+                    real fs = pass[u] ? dEdr * ir : zero;   // force on j = +dE/dr * (x_i - x_j)/r
+                    fjx += fs * dx[u]; fjy += fs * dy[u]; fjz += fs * dz[u] + (pass[u] ? fzx : zero);
+                }
             }
         }
-    })
+        if (vj) {
+            add_force(L, b, fjx, fjy, fjz);
+            atomicAdd(&L.drho[j], to_fixed(drho_j));
+        }
+    }
     flush_energy<ENERGY>(L, d.group, e);
 }
-// Contact pass 3: chain rule through the densities: F += -(dE/drho_i + dE/drho_j) theta_I'(r) r_hat
+// Contact pass 3: chain rule through the densities: F_j += (dE/drho_i + dE/drho_j) theta_I'(r) (x_i - x_j)/r
 template <class real> __device__ void contact_chain_rule(const ContactD<real>& d, const Lds<real>& L) {
-    TRI_FOREACH(d.nsites, i, j, {
-        int ri = d.resid[i] - d.resid[j];
-        if (ri >= 2 || ri <= -2) {
-            int a = d.atom[i], b = d.atom[j];
-            real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
-            real r2 = dx * dx + dy * dy + dz * dz;
-            if (r2 < d.cutoff2) {
-                real ir = M<real>::rsqrt(r2), r = r2 * ir;
-                real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
-                real dth = d.eta2 * s1 * s2 * (s2 - s1);
-                real c = (L.drhov[i] + L.drhov[j]) * dth;
-                if (c != (real)0) pair_force(L, a, b, dx, dy, dz, -c * ir);
+    constexpr int U = 4;
+    const int n = d.nsites, nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (int cj = 0; cj < n; cj += 64) {
+        const int j = cj + lane;
+        const bool vj = j < n;
+        const int jj = vj ? j : n - 1, b = d.atom[jj], rj = d.info[jj] & 0xffff;
+        const real xj = L.px[b], yj = L.py[b], zj = L.pz[b], gj = (real)fixed_to_double(L.drho[jj]);
+        real fjx = 0, fjy = 0, fjz = 0;
+        for (int ci = 0; ci < n; ci += 64) {
+            const int il = ci + lane, ii = il < n ? il : n - 1, a_l = d.atom[ii], ri_l = d.info[ii] & 0xffff;
+            const real xi_l = L.px[a_l], yi_l = L.py[a_l], zi_l = L.pz[a_l], gi_l = (real)fixed_to_double(L.drho[ii]);
+            const int nrows = min(64, n - ci);
+            AWSEM_ROW_GROUPS(U, nrows, k0) {
+                real dx[U], dy[U], dz[U], r2[U], gi[U];
+                bool pass[U], any = false;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int k = min(k0 + u, nrows - 1), dres = bcast(ri_l, k) - rj;
+                    gi[u] = bcast(gi_l, k);
+                    dx[u] = bcast(xi_l, k) - xj; dy[u] = bcast(yi_l, k) - yj; dz[u] = bcast(zi_l, k) - zj;
+                    r2[u] = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
+                    pass[u] = (k0 + u < nrows) && vj && (dres >= 2 || dres <= -2) && r2[u] < d.cutoff2;
+                    any |= pass[u];
+                }
+                if (__ballot(any) == 0) continue;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    real ir = M<real>::rsqrt(pass[u] ? r2[u] : (real)1), r = r2[u] * ir;
+                    real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
+                    real fs = pass[u] ? (gi[u] + gj) * d.eta2 * s1 * s2 * (s2 - s1) * ir : (real)0;
+                    fjx += fs * dx[u]; fjy += fs * dy[u]; fjz += fs * dz[u];
+                }
             }
         }
-    })
+        if (vj) add_force(L, b, fjx, fjy, fjz);
+    }
 }
 
 // ------------------------------------------------------------------ acceptor x donor scans (CustomHbondForce shape)
-// A wave takes acceptors round-robin (acceptor operands are wave-uniform LDS broadcasts), its lanes walk the donors.
+// Donors are lane-resident per 64-chunk (atoms and coordinates in registers), acceptors are broadcast row by row;
+// waves split the acceptor rows.  In fp32 the scan uses a conservative pre-screen (terms below e^-30 of their
+// maximum are skipped, far under fp32 resolution); the fp64 check mode applies only the reference's cutoff.
 template <bool ENERGY, class real> __device__ void term_beta(const BetaD<real>& d, const Lds<real>& L) {
     double e = 0;
-    const int nw = blockDim.x >> 6, lane = threadIdx.x & 63;
-    for (int ia = threadIdx.x >> 6; ia < d.nacc; ia += nw) {
-        Int4 A = d.acc[ia];
-        real ox = L.px[A.x], oy = L.py[A.x], oz = L.pz[A.x];
-        const real* lam_col = d.lambda + A.w;
-        for (int id = lane; id < d.ndon; id += 64) {
-            Int4 D = d.don[id];
-            real ax = ox - L.px[D.x], ay = oy - L.py[D.x], az = oz - L.pz[D.x];
-            real r1s = ax * ax + ay * ay + az * az;
-            if (r1s >= d.cutoff2) continue;
-            real c = lam_col[(size_t)D.w * d.nres];   // -k * lambda[don_res][acc_res]
-            if (c == (real)0) continue;
-            real bx = ox - L.px[D.y], by = oy - L.py[D.y], bz = oz - L.pz[D.y];
-            real r2s = bx * bx + by * by + bz * bz;
-            real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s), g1, g2;
-            real th1 = hb_theta(r1s * i1, r2s * i2, d.r_ON, d.r_OH, d.inv_sNO2, d.inv_sHO2, g1, g2);
-            if (!d.two_theta) {
-                if (ENERGY) e += (double)(c * th1);
-                pair_force(L, A.x, D.x, ax, ay, az, -c * g1 * i1);
-                pair_force(L, A.x, D.y, bx, by, bz, -c * g2 * i2);
-            } else {
-                real px = L.px[D.z], py = L.py[D.z], pz = L.pz[D.z];
-                real cx = px - L.px[A.y], cy = py - L.py[A.y], cz = pz - L.pz[A.y];
-                real ex = px - L.px[A.z], ey = py - L.py[A.z], ez = pz - L.pz[A.z];
-                real r3s = cx * cx + cy * cy + cz * cz, r4s = ex * ex + ey * ey + ez * ez;
-                real i3 = M<real>::rsqrt(r3s), i4 = M<real>::rsqrt(r4s), h1, h2;
-                real th2 = hb_theta(r3s * i3, r4s * i4, d.r_ON, d.r_OH, d.inv_sNO2, d.inv_sHO2, h1, h2);
-                if (ENERGY) e += (double)(c * th1 * th2);
-                pair_force(L, A.x, D.x, ax, ay, az, -c * g1 * th2 * i1);
-                pair_force(L, A.x, D.y, bx, by, bz, -c * g2 * th2 * i2);
-                pair_force(L, D.z, A.y, cx, cy, cz, -c * th1 * h1 * i3);
-                pair_force(L, D.z, A.z, ex, ey, ez, -c * th1 * h2 * i4);
+    const int nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (int cd = 0; cd < d.ndon; cd += 64) {
+        const int id = cd + lane;
+        const bool vd = id < d.ndon;
+        const Int4 D = d.don[vd ? id : d.ndon - 1];
+        const real nx = L.px[D.x], ny = L.py[D.x], nz = L.pz[D.x];
+        const real hx = L.px[D.y], hy = L.py[D.y], hz = L.pz[D.y];
+        const real* lam_row = d.lambda + (size_t)D.w * d.nres;
+        for (int ca = 0; ca < d.nacc; ca += 64) {
+            const int ial = ca + lane;
+            const Int4 A = d.acc[ial < d.nacc ? ial : d.nacc - 1];
+            const real ox_l = L.px[A.x], oy_l = L.py[A.x], oz_l = L.pz[A.x];
+            const int nrows = min(64, d.nacc - ca);
+            for (int k = wave; k < nrows; k += nw) {
+                const real ox = bcast(ox_l, k), oy = bcast(oy_l, k), oz = bcast(oz_l, k);
+                real ax = ox - nx, ay = oy - ny, az = oz - nz;
+                real r1s = ax * ax + ay * ay + az * az;
+                const int ares = bcast(A.w, k), dq = D.w - ares;
+                if (!(vd && r1s < d.screen2 && (dq <= d.band_lo || dq >= d.band_hi))) continue;
+                real c = lam_row[ares];   // -k * lambda[don_res][acc_res]
+                if (c == (real)0) continue;
+                real bx = ox - hx, by = oy - hy, bz = oz - hz;
+                real r2s = bx * bx + by * by + bz * bz;
+                real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
+                real da = r1s * i1 - d.r_ON, db = r2s * i2 - d.r_OH;
+                real ex1 = (real)0.5 * (da * da * d.inv_sNO2 + db * db * d.inv_sHO2);
+                if (ex1 > d.max_expo) continue;
+                real th1 = M<real>::exp(-ex1), g1 = -th1 * da * d.inv_sNO2, g2 = -th1 * db * d.inv_sHO2;
+                const int a1 = bcast(A.x, k);
+                if (!d.two_theta) {
+                    if (ENERGY) e += (double)(c * th1);
+                    pair_force(L, a1, D.x, ax, ay, az, -c * g1 * i1);
+                    pair_force(L, a1, D.y, bx, by, bz, -c * g2 * i2);
+                } else {
+                    const int a2 = bcast(A.y, k), a3 = bcast(A.z, k);
+                    real px = L.px[D.z], py = L.py[D.z], pz = L.pz[D.z];
+                    real cx = px - L.px[a2], cy = py - L.py[a2], cz = pz - L.pz[a2];
+                    real ex = px - L.px[a3], ey = py - L.py[a3], ez = pz - L.pz[a3];
+                    real r3s = cx * cx + cy * cy + cz * cz, r4s = ex * ex + ey * ey + ez * ez;
+                    real i3 = M<real>::rsqrt(r3s), i4 = M<real>::rsqrt(r4s), h1, h2;
+                    real th2 = hb_theta(r3s * i3, r4s * i4, d.r_ON, d.r_OH, d.inv_sNO2, d.inv_sHO2, h1, h2);
+                    if (ENERGY) e += (double)(c * th1 * th2);
+                    pair_force(L, a1, D.x, ax, ay, az, -c * g1 * th2 * i1);
+                    pair_force(L, a1, D.y, bx, by, bz, -c * g2 * th2 * i2);
+                    pair_force(L, D.z, a2, cx, cy, cz, -c * th1 * h1 * i3);
+                    pair_force(L, D.z, a3, ex, ey, ez, -c * th1 * h2 * i4);
+                }
             }
         }
     }
@@ -442,31 +584,48 @@ template <bool ENERGY, class real> __device__ void term_beta(const BetaD<real>& 
 
 template <bool ENERGY, class real> __device__ void term_pap(const PapD<real>& d, const Lds<real>& L) {
     double e = 0;
-    const int nw = blockDim.x >> 6, lane = threadIdx.x & 63;
-    for (int ia = threadIdx.x >> 6; ia < d.nacc; ia += nw) {
-        Int4 A = d.acc[ia];
-        real a1x = L.px[A.x], a1y = L.py[A.x], a1z = L.pz[A.x];
-        real a2x = L.px[A.y], a2y = L.py[A.y], a2z = L.pz[A.y];
-        real ex = a1x - a2x, ey = a1y - a2y, ez = a1z - a2z;
-        real r3s = ex * ex + ey * ey + ez * ez, i3 = M<real>::rsqrt(r3s);
-        real s3 = sigmoid(d.eta2 * (r3s * i3 - d.d_i4));   // 1/2 (1 + tanh(eta (|a1-a2| - d_i4)))
-        const real* gam_col = d.gamma + A.z;
-        for (int id = lane; id < d.ndon; id += 64) {
-            Int4 D = d.don[id];
-            real ax = a1x - L.px[D.x], ay = a1y - L.py[D.x], az = a1z - L.pz[D.x];
-            real r1s = ax * ax + ay * ay + az * az;
-            if (r1s >= d.cutoff2) continue;
-            real c = gam_col[(size_t)D.z * d.nres];   // -k * gamma[don_res][acc_res]
-            if (c == (real)0) continue;
-            real bx = a2x - L.px[D.y], by = a2y - L.py[D.y], bz = a2z - L.pz[D.y];
-            real r2s = bx * bx + by * by + bz * bz;
-            real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
-            real s1 = sigmoid(d.eta2 * (d.r0 - r1s * i1)), s2 = sigmoid(d.eta2 * (d.r0 - r2s * i2));
-            if (ENERGY) e += (double)(c * s1 * s2 * s3);
-            // d s1/dr1 = -eta2 s1 (1-s1) etc.
-            pair_force(L, A.x, D.x, ax, ay, az, c * d.eta2 * s1 * ((real)1 - s1) * s2 * s3 * i1);
-            pair_force(L, A.y, D.y, bx, by, bz, c * s1 * d.eta2 * s2 * ((real)1 - s2) * s3 * i2);
-            pair_force(L, A.x, A.y, ex, ey, ez, -c * s1 * s2 * d.eta2 * s3 * ((real)1 - s3) * i3);
+    const int nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const real one = (real)1;
+    for (int cd = 0; cd < d.ndon; cd += 64) {
+        const int id = cd + lane;
+        const bool vd = id < d.ndon;
+        const Int4 D = d.don[vd ? id : d.ndon - 1];
+        const real n1x = L.px[D.x], n1y = L.py[D.x], n1z = L.pz[D.x];
+        const real n2x = L.px[D.y], n2y = L.py[D.y], n2z = L.pz[D.y];
+        const real* gam_row = d.gamma + (size_t)D.z * d.nres;
+        for (int ca = 0; ca < d.nacc; ca += 64) {
+            const int ial = ca + lane;
+            const Int4 A = d.acc[ial < d.nacc ? ial : d.nacc - 1];
+            const real a1x_l = L.px[A.x], a1y_l = L.py[A.x], a1z_l = L.pz[A.x];
+            const real a2x_l = L.px[A.y], a2y_l = L.py[A.y], a2z_l = L.pz[A.y];
+            // row-only factor 1/2 (1 + tanh(eta (|a1-a2| - d_i4))), computed once per acceptor by its lane
+            const real ex_l = a1x_l - a2x_l, ey_l = a1y_l - a2y_l, ez_l = a1z_l - a2z_l;
+            const real r3s_l = ex_l * ex_l + ey_l * ey_l + ez_l * ez_l, i3_l = M<real>::rsqrt(r3s_l);
+            const real arg3_l = d.eta2 * (r3s_l * i3_l - d.d_i4);
+            const real s3_l = sigmoid(arg3_l);
+            const int nrows = min(64, d.nacc - ca);
+            for (int k = wave; k < nrows; k += nw) {
+                if (bcast(arg3_l, k) < d.min_arg) continue;   // whole acceptor switched off (uniform branch)
+                const real a1x = bcast(a1x_l, k), a1y = bcast(a1y_l, k), a1z = bcast(a1z_l, k);
+                real ax = a1x - n1x, ay = a1y - n1y, az = a1z - n1z;
+                real r1s = ax * ax + ay * ay + az * az;
+                const int ares = bcast(A.z, k), dq = D.z - ares;
+                if (!(vd && r1s < d.cutoff2 && (dq <= d.band_lo || dq >= d.band_hi))) continue;
+                real c = gam_row[ares];   // -k * gamma[don_res][acc_res]
+                if (c == (real)0) continue;
+                real bx = bcast(a2x_l, k) - n2x, by = bcast(a2y_l, k) - n2y, bz = bcast(a2z_l, k) - n2z;
+                real r2s = bx * bx + by * by + bz * bz;
+                real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
+                real arg2 = d.eta2 * (d.r0 - r2s * i2);
+                if (arg2 < d.min_arg) continue;
+                real s1 = sigmoid(d.eta2 * (d.r0 - r1s * i1)), s2 = sigmoid(arg2), s3 = bcast(s3_l, k);
+                if (ENERGY) e += (double)(c * s1 * s2 * s3);
+                const int a1 = bcast(A.x, k), a2 = bcast(A.y, k);
+                pair_force(L, a1, D.x, ax, ay, az, c * d.eta2 * s1 * (one - s1) * s2 * s3 * i1);
+                pair_force(L, a2, D.y, bx, by, bz, c * s1 * d.eta2 * s2 * (one - s2) * s3 * i2);
+                pair_force(L, a1, a2, bcast(ex_l, k), bcast(ey_l, k), bcast(ez_l, k),
+                           -c * s1 * s2 * d.eta2 * s3 * (one - s3) * bcast(i3_l, k));
+            }
         }
     }
     flush_energy<ENERGY>(L, d.group, e);
@@ -497,7 +656,15 @@ template <class real> __device__ void redistribute_forces(const DevSys<real>& S,
 
 // Evaluate every term whose group is in `mask`.  Forces accumulate into L.f* (must be zeroed by the caller and
 // be visible: call after a __syncthreads()); ends with all contributions visible to the whole workgroup.
-template <bool ENERGY, class real> __device__ void evaluate_terms(const DevSys<real>& S, const Lds<real>& L, unsigned mask) {
+template <class real> __device__ void stage_contact_gamma(const ContactD<real>& d, const Lds<real>& L) {
+    if (d.flags & 2) return;
+    const int ng = (d.flags & 1) ? 2400 : 1200;
+    const real* src = d.gamma + ((d.flags & 1) ? 0 : d.env * 1200);
+    for (int i = threadIdx.x; i < ng; i += blockDim.x) L.gamma[i] = src[i];
+}
+// `stage_gamma`: copy the contact gamma tables to LDS before use; a caller that evaluates a system with a single
+// contact term many times (the step kernel) stages them once itself and passes false.
+template <bool ENERGY, class real> __device__ void evaluate_terms(const DevSys<real>& S, const Lds<real>& L, unsigned mask, bool stage_gamma = true) {
 #define ON(d) ((mask >> (d).group) & 1u)
     for (int t = 0; t < S.n_harm; t++) if (ON(S.harm[t])) term_harmonic<ENERGY>(S.harm[t], L);
     for (int t = 0; t < S.n_fm; t++) if (ON(S.fm[t])) term_fm<ENERGY>(S.fm[t], L);
@@ -515,11 +682,7 @@ template <bool ENERGY, class real> __device__ void evaluate_terms(const DevSys<r
         if (!ON(d)) continue;
         __syncthreads();   // previous user of the contact scratch (or previous contact term) is done
         for (int i = threadIdx.x; i < d.nsites; i += blockDim.x) L.rho[i] = 0;
-        if (!(d.flags & 2)) {
-            const int ng = (d.flags & 1) ? 2400 : 1200;
-            const real* src = d.gamma + ((d.flags & 1) ? 0 : d.env * 1200);
-            for (int i = threadIdx.x; i < ng; i += blockDim.x) L.gamma[i] = src[i];
-        }
+        if (stage_gamma) stage_contact_gamma(d, L);
         __syncthreads();
         contact_density(d, L);
         __syncthreads();
@@ -529,8 +692,6 @@ template <bool ENERGY, class real> __device__ void evaluate_terms(const DevSys<r
             contact_pairs<ENERGY>(d, L);
             __syncthreads();
         }
-        for (int i = threadIdx.x; i < d.nsites; i += blockDim.x) L.drhov[i] = (real)fixed_to_double(L.drho[i]);
-        __syncthreads();
         contact_chain_rule(d, L);
     }
 #undef ON
@@ -571,10 +732,9 @@ template <class real> __device__ inline void load_positions(const real* g, const
 
 // ------------------------------------------------------------------ evaluation kernel (energies and/or forces)
 template <bool ENERGY, class real>
-__global__ void awsem_eval_kernel(const DevSys<real>* __restrict__ Sp, const real* __restrict__ pos, unsigned mask, int redistribute,
+__global__ void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__ pos, unsigned mask, int redistribute,
                                   double* __restrict__ e_out /* [R][32] or null */, double* __restrict__ f_out /* [R][natoms][3] or null */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const DevSys<real>& S = *Sp;
     const int natoms = S.natoms, rep = blockIdx.x;
     Lds<real> L = carve_lds<real>(smem, natoms, S.max_contact_sites, false);
     load_positions(pos + (size_t)rep * 3 * natoms, L, natoms);
@@ -622,9 +782,8 @@ template <class real> __device__ __forceinline__ void gauss3(unsigned long long 
 #define AWSEM_KB 0.00831446261815324
 
 template <class real>
-__global__ void awsem_maxwell_kernel(const DevSys<real>* __restrict__ Sp, real* __restrict__ vel, const double* __restrict__ T,
+__global__ void awsem_maxwell_kernel(const DevSys<real> S, real* __restrict__ vel, const double* __restrict__ T,
                                      unsigned long long seed) {
-    const DevSys<real>& S = *Sp;
     const int natoms = S.natoms, rep = blockIdx.x;
     real* v = vel + (size_t)rep * 3 * natoms;
     for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
@@ -638,8 +797,7 @@ __global__ void awsem_maxwell_kernel(const DevSys<real>* __restrict__ Sp, real* 
 }
 
 template <class real>
-__global__ void awsem_vsite_kernel(const DevSys<real>* __restrict__ Sp, real* __restrict__ pos) {
-    const DevSys<real>& S = *Sp;
+__global__ void awsem_vsite_kernel(const DevSys<real> S, real* __restrict__ pos) {
     const int natoms = S.natoms;
     real* p = pos + (size_t)blockIdx.x * 3 * natoms;
     for (int i = threadIdx.x; i < S.nvs; i += blockDim.x) {
@@ -653,11 +811,10 @@ __global__ void awsem_vsite_kernel(const DevSys<real>* __restrict__ Sp, real* __
 // OpenMM LangevinIntegrator update (see oracle/awsem_oracle.c: awsem_oracle_step) with the state LDS-resident:
 // per step: virtual sites -> forces (all groups) -> virtual-site force redistribution -> v, x update.
 template <class real>
-__global__ void awsem_step_kernel(const DevSys<real>* __restrict__ Sp, real* __restrict__ pos, real* __restrict__ vel,
+__global__ void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, real* __restrict__ vel,
                                   const double* __restrict__ T, int nsteps, double dt, double friction, unsigned long long seed,
                                   long long step0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const DevSys<real>& S = *Sp;
     const int natoms = S.natoms, rep = blockIdx.x;
     Lds<real> L = carve_lds<real>(smem, natoms, S.max_contact_sites, true);
     real* gp = pos + (size_t)rep * 3 * natoms;
@@ -667,12 +824,14 @@ __global__ void awsem_step_kernel(const DevSys<real>* __restrict__ Sp, real* __r
     const double a_d = ::exp(-friction * dt);
     const real a = (real)a_d, fs = (real)(friction == 0.0 ? dt : (1.0 - a_d) / friction);
     const real ns = (real)::sqrt(AWSEM_KB * T[rep] * (1.0 - a_d * a_d)), dtr = (real)dt;
+    const bool stage_each_step = S.n_contact != 1;
+    if (!stage_each_step) stage_contact_gamma(S.contact[0], L);
     __syncthreads();
     for (int s = 0; s < nsteps; s++) {
         compute_virtual_sites(S, L);
         for (int i = threadIdx.x; i < natoms; i += blockDim.x) { L.fx[i] = 0; L.fy[i] = 0; L.fz[i] = 0; }
         __syncthreads();
-        evaluate_terms<false>(S, L, 0xffffffffu);
+        evaluate_terms<false>(S, L, 0xffffffffu, stage_each_step);
         redistribute_forces(S, L);
         __syncthreads();
         for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
