@@ -153,6 +153,11 @@ int awsem_compute_virtual_sites(awsem_handle h);
 /* context.setVelocitiesToTemperature scripts/mm_run.py:151; T is per replica (n_replicas). */
 int awsem_set_velocities_to_temperature(awsem_handle h, const double* T_kelvin, uint64_t seed);
 
+/* Multiply the velocities of replica r by scale[r] (n_replicas factors).  Used after a replica-exchange swap of
+ * temperature labels, v *= sqrt(T_new/T_old); the reference delegates REMD to openmmtools' ReplicaExchangeSampler
+ * (scripts/mm_remd.py:133-149), which exchanges thermodynamic states between replicas in the same way. */
+int awsem_scale_velocities(awsem_handle h, const double* scale);
+
 /* ---- evaluation ----------------------------------------------------------------------------------------
  * context.getState(getEnergy=True, groups=...) scripts/mm_analyze.py:165-178, tests/test_energies.py:119.
  * awsem_energy: one potential energy per replica for the masked groups.

@@ -33,7 +33,7 @@ from .unit import *  # noqa: E402,F401,F403
 from .openAWSEM import (OpenMMAWSEMSystem, PDBFile, getAllChains, read_fasta, xml,  # noqa: E402,F401
                         three_to_one, one_to_three)
 from . import functionTerms  # noqa: E402,F401
-from .functionTerms import (basicTerms, contactTerms, debyeHuckelTerms, hydrogenBondTerms, membraneTerms,  # noqa: E402,F401
+from .functionTerms import (basicTerms, biasTerms, contactTerms, debyeHuckelTerms, hydrogenBondTerms, membraneTerms,  # noqa: E402,F401
                             templateTerms)
 
 
@@ -48,7 +48,7 @@ def install_as_openawsem(force: bool = False):
         sys.modules["openawsem"] = me
         for sub in ("functionTerms", "openAWSEM", "unit", "forces"):
             sys.modules[f"openawsem.{sub}"] = importlib.import_module(f"{__name__}.{sub}")
-        for sub in ("basicTerms", "contactTerms", "debyeHuckelTerms", "hydrogenBondTerms", "membraneTerms", "templateTerms"):
+        for sub in ("basicTerms", "biasTerms", "contactTerms", "debyeHuckelTerms", "hydrogenBondTerms", "membraneTerms", "templateTerms"):
             sys.modules[f"openawsem.functionTerms.{sub}"] = importlib.import_module(f"{__name__}.functionTerms.{sub}")
         helper = types.ModuleType("openawsem.helperFunctions")
         myf = types.ModuleType("openawsem.helperFunctions.myFunctions")

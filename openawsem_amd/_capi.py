@@ -45,6 +45,7 @@ _SIGNATURES = {
     "get_velocities": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_int]),
     "compute_virtual_sites": (C.c_int, ["H"]),
     "set_velocities_to_temperature": (C.c_int, ["H", c_dbl_p, C.c_uint64]),
+    "scale_velocities": (C.c_int, ["H", c_dbl_p]),
     "energy": (C.c_int, ["H", C.c_uint32, c_dbl_p]),
     "energy_by_group": (C.c_int, ["H", c_dbl_p]),
     "forces": (C.c_int, ["H", C.c_uint32, C.c_int, c_dbl_p]),
@@ -234,6 +235,10 @@ class Context:
     def set_velocities_to_temperature(self, T, seed):
         T = np.broadcast_to(_f64(T), (self.n_replicas,)).copy()
         self._call("set_velocities_to_temperature", _dp(T), C.c_uint64(int(seed)))
+
+    def scale_velocities(self, scale):
+        sc = np.broadcast_to(_f64(scale), (self.n_replicas,)).copy()
+        self._call("scale_velocities", _dp(sc))
 
     # ---- evaluation
     def energy(self, group_mask=0xFFFFFFFF):

@@ -76,6 +76,7 @@ struct EngineBase {
     virtual void get_velocities(int rep, double* v) = 0;
     virtual void compute_virtual_sites() = 0;
     virtual void maxwell(const double* T, uint64_t seed) = 0;
+    virtual void scale_velocities(const double* scale) = 0;
     virtual void energy_by_group(unsigned mask, double* e) = 0;
     virtual void forces(unsigned mask, int redistribute, double* f) = 0;
     virtual void step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) = 0;
@@ -116,6 +117,13 @@ public:
         HIP_TRY(hipSetDevice(device_));
         upload_T(T);
         hipLaunchKernelGGL(awsem_maxwell_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, vel_, dT_, (unsigned long long)seed);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream_));
+    }
+    void scale_velocities(const double* scale) override {
+        HIP_TRY(hipSetDevice(device_));
+        upload_T(scale);   // reuses the per-replica double buffer
+        hipLaunchKernelGGL(awsem_scale_velocities_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, vel_, dT_, 3 * natoms_);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream_));
     }
@@ -692,6 +700,11 @@ int awsem_set_velocities_to_temperature(awsem_handle h, const double* T, uint64_
     NEED_RUN(h);
     if (!T) return fail(AWSEM_EINVAL, "set_velocities_to_temperature: null temperatures");
     GUARD_BEGIN h->eng->maxwell(T, seed); return AWSEM_OK; GUARD_END
+}
+int awsem_scale_velocities(awsem_handle h, const double* scale) {
+    NEED_RUN(h);
+    if (!scale) return fail(AWSEM_EINVAL, "scale_velocities: null factors");
+    GUARD_BEGIN h->eng->scale_velocities(scale); return AWSEM_OK; GUARD_END
 }
 int awsem_energy_by_group(awsem_handle h, double* e) {
     NEED_RUN(h);

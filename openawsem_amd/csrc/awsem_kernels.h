@@ -797,6 +797,13 @@ __global__ void awsem_maxwell_kernel(const DevSys<real> S, real* __restrict__ ve
 }
 
 template <class real>
+__global__ void awsem_scale_velocities_kernel(real* __restrict__ vel, const double* __restrict__ scale, int n3) {
+    real* v = vel + (size_t)blockIdx.x * n3;
+    const real s = (real)scale[blockIdx.x];
+    for (int i = threadIdx.x; i < n3; i += blockDim.x) v[i] *= s;
+}
+
+template <class real>
 __global__ void awsem_vsite_kernel(const DevSys<real> S, real* __restrict__ pos) {
     const int natoms = S.natoms;
     real* p = pos + (size_t)blockIdx.x * 3 * natoms;

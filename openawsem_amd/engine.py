@@ -1,0 +1,430 @@
+"""The handful of OpenMM classes the openawsem drivers use, backed by libawsem_hip.so.
+
+Reference call sites: openawsem/scripts/mm_run.py:33-38,125-175 (Platform, LangevinIntegrator, CustomIntegrator,
+Simulation, reporters, minimizeEnergy, step, checkpoints), openawsem/scripts/mm_analyze.py:115-178 and
+tests/test_energies.py:105-122 (context.setPositions / getState(getEnergy=True, groups=...)).
+
+Beyond the OpenMM surface, `Simulation(..., n_replicas=R)` runs R independent trajectories of the same system in one
+engine handle (one workgroup per replica on the GPU); `Context.getState(replica=r)`, per-replica temperatures and
+`Context.energies()` expose the batch.  There is no CPU fallback: creating a Context without a GPU raises.
+"""
+from __future__ import annotations
+
+import sys
+import time
+
+import numpy as np
+
+from . import _capi, unit as u
+from .dcd import DCDWriter
+from .forces import Force, System
+
+KB = u.BOLTZMANN_KJ_PER_MOL_K
+
+
+def _value(x, unit_):
+    return x.value_in_unit(unit_) if u.is_quantity(x) else float(x)
+
+
+# --------------------------------------------------------------------------- platform / integrators
+class Platform:
+    """Platform.getPlatformByName(name): every OpenMM platform name maps onto the MI355X engine; 'Reference' selects
+    its fp64 check mode (the reference's golden energies were produced on OpenMM's Reference platform), everything
+    else ('HIP', 'CUDA', 'OpenCL', 'CPU') the fp32 production kernels."""
+    _names = ("HIP", "CUDA", "OpenCL", "CPU", "Reference")
+
+    def __init__(self, name):
+        self.name = name
+        self.properties = {"Threads": "1", "DeviceIndex": "0", "Precision": "double" if name == "Reference" else "single"}
+
+    @staticmethod
+    def getPlatformByName(name):
+        if name not in Platform._names:
+            raise ValueError(f'There is no registered Platform called "{name}"')
+        return Platform(name)
+
+    @staticmethod
+    def getNumPlatforms():
+        return len(Platform._names)
+
+    def getName(self):
+        return self.name
+
+    def setPropertyDefaultValue(self, key, value):
+        self.properties[key] = str(value)
+
+    def getPropertyDefaultValue(self, key):
+        return self.properties[key]
+
+    @property
+    def device(self):
+        return int(self.properties.get("DeviceIndex", "0"))
+
+
+class LangevinIntegrator:
+    """openmm.LangevinIntegrator(temperature, frictionCoeff, stepSize) -- scripts/mm_run.py:145."""
+
+    def __init__(self, temperature, frictionCoeff, stepSize):
+        self._T = _value(temperature, u.kelvin)
+        self._friction = _value(frictionCoeff, u.picosecond ** -1)
+        self._dt = _value(stepSize, u.picosecond)
+        self._seed = 0
+
+    def getTemperature(self):
+        return self._T * u.kelvin
+
+    def setTemperature(self, temperature):
+        self._T = _value(temperature, u.kelvin)
+
+    def getFriction(self):
+        return self._friction / u.picosecond
+
+    def setFriction(self, f):
+        self._friction = _value(f, u.picosecond ** -1)
+
+    def getStepSize(self):
+        return self._dt * u.picosecond
+
+    def setStepSize(self, dt):
+        self._dt = _value(dt, u.picosecond)
+
+    def setRandomNumberSeed(self, seed):
+        self._seed = int(seed)
+
+    def getRandomNumberSeed(self):
+        return self._seed
+
+
+class CustomIntegrator:
+    """openmm.CustomIntegrator(stepSize) with no computations, as the reference uses it to write the un-minimised and
+    minimised structure (scripts/mm_run.py:130-137): stepping advances the step counter only."""
+
+    def __init__(self, stepSize):
+        self._dt = _value(stepSize, u.picosecond)
+
+    def getStepSize(self):
+        return self._dt * u.picosecond
+
+
+# --------------------------------------------------------------------------- state / context
+class State:
+    def __init__(self, energy=None, kinetic=None, positions=None, velocities=None, forces=None, time_ps=0.0):
+        self._e, self._ke, self._x, self._v, self._f, self._t = energy, kinetic, positions, velocities, forces, time_ps
+
+    def getPotentialEnergy(self):
+        if self._e is None:
+            raise RuntimeError("getState was not called with getEnergy=True")
+        return self._e * u.kilojoule_per_mole
+
+    def getKineticEnergy(self):
+        if self._ke is None:
+            raise RuntimeError("getState was not called with getEnergy=True")
+        return self._ke * u.kilojoule_per_mole
+
+    def getPositions(self, asNumpy=False):
+        if self._x is None:
+            raise RuntimeError("getState was not called with getPositions=True")
+        return u.Quantity(self._x, u.nanometer)
+
+    def getVelocities(self, asNumpy=False):
+        if self._v is None:
+            raise RuntimeError("getState was not called with getVelocities=True")
+        return u.Quantity(self._v, u.nanometer / u.picosecond)
+
+    def getForces(self, asNumpy=False):
+        if self._f is None:
+            raise RuntimeError("getState was not called with getForces=True")
+        return u.Quantity(self._f, u.kilojoule_per_mole / u.nanometer)
+
+    def getTime(self):
+        return self._t * u.picosecond
+
+
+def _group_mask(groups):
+    if groups is None or groups == -1:
+        return 0xFFFFFFFF
+    if isinstance(groups, (set, frozenset, list, tuple)):
+        m = 0
+        for g in groups:
+            m |= 1 << int(g)
+        return m & 0xFFFFFFFF
+    return int(groups) & 0xFFFFFFFF
+
+
+class Context:
+    """openmm.Context for a `forces.System`; the arithmetic happens in libawsem_hip.so."""
+
+    def __init__(self, system: System, integrator, platform: Platform | None = None, n_replicas: int = 1):
+        if not isinstance(system, System):
+            raise TypeError("Context needs the System of an openawsem_amd.OpenMMAWSEMSystem")
+        self.system, self.integrator = system, integrator
+        self.platform = platform or Platform("HIP")
+        self.n_replicas = int(n_replicas)
+        api = _capi.load_hip_library()
+        self._ctx = _capi.Context(api, system.getNumParticles(), self.n_replicas, self.platform.device,
+                                  1 if self.platform.properties.get("Precision") == "double" else 0)
+        self._host_forces = [f for f in system.forces if getattr(f, "host_only", False)]
+        gpu_system = System(system.masses.copy())
+        gpu_system.virtual_sites = dict(system.virtual_sites)
+        gpu_system.forces = [f for f in system.forces if not getattr(f, "host_only", False)]
+        gpu_system.upload(self._ctx)
+        self.temperatures = None        # per-replica override of the integrator temperature
+        self._time_ps = 0.0
+        self._have_positions = False
+
+    # ---- state setters
+    def setPositions(self, positions, replica=-1):
+        x = np.asarray(_value(positions, u.nanometer) if u.is_quantity(positions) else positions, dtype=np.float64)
+        self._ctx.set_positions(x.reshape(-1, 3), replica)
+        self._have_positions = True
+
+    def setVelocities(self, velocities, replica=-1):
+        v = np.asarray(_value(velocities, u.nanometer / u.picosecond) if u.is_quantity(velocities) else velocities, dtype=np.float64)
+        self._ctx.set_velocities(v.reshape(-1, 3), replica)
+
+    def setVelocitiesToTemperature(self, temperature, randomSeed=None):
+        T = _value(temperature, u.kelvin) if not isinstance(temperature, (list, tuple, np.ndarray)) else np.asarray(temperature, float)
+        if randomSeed is None:
+            randomSeed = int(time.time() * 1e3) & 0x7FFFFFFF
+        self._ctx.set_velocities_to_temperature(T, int(randomSeed))
+
+    def computeVirtualSites(self):
+        self._ctx.compute_virtual_sites()
+
+    def setParameter(self, name, value):
+        raise NotImplementedError(f"global parameter {name!r}: the MI355X AWSEM engine has no run-time expression parameters")
+
+    def setReplicaTemperatures(self, T):
+        self.temperatures = None if T is None else np.broadcast_to(np.asarray(T, float), (self.n_replicas,)).copy()
+
+    # ---- queries
+    def energies(self, groups=-1):
+        """Potential energy of every replica (kJ/mol) for the given force groups."""
+        mask = _group_mask(groups)
+        e = self._ctx.energy(mask)
+        for f in self._host_forces:
+            if (mask >> f.getForceGroup()) & 1:
+                e = e + np.array([f.host_energy(self._ctx.get_positions(r)) for r in range(self.n_replicas)])
+        return e
+
+    def energiesByGroup(self):
+        e = self._ctx.energy_by_group()
+        for f in self._host_forces:
+            e[:, f.getForceGroup()] += [f.host_energy(self._ctx.get_positions(r)) for r in range(self.n_replicas)]
+        return e
+
+    def kineticEnergies(self):
+        m = self.system.masses
+        return np.array([0.5 * float((m[:, None] * self._ctx.get_velocities(r) ** 2).sum()) for r in range(self.n_replicas)])
+
+    def getState(self, getPositions=False, getVelocities=False, getForces=False, getEnergy=False, groups=-1,
+                 enforcePeriodicBox=False, replica=0):
+        e = ke = x = v = f = None
+        mask = _group_mask(groups)
+        if getEnergy:
+            e = float(self.energies(mask)[replica])
+            m = self.system.masses
+            ke = 0.5 * float((m[:, None] * self._ctx.get_velocities(replica) ** 2).sum())
+        if getPositions:
+            x = self._ctx.get_positions(replica)
+        if getVelocities:
+            v = self._ctx.get_velocities(replica)
+        if getForces:
+            f = self._ctx.forces(mask, redistribute=True)[replica]
+        return State(e, ke, x, v, f, self._time_ps)
+
+    def getSystem(self):
+        return self.system
+
+    def getIntegrator(self):
+        return self.integrator
+
+    def getPlatform(self):
+        return self.platform
+
+    # ---- dynamics
+    def _step(self, n):
+        integ = self.integrator
+        if isinstance(integ, CustomIntegrator):
+            self._ctx.step_count = self._ctx.step_count + n
+        else:
+            if self._host_forces:
+                raise NotImplementedError("the system contains analysis-only order parameters (q_value / rg_term); "
+                                          "they cannot bias a dynamics run on the MI355X engine")
+            T = self.temperatures if self.temperatures is not None else integ._T
+            self._ctx.step(n, T, integ._dt, integ._friction, integ._seed)
+        self._time_ps += n * _value(integ.getStepSize(), u.picosecond)
+
+
+# --------------------------------------------------------------------------- minimiser
+def minimize(context: Context, tolerance=10.0, maxIterations=0, replica=0):
+    """L-BFGS on the massive particles with virtual sites re-derived each evaluation -- the job of OpenMM's
+    LocalEnergyMinimizer behind simulation.minimizeEnergy() (scripts/mm_run.py:136,153).  Host-driven: energies and
+    redistributed forces come from the GPU engine, the optimiser is scipy's L-BFGS-B.  `tolerance` is the RMS force
+    criterion in kJ/mol/nm (OpenMM's default is 10)."""
+    from scipy.optimize import minimize as sp_minimize
+    tolerance = _value(tolerance, u.kilojoule_per_mole / u.nanometer)
+    ctx = context._ctx
+    massive = np.flatnonzero(context.system.masses > 0)
+    x_full = ctx.get_positions(replica)
+
+    def fun(xm):
+        x_full[massive] = xm.reshape(-1, 3)
+        ctx.set_positions(x_full, replica)
+        ctx.compute_virtual_sites()
+        e = float(context.energies()[replica])
+        f = ctx.forces(redistribute=True)[replica][massive]
+        return e, -f.reshape(-1)
+
+    res = sp_minimize(fun, x_full[massive].reshape(-1), jac=True, method="L-BFGS-B",
+                      options={"maxiter": int(maxIterations) if maxIterations else 5000,
+                               "gtol": tolerance, "ftol": 0.0, "maxcor": 20})
+    x_full[massive] = res.x.reshape(-1, 3)
+    ctx.set_positions(x_full, replica)
+    ctx.compute_virtual_sites()
+    return res
+
+
+# --------------------------------------------------------------------------- simulation + reporters
+class Simulation:
+    """openmm.app.Simulation(topology, system, integrator, platform) -- scripts/mm_run.py:126-175."""
+
+    def __init__(self, topology, system, integrator, platform=None, platformProperties=None, n_replicas=1):
+        self.topology, self.system, self.integrator = topology, system, integrator
+        self.context = Context(system, integrator, platform, n_replicas=n_replicas)
+        self.reporters = []
+        self.currentStep = 0
+
+    def minimizeEnergy(self, tolerance=10.0, maxIterations=0):
+        for r in range(self.context.n_replicas):
+            minimize(self.context, tolerance, maxIterations, replica=r)
+
+    def step(self, steps):
+        steps = int(steps)
+        end = self.currentStep + steps
+        while self.currentStep < end:
+            nxt = end
+            for rep in self.reporters:
+                k = rep._interval - self.currentStep % rep._interval
+                nxt = min(nxt, self.currentStep + k)
+            n = nxt - self.currentStep
+            self.context._step(n)
+            self.currentStep = nxt
+            for rep in self.reporters:
+                if self.currentStep % rep._interval == 0:
+                    rep.report(self)
+
+    # own checkpoint format: a numpy archive (OpenMM's is a platform-specific binary blob)
+    def saveCheckpoint(self, file):
+        c = self.context._ctx
+        R = self.context.n_replicas
+        arrays = {"positions": np.stack([c.get_positions(r) for r in range(R)]),
+                  "velocities": np.stack([c.get_velocities(r) for r in range(R)]),
+                  "step": np.array([self.currentStep, c.step_count], dtype=np.int64), "time_ps": np.array([self.context._time_ps])}
+        if isinstance(file, str):
+            with open(file, "wb") as fh:
+                np.savez(fh, **arrays)
+        else:
+            np.savez(file, **arrays)
+
+    def loadCheckpoint(self, file):
+        with np.load(file, allow_pickle=False) as z:
+            x, v, step, t = z["positions"], z["velocities"], z["step"], z["time_ps"]
+        if x.shape != (self.context.n_replicas, self.system.getNumParticles(), 3):
+            raise ValueError("checkpoint does not match this system / replica count")
+        for r in range(len(x)):
+            self.context._ctx.set_positions(x[r], r)
+            self.context._ctx.set_velocities(v[r], r)
+        self.currentStep = int(step[0])
+        self.context._ctx.step_count = int(step[1])
+        self.context._time_ps = float(t[0])
+
+    saveState, loadState = saveCheckpoint, loadCheckpoint
+
+
+class _Reporter:
+    def __init__(self, interval):
+        self._interval = max(1, int(interval))
+
+
+class StateDataReporter(_Reporter):
+    """step / potentialEnergy / temperature columns in OpenMM's CSV layout (scripts/mm_run.py:157-158); reports
+    replica 0 (plus the ensemble mean when there are several replicas)."""
+
+    def __init__(self, file, reportInterval, step=False, time=False, potentialEnergy=False, kineticEnergy=False,
+                 totalEnergy=False, temperature=False, separator=",", append=False, **_ignored):
+        super().__init__(reportInterval)
+        self._own = isinstance(file, str)
+        self._out = open(file, "a" if append else "w") if self._own else file
+        self._cols = dict(step=step, time=time, potentialEnergy=potentialEnergy, kineticEnergy=kineticEnergy,
+                          totalEnergy=totalEnergy, temperature=temperature)
+        self._sep, self._header = separator, False
+
+    def report(self, simulation, state=None):
+        ctx = simulation.context
+        names = {"step": "Step", "time": "Time (ps)", "potentialEnergy": "Potential Energy (kJ/mole)",
+                 "kineticEnergy": "Kinetic Energy (kJ/mole)", "totalEnergy": "Total Energy (kJ/mole)", "temperature": "Temperature (K)"}
+        if not self._header:
+            print('#"' + (f'"{self._sep}"').join(names[k] for k, on in self._cols.items() if on) + '"', file=self._out)
+            self._header = True
+        need_e = self._cols["potentialEnergy"] or self._cols["totalEnergy"]
+        pe = float(ctx.energies()[0]) if need_e else 0.0
+        ke = float(ctx.kineticEnergies()[0])
+        dof = 3 * int((simulation.system.masses > 0).sum())
+        vals = {"step": simulation.currentStep, "time": ctx._time_ps, "potentialEnergy": pe, "kineticEnergy": ke,
+                "totalEnergy": pe + ke, "temperature": 2 * ke / (dof * KB)}
+        print(self._sep.join(str(vals[k]) for k, on in self._cols.items() if on), file=self._out)
+        self._out.flush()
+
+    def __del__(self):
+        if getattr(self, "_own", False):
+            self._out.close()
+
+
+class DCDReporter(_Reporter):
+    """movie.dcd writer (scripts/mm_run.py:134,161); replica 0 unless `replica` is given."""
+
+    def __init__(self, file, reportInterval, append=False, enforcePeriodicBox=None, replica=0):
+        super().__init__(reportInterval)
+        self._file, self._append, self._writer, self._replica = file, append, None, replica
+
+    def report(self, simulation, state=None):
+        if self._writer is None:
+            self._writer = DCDWriter(self._file, simulation.system.getNumParticles(), append=self._append,
+                                     dt_ps=_value(simulation.integrator.getStepSize(), u.picosecond), interval=self._interval)
+        self._writer.write(simulation.context._ctx.get_positions(self._replica))
+
+
+class PDBReporter(_Reporter):
+    """native.pdb writer (scripts/mm_run.py:133): one MODEL per report."""
+
+    def __init__(self, file, reportInterval, enforcePeriodicBox=None, replica=0):
+        super().__init__(reportInterval)
+        self._out, self._model, self._replica = open(file, "w"), 0, replica
+
+    def report(self, simulation, state=None):
+        self._model += 1
+        x = simulation.context._ctx.get_positions(self._replica) * 10.0
+        print(f"MODEL     {self._model:4d}", file=self._out)
+        for a in simulation.topology.atoms():
+            r = a.residue
+            name = a.name if len(a.name) == 4 else " " + a.name
+            print("ATOM  %5d %-4s %3s %s%4s    %8.3f%8.3f%8.3f  1.00  0.00          %2s" %
+                  ((a.index + 1) % 100000, name, r.name, r.chain.id, r.id, x[a.index, 0], x[a.index, 1], x[a.index, 2],
+                   a.element if a.element else a.name[0]), file=self._out)
+        print("ENDMDL", file=self._out)
+        self._out.flush()
+
+
+class CheckpointReporter(_Reporter):
+    def __init__(self, file, reportInterval):
+        super().__init__(reportInterval)
+        self._file = file
+
+    def report(self, simulation, state=None):
+        simulation.saveCheckpoint(self._file)
+
+
+stdout = sys.stdout
+__all__ = ["Platform", "LangevinIntegrator", "CustomIntegrator", "Context", "State", "Simulation", "StateDataReporter",
+           "DCDReporter", "PDBReporter", "CheckpointReporter", "minimize", "Force", "System"]

@@ -712,6 +712,12 @@ int awsem_oracle_set_velocities_to_temperature(ctx_t* c, const double* T, uint64
     }
     return 0;
 }
+int awsem_oracle_scale_velocities(ctx_t* c, const double* scale) {
+    CHECK_RUN(c);
+    if (!scale) return fail(-1, "scale_velocities: null factors");
+    for (int r = 0; r < c->nrep; r++) for (int i = 0; i < c->natoms * 3; i++) c->vel[(size_t)r * c->natoms * 3 + i] *= scale[r];
+    return 0;
+}
 /* OpenMM LangevinIntegrator (ReferenceStochasticDynamics), as configured at scripts/mm_run.py:145:
  *   v <- a v + (1-a)/gamma F/m + sqrt(kT(1-a^2)/m) N(0,1),  a = exp(-gamma dt);   x <- x + v dt; virtual sites re-derived.
  * No constraints exist in the AWSEM system, so OpenMM's post-constraint v = (x'-x)/dt is the identity. */
