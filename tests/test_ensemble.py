@@ -1,0 +1,126 @@
+"""Multi-rank replica bookkeeping on CPU: sharding and temperature replica exchange over gloo (world_size 2).
+
+The reference has no multi-process code (its REMD driver, scripts/mm_remd.py:85-149, hands a linear temperature
+ladder to openmmtools' ReplicaExchangeSampler in one process), so there is no reference fixture for this: the swap
+rule is checked against the closed-form Metropolis criterion min(1, exp((beta_i - beta_j)(U_i - U_j))) and the
+multi-rank run against the single-rank run of the same seed ("parity unpinned").
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from openawsem_amd import ensemble
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_partitions_every_replica_exactly_once():
+    for n, world in [(1024, 8), (1024, 3), (12, 5), (7, 8), (1, 1)]:
+        seen = []
+        for rank in range(world):
+            r = ensemble.shard(n, world, rank)
+            assert len(r) in (n // world, n // world + 1)
+            seen.extend(r)
+        assert seen == list(range(n))
+
+
+def test_counter_uniform_is_deterministic_and_uniform():
+    u = np.array([ensemble.counter_uniform(7, it, i) for it in range(200) for i in range(10)])
+    assert np.all((u >= 0) & (u < 1))
+    assert abs(u.mean() - 0.5) < 0.03 and abs(np.var(u) - 1 / 12) < 0.01
+    assert ensemble.counter_uniform(7, 3, 4) == ensemble.counter_uniform(7, 3, 4)
+    assert ensemble.counter_uniform(7, 3, 4) != ensemble.counter_uniform(8, 3, 4)
+
+
+def test_exchange_follows_metropolis_criterion():
+    T = np.linspace(300.0, 600.0, 2)
+    beta = 1.0 / (ensemble.KB * T)
+    # favourable swap (hot replica has the lower energy): always accepted
+    remd = ensemble.ReplicaExchange(T, seed=1)
+    scale = remd.exchange(np.array([-100.0, -300.0]))
+    assert list(remd.slot) == [1, 0]
+    assert np.allclose(scale, np.sqrt([T[1] / T[0], T[0] / T[1]]))
+    # unfavourable swap: acceptance frequency -> exp(delta)
+    dU = 4.0
+    p_expected = np.exp((beta[0] - beta[1]) * (-dU))
+    acc, n = 0, 4000
+    for seed in range(n):
+        remd = ensemble.ReplicaExchange(T, seed=seed)
+        remd.exchange(np.array([-300.0, -300.0 + dU]))
+        acc += int(remd.accepted[0])
+    assert abs(acc / n - p_expected) < 4 * np.sqrt(p_expected * (1 - p_expected) / n)
+
+
+def test_exchange_alternates_even_and_odd_pairs_and_keeps_a_permutation():
+    T = np.linspace(200.0, 600.0, 12)      # the reference's default ladder (mm_remd.py:166-171)
+    remd = ensemble.ReplicaExchange(T, seed=5)
+    rng = np.random.default_rng(0)
+    for it in range(50):
+        U = rng.normal(-500, 50, size=12)
+        before = remd.attempted.copy()
+        remd.exchange(U)
+        tried = np.flatnonzero(remd.attempted - before)
+        assert np.all(tried % 2 == it % 2)
+        assert sorted(remd.slot) == list(range(12))
+    assert remd.accepted.sum() > 0
+
+
+_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from openawsem_amd import ensemble
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+T = np.linspace(200.0, 600.0, 13)          # odd count: unequal shards (7 + 6)
+remd = ensemble.ReplicaExchange(T, rank=rank, world=world, seed=11)
+local = remd.local
+slots, scales = [], []
+for it in range(40):
+    # synthetic 'potential energy' of replica r at its current temperature (deterministic, rank-independent)
+    U_all = -400.0 + 0.5 * T[remd.slot] + 40.0 * np.sin(0.7 * np.arange(13) + it)
+    s = remd.exchange(U_all[local.start:local.stop])
+    slots.append(remd.slot.copy()); scales.append(s)
+np.savez(os.path.join({out!r}, f"rank{{rank}}.npz"), slots=np.array(slots), scales=np.array(scales),
+         accepted=remd.accepted, start=local.start, stop=local.stop)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_over_gloo_take_identical_decisions(tmp_path):
+    import subprocess
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path)))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+    for p in procs:
+        assert p.wait(timeout=120) == 0
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    assert (int(r0["start"]), int(r0["stop"]), int(r1["start"]), int(r1["stop"])) == (0, 7, 7, 13)
+    assert np.array_equal(r0["slots"], r1["slots"])             # replicated bookkeeping stays in lock step
+    assert np.array_equal(r0["accepted"], r1["accepted"]) and r0["accepted"].sum() > 0
+
+    # single-rank run of the same ladder and seed: same decisions, and the per-rank scale vectors tile it
+    T = np.linspace(200.0, 600.0, 13)
+    remd = ensemble.ReplicaExchange(T, seed=11)
+    for it in range(40):
+        U_all = -400.0 + 0.5 * T[remd.slot] + 40.0 * np.sin(0.7 * np.arange(13) + it)
+        s = remd.exchange(U_all)
+        assert np.array_equal(remd.slot, r0["slots"][it])
+        assert np.allclose(s[:7], r0["scales"][it]) and np.allclose(s[7:], r1["scales"][it])
