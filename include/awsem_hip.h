@@ -168,6 +168,23 @@ int awsem_energy(awsem_handle h, uint32_t group_mask, double* e_per_replica);
 int awsem_energy_by_group(awsem_handle h, double* e_replica_by_group);
 int awsem_forces(awsem_handle h, uint32_t group_mask, int redistribute, double* f);
 
+/* Pair set of one pair term for one replica, from the engine's own list builder (the step kernel evaluates the
+ * pair terms from such lists, rebuilt whenever an atom has moved more than half the skin).  No counterpart in the
+ * reference: OpenMM keeps its neighbour lists private; this exists for the bit-exact list check against a
+ * brute-force O(N^2) scan.  kind/index select the term (index = order of the add_* calls of that kind).  A pair is
+ * listed when its screening distance r satisfies r < cutoff + skin, with r^2 = fma(dz,dz,fma(dy,dy,dx*dx))
+ * evaluated in the handle's precision from the stored coordinates:
+ *   AWSEM_LIST_EXCL     same-class site pairs minus the bonded exclusions, cutoff = r_excl;   pairs = atom indices (a < b)
+ *   AWSEM_LIST_CONTACT  site pairs that enter the density (|resid_i - resid_j| >= 2) or the pair energy (different chains
+ *                       or |resid_i - resid_j| >= min_seq_sep), cutoff = the CustomGB cutoff; pairs = site indices (i < j)
+ *   AWSEM_LIST_BETA     (acceptor, donor) index pairs with lambda != 0, r = |a1 - d1|, cutoff = the reference's
+ *                       cutoff (fp64) or the fp32 pre-screen r_ON + sqrt(60) sigma_NO, whichever is smaller
+ *   AWSEM_LIST_PAP      (acceptor, donor) index pairs with gamma != 0, r = |a1 - d1|, cutoff = the reference's cutoff
+ * Pairs are written sorted; *n_pairs is the total (call again with a larger buffer if it exceeds capacity). */
+enum { AWSEM_LIST_EXCL = 0, AWSEM_LIST_CONTACT = 1, AWSEM_LIST_BETA = 2, AWSEM_LIST_PAP = 3 };
+int awsem_neighbors(awsem_handle h, int replica, int kind, int index, double skin, int32_t* pairs, int capacity,
+                    int* n_pairs);
+
 /* simulation.step(n) with LangevinIntegrator(T, friction, dt) scripts/mm_run.py:145,171-175.
  * T_kelvin is per replica (integrator.setTemperature); all terms (every group) drive the dynamics. */
 int awsem_step(awsem_handle h, int nsteps, const double* T_kelvin, double dt_ps, double friction_per_ps,

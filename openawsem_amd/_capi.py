@@ -52,6 +52,7 @@ _SIGNATURES = {
     "step": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_double, C.c_double, C.c_uint64]),
     "step_count": (C.c_int64, ["H"]),
     "set_step_count": (C.c_int, ["H", C.c_int64]),
+    "neighbors": (C.c_int, ["H", C.c_int, C.c_int, C.c_int, C.c_double, c_int_p, C.c_int, c_int_p]),
     "last_kernel_ms": (C.c_int, ["H", c_dbl_p]),
     "synchronize": (C.c_int, ["H"]),
     "last_error": (C.c_char_p, []),
@@ -61,6 +62,9 @@ _SIGNATURES = {
 _HIP_ONLY = {}
 
 EXPORTED_SYMBOLS = tuple("awsem_" + n for n in list(_SIGNATURES) + list(_HIP_ONLY))
+
+
+LIST_EXCL, LIST_CONTACT, LIST_BETA, LIST_PAP = 0, 1, 2, 3
 
 
 class AwsemError(RuntimeError):
@@ -267,6 +271,17 @@ class Context:
     @step_count.setter
     def step_count(self, v):
         self._call("set_step_count", C.c_int64(int(v)))
+
+    def neighbors(self, kind, index=0, replica=0, skin=0.0):
+        """Sorted pair set (n x 2 int32) of one pair term; kind in LIST_EXCL / LIST_CONTACT / LIST_BETA / LIST_PAP."""
+        n = C.c_int32(0)
+        cap = 4096
+        while True:
+            pairs = np.empty((cap, 2), dtype=np.int32)
+            self._call("neighbors", int(replica), int(kind), int(index), float(skin), _ip(pairs), cap, C.byref(n))
+            if n.value <= cap:
+                return pairs[:n.value].copy()
+            cap = n.value
 
     def last_kernel_ms(self):
         ms = C.c_double()

@@ -24,6 +24,13 @@
 #define AWSEM_MAX_MEMB 2
 #define AWSEM_MAX_DH 2
 #define AWSEM_FIXED_SCALE 4294967296.0   // 2^32: forces, energies and densities are accumulated as int64 fixed point
+#define AWSEM_MAX_LISTS (AWSEM_MAX_EXCL + AWSEM_MAX_CONTACT + AWSEM_MAX_BETA + AWSEM_MAX_PAP)
+
+// Every pair term (excl, contact, beta, pap) owns one Verlet pair list per replica: 32-bit entries in a per-replica
+// global buffer (`DevSys::lists + replica * list_stride + list_off`), at most `list_cap` of them (= the number of
+// candidate pairs, so a list cannot overflow), counted by LDS counter `list_id`.  A pair is listed when its screening
+// distance is below cutoff + skin (`list_rc2` = (cutoff + skin)^2).
+struct ListSlot { int list_off, list_cap, list_id; };
 
 template <class real> struct HarmItem { int i, j; real r0, k; };
 template <class real> struct HelicalItem { int o, n, h; real coef; };
@@ -48,6 +55,7 @@ template <class real> struct ExclD {
     const Int4* partners;                 // per site: up to 4 excluded partner ATOM indices (-1 padded)
     int class_start[9];                   // class c occupies sites [class_start[c], class_start[c+1])
     real k, r0;
+    ListSlot ls; real list_rc2;           // entry = atom_a << 16 | atom_b
 };
 template <class real> struct ContactD {
     int group, nsites, env, min_seq_sep, flags, has_burial;
@@ -58,8 +66,10 @@ template <class real> struct ContactD {
     real k, rmin, rmax, rminII, rmaxII, eta2, eta_s2, rho0, cutoff2, kappa2;
     real rho_lo[3], rho_hi[3];
     real eta_sw2, z_m, zc, kb;
+    ListSlot ls; real list_rc2;           // entry = site_i | site_j << 10 | (type_i*20+type_j) << 20 | in_density << 30 | has_pair_energy << 31
 };
 template <class real> struct BetaD {
+    static constexpr int res_slot = 3;    // acc/don records carry the residue index in .w
     int group, two_theta, nacc, ndon, nres;
     const Int4* acc;                      // a1, a2, a3, residue
     const Int4* don;                      // d1, d2, d3, residue
@@ -67,8 +77,10 @@ template <class real> struct BetaD {
     real r_ON, r_OH, inv_sNO2, inv_sHO2, cutoff2;   // inv_s*2 = 1/sigma^2
     real screen2, max_expo;               // fp32 pre-screen: r_ON^2 bound and largest Gaussian exponent evaluated
     int band_lo, band_hi;                 // lambda[q][p] == 0 whenever band_lo < q - p < band_hi (zero band around the diagonal)
+    ListSlot ls; real list_rc2;           // entry = acceptor index << 16 | donor index
 };
 template <class real> struct PapD {
+    static constexpr int res_slot = 2;    // acc/don records carry the residue index in .z
     int group, nacc, ndon, nres;
     const Int4* acc;                      // a1, a2, residue, -
     const Int4* don;                      // d1, d2, residue, -
@@ -76,6 +88,7 @@ template <class real> struct PapD {
     real eta2, r0, d_i4, cutoff2;
     real min_arg;                         // fp32 pre-screen: switches with argument below this are treated as 0
     int band_lo, band_hi;                 // gamma[q][p] == 0 whenever band_lo < q - p < band_hi
+    ListSlot ls; real list_rc2;           // entry = acceptor index << 16 | donor index
 };
 template <class real> struct HelicalD { int group, n; const HelicalItem<real>* items; real r_ON, r_OH, inv_sNO2, inv_sHO2; };
 // table2[b][i] = (t[b][i], t[b][i+1]) for i < ntab-1: the two interpolation nodes of a bin in one aligned load
@@ -97,5 +110,10 @@ template <class real> struct DevSys {
     MembD<real> memb[AWSEM_MAX_MEMB]; DhD<real> dh[AWSEM_MAX_DH];
     int max_contact_sites;                // LDS scratch sizing
     int any_zdep;
+    unsigned* lists;                      // [n_replicas][list_stride] pair-list entries
+    long long list_stride;
+    int n_lists;
+    real skin_half2;                      // (skin/2)^2: lists are rebuilt once an atom has moved further than skin/2
+    int* status;                          // device error word: bit 0 = a pair list overflowed
 };
 static_assert(sizeof(DevSys<double>) <= 4000, "DevSys must fit the 4 KB kernarg segment");

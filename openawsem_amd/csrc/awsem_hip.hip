@@ -81,6 +81,7 @@ struct EngineBase {
     virtual void forces(unsigned mask, int redistribute, double* f) = 0;
     virtual void step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) = 0;
     virtual void synchronize() = 0;
+    virtual int neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) = 0;
     double last_ms = 0.0;
 };
 
@@ -136,6 +137,7 @@ public:
         HIP_TRY(hipMemcpyAsync(e, dE_, sizeof(double) * nrep_ * AWSEM_NGROUPS, hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
         record_ms();
+        check_status();
     }
     void forces(unsigned mask, int redistribute, double* f) override {
         HIP_TRY(hipSetDevice(device_));
@@ -146,6 +148,7 @@ public:
         HIP_TRY(hipMemcpyAsync(f, dF_, sizeof(double) * 3 * natoms_ * nrep_, hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
         record_ms();
+        check_status();
     }
     void step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) override {
         HIP_TRY(hipSetDevice(device_));
@@ -160,8 +163,9 @@ public:
     void synchronize() override {
         HIP_TRY(hipSetDevice(device_));
         HIP_TRY(hipStreamSynchronize(stream_));
-        if (timing_pending_) record_ms();
+        if (timing_pending_) { record_ms(); check_status(); }
     }
+    int neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) override;
 
 private:
     template <class T> T* dalloc(size_t n) {
@@ -183,6 +187,14 @@ private:
     void upload_T(const double* T) {
         HIP_TRY(hipMemcpyAsync(dT_, T, sizeof(double) * nrep_, hipMemcpyHostToDevice, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));   // T is a caller-owned pageable buffer
+    }
+    void check_status() {
+        int st = 0;
+        HIP_TRY(hipMemcpy(&st, dstatus_, sizeof st, hipMemcpyDeviceToHost));
+        if (st) {
+            HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
+            throw std::string("pair list overflow on the device (internal error: list capacity below the candidate pair count)");
+        }
     }
     void record_ms() {
         float ms = 0;
@@ -218,6 +230,11 @@ private:
     DevSys<real> dsys_;
     real *pos_ = nullptr, *vel_ = nullptr;
     double *dT_ = nullptr, *dE_ = nullptr, *dF_ = nullptr;
+    const HostSystem* host_ = nullptr;   // owned by the handle, outlives the engine
+    int* dstatus_ = nullptr;
+    unsigned* dcounts_ = nullptr;
+    double skin_ = 0.15;
+    size_t lds_list_ = 0;
 };
 
 // Largest band of diagonals q - p around 0 on which the nres x nres table t[q][p] is identically zero:
@@ -237,6 +254,7 @@ static void zero_band(const std::vector<double>& t, int nres, int* lo, int* hi) 
 
 template <class real> void Engine<real>::finalize(const HostSystem& H) {
     HIP_TRY(hipSetDevice(device_));
+    host_ = &H;
     DevSys<real> S;
     memset(&S, 0, sizeof S);
     S.natoms = natoms_;
@@ -453,6 +471,62 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         if (D.size() > AWSEM_MAX_DH) throw std::string("too many dh terms: at most " + std::to_string(AWSEM_MAX_DH) + " per system");
         S.n_dh = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.dh[t] = D[t];
     }
+    // pair lists: one slot per pair term, capacity = number of candidate pairs (cannot overflow)
+    if (const char* env = getenv("AWSEM_SKIN")) {
+        double v = atof(env);
+        if (v >= 0.0 && v <= 1.0) skin_ = v;
+    }
+    {
+        if (natoms_ > 65535) throw std::string("the replica-resident path addresses atoms with 16 bits: at most 65535 atoms");
+        long long off = 0;
+        int id = 0;
+        auto slot = [&](long long cap) {
+            ListSlot ls{(int)off, (int)cap, id++};
+            off += (cap + 63) & ~63LL;   // 256-byte aligned starts
+            if (off > 0x7fffffffLL) throw std::string("pair lists of one replica exceed 2^31 entries");
+            return ls;
+        };
+        auto rc2 = [&](double cutoff) { double r = cutoff + skin_; return (real)(r * r); };
+        for (int t = 0; t < S.n_contact; t++) {
+            ContactD<real>& d = S.contact[t];
+            if (d.nsites > 1023) throw std::string("contact term: at most 1023 sites on the replica-resident path");
+            d.ls = slot((long long)d.nsites * (d.nsites - 1) / 2);
+            d.list_rc2 = rc2((H.contact[t].flags & AWSEM_CONTACT_NOCUTOFF) ? 1e15 : H.contact[t].p[AWSEM_CP_CUTOFF]);
+        }
+        for (int t = 0; t < S.n_excl; t++) {
+            ExclD<real>& d = S.excl[t];
+            long long cap = 0;
+            for (int c = 0; c < d.nclass; c++) { long long n = d.class_start[c + 1] - d.class_start[c]; cap += n * (n - 1) / 2; }
+            d.ls = slot(cap);
+            d.list_rc2 = rc2(H.excl[t].r0);
+        }
+        for (int t = 0; t < S.n_beta; t++) {
+            BetaD<real>& d = S.beta[t];
+            if (d.nacc > 65535 || d.ndon > 65535) throw std::string("hydrogen-bond term: at most 65535 acceptors / donors");
+            d.ls = slot((long long)d.nacc * d.ndon);
+            d.list_rc2 = rc2(std::sqrt((double)d.screen2));
+        }
+        for (int t = 0; t < S.n_pap; t++) {
+            PapD<real>& d = S.pap[t];
+            if (d.nacc > 65535 || d.ndon > 65535) throw std::string("hydrogen-bond term: at most 65535 acceptors / donors");
+            d.ls = slot((long long)d.nacc * d.ndon);
+            d.list_rc2 = rc2(H.pap[t].cutoff);
+        }
+        S.n_lists = id;
+        S.list_stride = off ? off : 64;
+        const double bytes = (double)S.list_stride * 4.0 * nrep_;
+        if (bytes > 64e9) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "pair lists need %.1f GB for %d replicas of this system; use fewer replicas per handle", bytes / 1e9, nrep_);
+            throw std::string(msg);
+        }
+        S.lists = dalloc<unsigned>((size_t)S.list_stride * nrep_);
+        S.skin_half2 = (real)(0.25 * skin_ * skin_ * 0.999);
+        dstatus_ = dalloc<int>(1);
+        HIP_TRY(hipMemset(dstatus_, 0, sizeof(int)));
+        S.status = dstatus_;
+        dcounts_ = dalloc<unsigned>((size_t)nrep_ * AWSEM_MAX_LISTS);
+    }
     dsys_ = S;
 
     // replica state and outputs
@@ -463,8 +537,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
     dT_ = dalloc<double>(nrep_); dE_ = dalloc<double>((size_t)nrep_ * AWSEM_NGROUPS); dF_ = dalloc<double>(nstate);
 
     // launch geometry: one workgroup per replica, LDS sized by the system
-    lds_eval_ = lds_bytes<real>(natoms_, S.max_contact_sites, false);
-    lds_step_ = lds_bytes<real>(natoms_, S.max_contact_sites, true);
+    lds_eval_ = lds_bytes<real>(natoms_, S.max_contact_sites, S.n_contact, false);
+    lds_step_ = lds_bytes<real>(natoms_, S.max_contact_sites, S.n_contact, true);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_));
     size_t lds_max = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
@@ -478,11 +552,55 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<true, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<false, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
+    HIP_TRY(hipFuncSetAttribute((const void*)awsem_list_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     block_ = natoms_ > 1024 ? 512 : 256;
     if (const char* env = getenv("AWSEM_BLOCK")) {
         int b = atoi(env);
         if (b >= 64 && b <= 1024 && b % 64 == 0) block_ = b;
     }
+}
+
+// Pair set of one pair term: rebuild that term's list with cutoff + skin and decode the entries.
+template <class real> int Engine<real>::neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) {
+    HIP_TRY(hipSetDevice(device_));
+    DevSys<real> S = dsys_;
+    ListSlot ls;
+    int group;
+    auto rc2 = [&](double cutoff) { double r = cutoff + skin; return (real)(r * r); };
+    const auto& Hs = *host_;
+    switch (kind) {
+    case AWSEM_LIST_EXCL:
+        if (index < 0 || index >= S.n_excl) throw std::string("neighbors: no such excl term");
+        S.excl[index].list_rc2 = rc2(Hs.excl[index].r0); ls = S.excl[index].ls; group = S.excl[index].group; break;
+    case AWSEM_LIST_CONTACT:
+        if (index < 0 || index >= S.n_contact) throw std::string("neighbors: no such contact term");
+        S.contact[index].list_rc2 = rc2((Hs.contact[index].flags & AWSEM_CONTACT_NOCUTOFF) ? 1e15 : Hs.contact[index].p[AWSEM_CP_CUTOFF]);
+        ls = S.contact[index].ls; group = S.contact[index].group; break;
+    case AWSEM_LIST_BETA:
+        if (index < 0 || index >= S.n_beta) throw std::string("neighbors: no such beta term");
+        S.beta[index].list_rc2 = rc2(std::sqrt((double)S.beta[index].screen2)); ls = S.beta[index].ls; group = S.beta[index].group; break;
+    case AWSEM_LIST_PAP:
+        if (index < 0 || index >= S.n_pap) throw std::string("neighbors: no such pap term");
+        S.pap[index].list_rc2 = rc2(Hs.pap[index].cutoff); ls = S.pap[index].ls; group = S.pap[index].group; break;
+    default: throw std::string("neighbors: kind must be AWSEM_LIST_EXCL, _CONTACT, _BETA or _PAP");
+    }
+    hipLaunchKernelGGL(awsem_list_kernel<real>, dim3(nrep_), dim3(block_), lds_eval_, stream_, S, pos_, 1u << group, dcounts_);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream_));
+    check_status();
+    unsigned n = 0;
+    HIP_TRY(hipMemcpy(&n, dcounts_ + (size_t)rep * AWSEM_MAX_LISTS + ls.list_id, sizeof n, hipMemcpyDeviceToHost));
+    std::vector<unsigned> e(n);
+    if (n) HIP_TRY(hipMemcpy(e.data(), S.lists + (size_t)rep * S.list_stride + ls.list_off, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost));
+    std::vector<std::pair<int, int>> out(n);
+    for (unsigned k = 0; k < n; k++) {
+        if (kind == AWSEM_LIST_CONTACT) out[k] = {(int)(e[k] & 0x3ff), (int)((e[k] >> 10) & 0x3ff)};
+        else out[k] = {(int)(e[k] >> 16), (int)(e[k] & 0xffff)};
+        if (kind == AWSEM_LIST_EXCL && out[k].first > out[k].second) std::swap(out[k].first, out[k].second);
+    }
+    std::sort(out.begin(), out.end());
+    for (unsigned k = 0; k < n && (int)k < capacity; k++) { pairs[2 * k] = out[k].first; pairs[2 * k + 1] = out[k].second; }
+    return (int)n;
 }
 
 }  // namespace
@@ -744,6 +862,12 @@ int awsem_set_step_count(awsem_handle h, int64_t s) {
     if (!h) return fail(AWSEM_EINVAL, "null handle");
     h->step = s;
     return AWSEM_OK;
+}
+int awsem_neighbors(awsem_handle h, int replica, int kind, int index, double skin, int32_t* pairs, int capacity, int* n_pairs) {
+    NEED_RUN(h);
+    if (replica < 0 || replica >= h->nrep || capacity < 0 || (capacity && !pairs) || !n_pairs || !(skin >= 0))
+        return fail(AWSEM_EINVAL, "neighbors: bad arguments");
+    GUARD_BEGIN *n_pairs = h->eng->neighbors(replica, kind, index, skin, pairs, capacity); return AWSEM_OK; GUARD_END
 }
 int awsem_last_kernel_ms(awsem_handle h, double* ms) {
     NEED_RUN(h);

@@ -51,10 +51,15 @@ template <class real> struct Lds {
     u64 *fx, *fy, *fz;       // fixed-point force accumulators
     real *vx, *vy, *vz;      // velocities (step kernel only)
     u64 *rho, *drho;         // contact density and dE/drho accumulators (fixed point)
-    real *rhov, *drhov;      // converted density / dE/drho
+    real *rhov;              // per-site water switch s_i = sig(-2 eta_s (rho_i - rho0))
     real *alpha, *dalpha;    // z-dependent membrane switch
     real *gamma;             // staged gamma tables of the current contact term (env-major)
     u64* eg;                 // per-group energies (fixed point)
+    real *rx, *ry, *rz;      // positions at the last pair-list build (step kernel only)
+    int* satom;              // contact site -> atom, [contact term][max_contact_sites]
+    unsigned* lcount;        // pair-list entry counts, one per list
+    unsigned* flag;          // [0] = largest squared displacement since the last list build (float bits)
+    unsigned* lists;         // GLOBAL: this replica's pair-list entries
 };
 
 template <class real> __device__ __forceinline__ void add_force(const Lds<real>& L, int a, real x, real y, real z) {
@@ -70,11 +75,18 @@ template <class real> __device__ __forceinline__ void pair_force(const Lds<real>
     atomicSub(&L.fx[j], X); atomicSub(&L.fy[j], Y); atomicSub(&L.fz[j], Z);
 }
 
-template <bool ENERGY, class real> __device__ __forceinline__ void flush_energy(const Lds<real>& L, int group, double& e) {
+// Energies are summed as 2^-32 fixed point from the first addition on (integer adds commute, so a sum does not
+// depend on the order in which a pair list happens to hold its entries): `Energy` is a per-lane accumulator.
+struct Energy {
+    u64 v = 0;
+    __device__ __forceinline__ void operator+=(double x) { v += (u64)__double2ll_rn(x * AWSEM_FIXED_SCALE); }   // round to nearest: no bias over 10^4 terms
+};
+template <bool ENERGY, class real> __device__ __forceinline__ void flush_energy(const Lds<real>& L, int group, Energy& e) {
     if (ENERGY) {
-        for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off);
-        if ((threadIdx.x & 63) == 0 && e != 0.0) atomicAdd(&L.eg[group], to_fixed(e));
-        e = 0.0;
+        u64 s = e.v;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(&L.eg[group], s);
+        e.v = 0;
     }
 }
 
@@ -84,7 +96,7 @@ template <class real> __device__ __forceinline__ real sigmoid(real x) { return M
 
 // ------------------------------------------------------------------ bonded terms
 template <bool ENERGY, class real> __device__ void term_harmonic(const HarmD<real>& d, const Lds<real>& L) {
-    double e = 0;
+    Energy e;
     for (int b = threadIdx.x; b < d.n; b += blockDim.x) {
         HarmItem<real> it = d.items[b];
         real dx = L.px[it.i] - L.px[it.j], dy = L.py[it.i] - L.py[it.j], dz = L.pz[it.i] - L.pz[it.j];
@@ -96,7 +108,7 @@ template <bool ENERGY, class real> __device__ void term_harmonic(const HarmD<rea
 }
 
 template <bool ENERGY, class real> __device__ void term_chi(const ChiD<real>& d, const Lds<real>& L) {
-    double e = 0;
+    Energy e;
     for (int b = threadIdx.x; b < d.n; b += blockDim.x) {
         Int4 a = d.atoms[b];   // CA, C, N, CB
         real ux = L.px[a.x] - L.px[a.y], uy = L.py[a.x] - L.py[a.y], uz = L.pz[a.x] - L.pz[a.y];
@@ -145,7 +157,7 @@ template <class real> __device__ __forceinline__ void dihedral(const Lds<real>& 
 }
 
 template <bool ENERGY, class real> __device__ void term_rama(const RamaD<real>& d, const Lds<real>& L) {
-    double e = 0;
+    Energy e;
     for (int b = threadIdx.x; b < d.n; b += blockDim.x) {
         Int5 a = d.atoms[b];
         Dihedral<real> P, S;
@@ -181,7 +193,7 @@ template <class real> __device__ __forceinline__ real hb_theta(real r1, real r2,
 }
 
 template <bool ENERGY, class real> __device__ void term_helical(const HelicalD<real>& d, const Lds<real>& L) {
-    double e = 0;
+    Energy e;
     for (int b = threadIdx.x; b < d.n; b += blockDim.x) {
         HelicalItem<real> it = d.items[b];
         real ax = L.px[it.o] - L.px[it.n], ay = L.py[it.o] - L.py[it.n], az = L.pz[it.o] - L.pz[it.n];
@@ -199,7 +211,7 @@ template <bool ENERGY, class real> __device__ void term_helical(const HelicalD<r
 // Fragment memory: per bond two neighbouring floats of an L2-resident table row.  Four bonds are kept in flight per
 // thread so that the dependent chain (pair indices -> LDS coordinates -> table gather) overlaps across bonds.
 template <bool ENERGY, class real> __device__ void term_fm(const FmD<real>& d, const Lds<real>& L) {
-    double e = 0;
+    Energy e;
     constexpr int U = 4;
     const int stride = blockDim.x;
     for (int b0 = threadIdx.x; b0 < d.n; b0 += U * stride) {
@@ -237,7 +249,7 @@ template <bool ENERGY, class real> __device__ void term_fm(const FmD<real>& d, c
 }
 
 template <bool ENERGY, class real> __device__ void term_memb(const MembD<real>& d, const Lds<real>& L) {
-    double e = 0;
+    Energy e;
     for (int b = threadIdx.x; b < d.n; b += blockDim.x) {
         MembItem<real> it = d.items[b];
         real z = L.pz[it.atom] - d.center;
@@ -251,7 +263,7 @@ template <bool ENERGY, class real> __device__ void term_memb(const MembD<real>& 
 }
 
 template <bool ENERGY, class real> __device__ void term_dh(const DhD<real>& d, const Lds<real>& L) {
-    double e = 0;
+    Energy e;
     for (int b = threadIdx.x; b < d.n; b += blockDim.x) {
         DhItem<real> it = d.items[b];
         real dx = L.px[it.i] - L.px[it.j], dy = L.py[it.i] - L.py[it.j], dz = L.pz[it.i] - L.pz[it.j];
@@ -263,120 +275,140 @@ template <bool ENERGY, class real> __device__ void term_dh(const DhD<real>& d, c
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-// ------------------------------------------------------------------ wave-level primitives for the pair scans
-// Pair scans keep the "column" entity (site j / donor) resident in the registers of lane j for a whole 64-wide
-// chunk and walk the "row" entities (site i / acceptor) with v_readlane broadcasts: no memory traffic and no
-// index loads in the inner loop.  Column-side sums stay in registers (fixed row order, so the result is
-// deterministic) and leave the wave as one conflict-free fixed-point atomic per column entity.
-__device__ __forceinline__ int bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ float bcast(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
-__device__ __forceinline__ double bcast(double v, int lane) {
-    long long b = __double_as_longlong(v);
-    int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+// ------------------------------------------------------------------ Verlet pair lists
+// Every pair term (excl, contact, beta, pap) is evaluated from a per-replica pair list instead of an all-pairs
+// scan.  BUILD (amortised: only when some atom has moved more than skin/2 since the last build) enumerates the
+// candidate pairs along *diagonals* -- in one wave iteration lane l tests pair (i0 + l, i0 + l + d) -- so that the
+// entries one iteration appends have pairwise distinct first and distinct second members; the wave compacts the
+// passing lanes (ballot + mbcnt) behind one LDS counter bump and stores them to the replica's global list with one
+// coalesced store.  EVALUATE reads the list 64 entries per wave iteration with every lane busy, and books both
+// sides of the pair with fixed-point LDS atomics (conflict-light thanks to the diagonal order).  The evaluators
+// re-apply the exact cutoff of the reference, so the result does not depend on when a list was built.
+template <class real> __device__ __forceinline__ real dist2(real dx, real dy, real dz) {
+    return __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));   // fixed evaluation order: the pair set is bit-exact
 }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// Rows are walked in groups of U per wave: the U distance screens (and, when any lane of any row passes, the U
-// branch-free bodies) are independent instruction chains that the scheduler interleaves, which is what hides the
-// readlane / transcendental / LDS latencies at the 4 waves per SIMD this kernel runs at.  Bodies are predicated
-// (select, not branch) so that a group stays one basic block; a group in which no lane passes is skipped.
-#define AWSEM_ROW_GROUPS(U, nrows, k0) for (int k0 = wave * (U); k0 < (nrows); k0 += nw * (U))
+__device__ __forceinline__ void list_append(unsigned* __restrict__ e, unsigned* cnt, int cap, int* status, bool pass, unsigned entry) {
+    const u64 m = __ballot(pass);
+    if (m == 0) return;   // wave-uniform
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(cnt, (unsigned)__popcll(m));
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+    const unsigned off = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (pass) {
+        if (base + off < (unsigned)cap) e[base + off] = entry;
+        else *status = 1;   // cannot happen while cap = number of candidate pairs; kept as a guard
+    }
+}
 
-template <bool ENERGY, class real> __device__ void term_excl(const ExclD<real>& d, const Lds<real>& L) {
-    double e = 0;
-    constexpr int U = 4;
-    const real r02 = d.r0 * d.r0;
-    const int nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#define AWSEM_WAVE_VARS const int nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63
+// list chunks of 64 entries are dealt to the waves round-robin, starting at a different wave for every list so
+// that short lists do not all land on wave 0
+#define AWSEM_LIST_CHUNKS(c0, count, rot) for (int c0 = ((wave + nw - ((rot) % nw)) % nw) * 64; c0 < (count); c0 += nw * 64)
+
+template <class real> struct ListView { const unsigned* e; int count; };
+template <class real> __device__ __forceinline__ ListView<real> list_view(const Lds<real>& L, const ListSlot& ls) {
+    const int n = (int)L.lcount[ls.list_id];
+    return ListView<real>{L.lists + ls.list_off, n < ls.list_cap ? n : ls.list_cap};
+}
+
+// ---- excluded volume: same-class site pairs that are not bonded partners
+template <class real> __device__ void build_excl(const ExclD<real>& d, const Lds<real>& L, int* status) {
+    AWSEM_WAVE_VARS;
+    unsigned* e = L.lists + d.ls.list_off;
+    unsigned* cnt = &L.lcount[d.ls.list_id];
     for (int c = 0; c < d.nclass; c++) {
         const int base = d.class_start[c], n = d.class_start[c + 1] - base;
-        for (int cj = 0; cj < n; cj += 64) {
-            const int j = cj + lane;
-            const bool vj = j < n;
-            const int b = d.atom[base + (vj ? j : n - 1)];
-            const Int4 pj = d.partners[base + (vj ? j : n - 1)];   // atoms excluded from interacting with b
-            const real xj = L.px[b], yj = L.py[b], zj = L.pz[b];
-            real fjx = 0, fjy = 0, fjz = 0;
-            for (int ci = 0; ci < n; ci += 64) {   // full square: lane j collects the force on its own site only
-                const int il = ci + lane;
-                const int a_l = d.atom[base + (il < n ? il : n - 1)];
-                const real xi_l = L.px[a_l], yi_l = L.py[a_l], zi_l = L.pz[a_l];
-                const int nrows = min(64, n - ci);
-                AWSEM_ROW_GROUPS(U, nrows, k0) {
-                    real dx[U], dy[U], dz[U], r2[U];
-                    bool pass[U], any = false;
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const int k = min(k0 + u, nrows - 1), a = bcast(a_l, k);
-                        dx[u] = bcast(xi_l, k) - xj; dy[u] = bcast(yi_l, k) - yj; dz[u] = bcast(zi_l, k) - zj;
-                        r2[u] = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
-                        pass[u] = (k0 + u < nrows) && vj && a != b && r2[u] < r02 && pj.x != a && pj.y != a && pj.z != a && pj.w != a;
-                        any |= pass[u];
-                    }
-                    if (__ballot(any) == 0) continue;   // clashes only
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        real ir = M<real>::rsqrt(pass[u] ? r2[u] : (real)1), dr = r2[u] * ir - d.r0;
-                        if (ENERGY) e += pass[u] ? 0.5 * (double)(d.k * dr * dr) : 0.0;
-                        real fs = pass[u] ? (real)2 * d.k * dr * ir : (real)0;   // force on j = +dE/dr (x_i - x_j)/r
-                        fjx += fs * dx[u]; fjy += fs * dy[u]; fjz += fs * dz[u];
-                    }
+        for (int dd = 1 + wave; dd < n; dd += nw) {
+            for (int i0 = 0; i0 + dd < n; i0 += 64) {
+                const int i = i0 + lane, j = i + dd;
+                const bool v = j < n;
+                const int si = base + (v ? i : 0), sj = base + (v ? j : 0);
+                const int a = d.atom[si], b = d.atom[sj];
+                const real r2 = dist2(L.px[a] - L.px[b], L.py[a] - L.py[b], L.pz[a] - L.pz[b]);
+                bool pass = v && r2 < d.list_rc2;
+                if (pass) {
+                    const Int4 p = d.partners[si];
+                    pass = p.x != b && p.y != b && p.z != b && p.w != b;
                 }
+                list_append(e, cnt, d.ls.list_cap, status, pass, ((unsigned)a << 16) | (unsigned)b);
             }
-            if (vj && (fjx != (real)0 || fjy != (real)0 || fjz != (real)0)) add_force(L, b, fjx, fjy, fjz);
+        }
+    }
+}
+template <bool ENERGY, class real> __device__ void eval_excl(const ExclD<real>& d, const Lds<real>& L) {
+    AWSEM_WAVE_VARS;
+    Energy e;
+    const ListView<real> lv = list_view(L, d.ls);
+    const real r02 = d.r0 * d.r0;
+    AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id) {
+        const int idx = c0 + lane;
+        const bool v = idx < lv.count;
+        const unsigned ent = v ? lv.e[idx] : 0u;
+        const int a = ent >> 16, b = ent & 0xffff;
+        const real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
+        const real r2 = dist2(dx, dy, dz);
+        if (v && r2 < r02) {   // clashes are rare: divergent body
+            const real ir = M<real>::rsqrt(r2), dr = r2 * ir - d.r0;
+            if (ENERGY) e += (double)(d.k * dr * dr);
+            pair_force(L, a, b, dx, dy, dz, (real)-2 * d.k * dr * ir);
         }
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-// The three contact passes walk the FULL n x n pair square: lane j owns site j and accumulates everything that
-// belongs to j (density, dE/drho_j, force on j) in registers over all rows i != j; the mirrored contribution to i
-// is produced when the roles are swapped.  Every pair is therefore evaluated twice, but no lane is idle (a
-// triangular walk masks half of them), there is no cross-lane reduction, and the only atomics are one
-// conflict-free fixed-point add per site and wave at the end of a pass.  The pair energy is symmetric bit for bit
-// (all operands commute), so each evaluation books half of it.
-//
-// Contact pass 1: density rho_j = sum_i theta_I(r_ij) over |resid_i - resid_j| >= 2 inside the cutoff.
-template <class real> __device__ void contact_density(const ContactD<real>& d, const Lds<real>& L) {
-    constexpr int U = 4;
-    const int n = d.nsites, nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    for (int cj = 0; cj < n; cj += 64) {
-        const int j = cj + lane;
-        const bool vj = j < n;
-        const int jj = vj ? j : n - 1, b = d.atom[jj], rj = d.info[jj] & 0xffff;
-        const real xj = L.px[b], yj = L.py[b], zj = L.pz[b];
-        real rho_j = 0;
-        for (int ci = 0; ci < n; ci += 64) {
-            const int il = ci + lane, ii = il < n ? il : n - 1, a_l = d.atom[ii], ri_l = d.info[ii] & 0xffff;
-            const real xi_l = L.px[a_l], yi_l = L.py[a_l], zi_l = L.pz[a_l];
-            const int nrows = min(64, n - ci);
-            AWSEM_ROW_GROUPS(U, nrows, k0) {
-                real r2[U];
-                bool pass[U], any = false;
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int k = min(k0 + u, nrows - 1), dres = bcast(ri_l, k) - rj;
-                    real dx = bcast(xi_l, k) - xj, dy = bcast(yi_l, k) - yj, dz = bcast(zi_l, k) - zj;
-                    r2[u] = dx * dx + dy * dy + dz * dz;
-                    pass[u] = (k0 + u < nrows) && vj && (dres >= 2 || dres <= -2) && r2[u] < d.cutoff2;
-                    any |= pass[u];
-                }
-                if (__ballot(any) == 0) continue;
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    real r = M<real>::sqrt(r2[u]);
-                    real th = sigmoid(d.eta2 * (r - d.rmin)) * sigmoid(d.eta2 * (d.rmax - r));
-                    rho_j += pass[u] ? th : (real)0;
-                }
-            }
+// ---- contact: site pairs with |resid_i - resid_j| >= 2 (the density's own exclusion; the pair energy needs more)
+template <class real> __device__ void build_contact(const ContactD<real>& d, const Lds<real>& L, const int* satom, int* status) {
+    AWSEM_WAVE_VARS;
+    unsigned* e = L.lists + d.ls.list_off;
+    unsigned* cnt = &L.lcount[d.ls.list_id];
+    const int n = d.nsites;
+    for (int dd = 1 + wave; dd < n; dd += nw) {
+        for (int i0 = 0; i0 + dd < n; i0 += 64) {
+            const int i = i0 + lane, j = i + dd;
+            const bool v = j < n;
+            const int si = v ? i : 0, sj = v ? j : 0;
+            const int info_i = d.info[si], info_j = d.info[sj], a = satom[si], b = satom[sj];
+            const int dres = (info_j & 0xffff) - (info_i & 0xffff);
+            const real r2 = dist2(L.px[a] - L.px[b], L.py[a] - L.py[b], L.pz[a] - L.pz[b]);
+            // the density counts |resid_i - resid_j| >= 2 whatever the chains (contactTerms.py:255); the pair energy
+            // counts different chains or |resid_i - resid_j| >= min_seq_sep (res_table, contactTerms.py:200-210)
+            const bool in_rho = dres >= 2 || dres <= -2;
+            const bool pair_e = !(d.flags & 2) && ((((info_i ^ info_j) >> 16) & 0x7ff) != 0 || dres >= d.min_seq_sep || -dres >= d.min_seq_sep);
+            const bool pass = v && (in_rho || pair_e) && r2 < d.list_rc2;
+            const unsigned ty = (unsigned)(((info_i >> 27) & 31) * 20 + ((info_j >> 27) & 31));
+            list_append(e, cnt, d.ls.list_cap, status, pass,
+                        (unsigned)si | ((unsigned)sj << 10) | (ty << 20) | (in_rho ? 0x40000000u : 0u) | (pair_e ? 0x80000000u : 0u));
         }
-        if (vj) atomicAdd(&L.rho[j], to_fixed(rho_j));
+    }
+}
+// pass 1: density rho_i = sum_j theta_I(r_ij) inside the cutoff
+template <class real> __device__ void contact_density(const ContactD<real>& d, const Lds<real>& L, const int* satom) {
+    AWSEM_WAVE_VARS;
+    const ListView<real> lv = list_view(L, d.ls);
+    AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id) {
+        const int idx = c0 + lane;
+        const bool v = idx < lv.count;
+        const unsigned ent = v ? lv.e[idx] : 0u;
+        const int i = ent & 0x3ff, j = (ent >> 10) & 0x3ff, a = satom[i], b = satom[j];
+        const real r2 = dist2(L.px[a] - L.px[b], L.py[a] - L.py[b], L.pz[a] - L.pz[b]);
+        const bool pass = v && (ent & 0x40000000u) && r2 < d.cutoff2;
+        if (__ballot(pass) == 0) continue;
+        const real r = M<real>::sqrt(r2);
+        const real th = sigmoid(d.eta2 * (r - d.rmin)) * sigmoid(d.eta2 * (d.rmax - r));
+        if (pass) {
+            const u64 t = to_fixed(th);
+            atomicAdd(&L.rho[i], t);
+            atomicAdd(&L.rho[j], t);
+        }
     }
 }
 // Between pass 1 and 2: evaluate the burial wells (single-particle energy), seed dE/drho, and precompute the
 // per-site water switch s_i = sig(-2 eta_s (rho_i - rho0)) (sigma_water_ij = s_i s_j) into L.rhov.
-template <bool ENERGY, class real> __device__ void contact_single(const ContactD<real>& d, const Lds<real>& L) {
-    double e = 0;
+template <bool ENERGY, class real> __device__ void contact_single(const ContactD<real>& d, const Lds<real>& L, const int* satom) {
+    Energy e;
     for (int i = threadIdx.x; i < d.nsites; i += blockDim.x) {
         real rho = (real)fixed_to_double(L.rho[i]);
         L.rhov[i] = sigmoid(-d.eta_s2 * (rho - d.rho0));
@@ -394,7 +426,7 @@ template <bool ENERGY, class real> __device__ void contact_single(const ContactD
         }
         L.drho[i] = to_fixed(dE);
         if (d.flags & 1) {
-            real z = L.pz[d.atom[i]] - d.zc;
+            real z = L.pz[satom[i]] - d.zc;
             real su = sigmoid(d.eta_sw2 * (z + d.z_m)), sv = sigmoid(d.eta_sw2 * (d.z_m - z));
             L.alpha[i] = su + sv - (real)1;
             L.dalpha[i] = d.eta_sw2 * (su * ((real)1 - su) - sv * ((real)1 - sv));
@@ -402,231 +434,183 @@ template <bool ENERGY, class real> __device__ void contact_single(const ContactD
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
-// Contact pass 2: pair energy (direct + mediated), its explicit radial force, and dE/drho through sigma_water.
-template <bool ENERGY, class real> __device__ void contact_pairs(const ContactD<real>& d, const Lds<real>& L) {
-    double e = 0;
-    constexpr int U = 2;
+// pass 2: pair energy (direct + mediated), its explicit radial force, and dE/drho through sigma_water
+template <bool ENERGY, class real> __device__ void contact_pairs(const ContactD<real>& d, const Lds<real>& L, const int* satom) {
+    AWSEM_WAVE_VARS;
+    Energy e;
     const bool zdep = d.flags & 1;
     const real* g0 = L.gamma;
     const real* g1 = L.gamma + 1200;
-    const int n = d.nsites, nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const real one = (real)1, zero = (real)0;
-    for (int cj = 0; cj < n; cj += 64) {
-        const int j = cj + lane;
-        const bool vj = j < n;
-        const int jj = vj ? j : n - 1, b = d.atom[jj], info_j = d.info[jj];
-        const int rj = info_j & 0xffff, chj = (info_j >> 16) & 0x7ff, tj = (info_j >> 27) & 31;
-        const real xj = L.px[b], yj = L.py[b], zj = L.pz[b], sj = L.rhov[jj];
-        const real dsj = -d.eta_s2 * sj * (one - sj);
-        const real alj = zdep ? L.alpha[jj] : zero, dalj = zdep ? L.dalpha[jj] : zero;
-        real fjx = 0, fjy = 0, fjz = 0, drho_j = 0;
-        for (int ci = 0; ci < n; ci += 64) {
-            const int il = ci + lane, ii = il < n ? il : n - 1, a_l = d.atom[ii], info_l = d.info[ii];
-            const real xi_l = L.px[a_l], yi_l = L.py[a_l], zi_l = L.pz[a_l], si_l = L.rhov[ii];
-            const real ali_l = zdep ? L.alpha[ii] : zero;
-            const int nrows = min(64, n - ci);
-            AWSEM_ROW_GROUPS(U, nrows, k0) {
-                real dx[U], dy[U], dz[U], r2[U];
-                int info_i[U], kk[U];
-                bool pass[U], any = false;
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int k = min(k0 + u, nrows - 1);
-                    kk[u] = k;
-                    info_i[u] = bcast(info_l, k);
-                    const int dres = (info_i[u] & 0xffff) - rj;
-                    dx[u] = bcast(xi_l, k) - xj; dy[u] = bcast(yi_l, k) - yj; dz[u] = bcast(zi_l, k) - zj;
-                    r2[u] = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
-                    pass[u] = (k0 + u < nrows) && vj && (ci + k != j) && r2[u] < d.cutoff2 &&
-                              (((info_i[u] >> 16) & 0x7ff) != chj || dres >= d.min_seq_sep || -dres >= d.min_seq_sep);
-                    any |= pass[u];
-                }
-                if (__ballot(any) == 0) continue;
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    real ir = M<real>::rsqrt(pass[u] ? r2[u] : one), r = r2[u] * ir;
-                    real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
-                    real s3 = sigmoid(d.eta2 * (r - d.rminII)), s4 = sigmoid(d.eta2 * (d.rmaxII - r));
-                    real th1 = s1 * s2, dth1 = d.eta2 * th1 * (s2 - s1);
-                    real th2 = s3 * s4, dth2 = d.eta2 * th2 * (s4 - s3);
-                    real si = bcast(si_l, kk[u]), sw = si * sj;
-                    int ty = ((info_i[u] >> 27) & 31) * 20 + tj;
-                    real E, dEdr, dEdsw, fzx = zero;
-                    if (!zdep) {
-                        real gd = g0[ty], gp = g0[400 + ty], gw = g0[800 + ty];
-                        real med = sw * gw + (one - sw) * gp;
-                        E = -d.k * (gd * th1 + th2 * med);
-                        dEdr = -d.k * (gd * dth1 + dth2 * med);
-                        dEdsw = -d.k * th2 * (gw - gp);
-                    } else {
-                        real med0 = sw * g0[800 + ty] + (one - sw) * g0[400 + ty];
-                        real med1 = sw * g1[800 + ty] + (one - sw) * g1[400 + ty];
-                        real W = -d.k * (g0[ty] * th1 + th2 * med0), Mm = -d.k * (g1[ty] * th1 + th2 * med1);
-                        real dW = -d.k * (g0[ty] * dth1 + dth2 * med0), dM = -d.k * (g1[ty] * dth1 + dth2 * med1);
-                        real ai = bcast(ali_l, kk[u]), aa = ai * alj;
-                        E = (one - aa) * W + aa * Mm;
-                        dEdr = (one - aa) * dW + aa * dM;
-                        dEdsw = -d.k * th2 * ((one - aa) * (g0[800 + ty] - g0[400 + ty]) + aa * (g1[800 + ty] - g1[400 + ty]));
-                        fzx = -(Mm - W) * ai * dalj;
-                    }
-                    if (ENERGY) e += pass[u] ? 0.5 * (double)E : 0.0;
-                    drho_j += pass[u] ? dEdsw * si * dsj : zero;
-                    real fs = pass[u] ? dEdr * ir : zero;   // force on j = +dE/dr * (x_i - x_j)/r
-                    fjx += fs * dx[u]; fjy += fs * dy[u]; fjz += fs * dz[u] + (pass[u] ? fzx : zero);
-                }
-            }
-        }
-        if (vj) {
-            add_force(L, b, fjx, fjy, fjz);
-            atomicAdd(&L.drho[j], to_fixed(drho_j));
-        }
-    }
-    flush_energy<ENERGY>(L, d.group, e);
-}
-// Contact pass 3: chain rule through the densities: F_j += (dE/drho_i + dE/drho_j) theta_I'(r) (x_i - x_j)/r
-template <class real> __device__ void contact_chain_rule(const ContactD<real>& d, const Lds<real>& L) {
-    constexpr int U = 4;
-    const int n = d.nsites, nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    for (int cj = 0; cj < n; cj += 64) {
-        const int j = cj + lane;
-        const bool vj = j < n;
-        const int jj = vj ? j : n - 1, b = d.atom[jj], rj = d.info[jj] & 0xffff;
-        const real xj = L.px[b], yj = L.py[b], zj = L.pz[b], gj = (real)fixed_to_double(L.drho[jj]);
-        real fjx = 0, fjy = 0, fjz = 0;
-        for (int ci = 0; ci < n; ci += 64) {
-            const int il = ci + lane, ii = il < n ? il : n - 1, a_l = d.atom[ii], ri_l = d.info[ii] & 0xffff;
-            const real xi_l = L.px[a_l], yi_l = L.py[a_l], zi_l = L.pz[a_l], gi_l = (real)fixed_to_double(L.drho[ii]);
-            const int nrows = min(64, n - ci);
-            AWSEM_ROW_GROUPS(U, nrows, k0) {
-                real dx[U], dy[U], dz[U], r2[U], gi[U];
-                bool pass[U], any = false;
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int k = min(k0 + u, nrows - 1), dres = bcast(ri_l, k) - rj;
-                    gi[u] = bcast(gi_l, k);
-                    dx[u] = bcast(xi_l, k) - xj; dy[u] = bcast(yi_l, k) - yj; dz[u] = bcast(zi_l, k) - zj;
-                    r2[u] = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
-                    pass[u] = (k0 + u < nrows) && vj && (dres >= 2 || dres <= -2) && r2[u] < d.cutoff2;
-                    any |= pass[u];
-                }
-                if (__ballot(any) == 0) continue;
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    real ir = M<real>::rsqrt(pass[u] ? r2[u] : (real)1), r = r2[u] * ir;
-                    real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
-                    real fs = pass[u] ? (gi[u] + gj) * d.eta2 * s1 * s2 * (s2 - s1) * ir : (real)0;
-                    fjx += fs * dx[u]; fjy += fs * dy[u]; fjz += fs * dz[u];
-                }
-            }
-        }
-        if (vj) add_force(L, b, fjx, fjy, fjz);
-    }
-}
-
-// ------------------------------------------------------------------ acceptor x donor scans (CustomHbondForce shape)
-// Donors are lane-resident per 64-chunk (atoms and coordinates in registers), acceptors are broadcast row by row;
-// waves split the acceptor rows.  In fp32 the scan uses a conservative pre-screen (terms below e^-30 of their
-// maximum are skipped, far under fp32 resolution); the fp64 check mode applies only the reference's cutoff.
-template <bool ENERGY, class real> __device__ void term_beta(const BetaD<real>& d, const Lds<real>& L) {
-    double e = 0;
-    const int nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    for (int cd = 0; cd < d.ndon; cd += 64) {
-        const int id = cd + lane;
-        const bool vd = id < d.ndon;
-        const Int4 D = d.don[vd ? id : d.ndon - 1];
-        const real nx = L.px[D.x], ny = L.py[D.x], nz = L.pz[D.x];
-        const real hx = L.px[D.y], hy = L.py[D.y], hz = L.pz[D.y];
-        const real* lam_row = d.lambda + (size_t)D.w * d.nres;
-        for (int ca = 0; ca < d.nacc; ca += 64) {
-            const int ial = ca + lane;
-            const Int4 A = d.acc[ial < d.nacc ? ial : d.nacc - 1];
-            const real ox_l = L.px[A.x], oy_l = L.py[A.x], oz_l = L.pz[A.x];
-            const int nrows = min(64, d.nacc - ca);
-            for (int k = wave; k < nrows; k += nw) {
-                const real ox = bcast(ox_l, k), oy = bcast(oy_l, k), oz = bcast(oz_l, k);
-                real ax = ox - nx, ay = oy - ny, az = oz - nz;
-                real r1s = ax * ax + ay * ay + az * az;
-                const int ares = bcast(A.w, k), dq = D.w - ares;
-                if (!(vd && r1s < d.screen2 && (dq <= d.band_lo || dq >= d.band_hi))) continue;
-                real c = lam_row[ares];   // -k * lambda[don_res][acc_res]
-                if (c == (real)0) continue;
-                real bx = ox - hx, by = oy - hy, bz = oz - hz;
-                real r2s = bx * bx + by * by + bz * bz;
-                real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
-                real da = r1s * i1 - d.r_ON, db = r2s * i2 - d.r_OH;
-                real ex1 = (real)0.5 * (da * da * d.inv_sNO2 + db * db * d.inv_sHO2);
-                if (ex1 > d.max_expo) continue;
-                real th1 = M<real>::exp(-ex1), g1 = -th1 * da * d.inv_sNO2, g2 = -th1 * db * d.inv_sHO2;
-                const int a1 = bcast(A.x, k);
-                if (!d.two_theta) {
-                    if (ENERGY) e += (double)(c * th1);
-                    pair_force(L, a1, D.x, ax, ay, az, -c * g1 * i1);
-                    pair_force(L, a1, D.y, bx, by, bz, -c * g2 * i2);
-                } else {
-                    const int a2 = bcast(A.y, k), a3 = bcast(A.z, k);
-                    real px = L.px[D.z], py = L.py[D.z], pz = L.pz[D.z];
-                    real cx = px - L.px[a2], cy = py - L.py[a2], cz = pz - L.pz[a2];
-                    real ex = px - L.px[a3], ey = py - L.py[a3], ez = pz - L.pz[a3];
-                    real r3s = cx * cx + cy * cy + cz * cz, r4s = ex * ex + ey * ey + ez * ez;
-                    real i3 = M<real>::rsqrt(r3s), i4 = M<real>::rsqrt(r4s), h1, h2;
-                    real th2 = hb_theta(r3s * i3, r4s * i4, d.r_ON, d.r_OH, d.inv_sNO2, d.inv_sHO2, h1, h2);
-                    if (ENERGY) e += (double)(c * th1 * th2);
-                    pair_force(L, a1, D.x, ax, ay, az, -c * g1 * th2 * i1);
-                    pair_force(L, a1, D.y, bx, by, bz, -c * g2 * th2 * i2);
-                    pair_force(L, D.z, a2, cx, cy, cz, -c * th1 * h1 * i3);
-                    pair_force(L, D.z, a3, ex, ey, ez, -c * th1 * h2 * i4);
-                }
-            }
-        }
-    }
-    flush_energy<ENERGY>(L, d.group, e);
-}
-
-template <bool ENERGY, class real> __device__ void term_pap(const PapD<real>& d, const Lds<real>& L) {
-    double e = 0;
-    const int nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const real one = (real)1;
-    for (int cd = 0; cd < d.ndon; cd += 64) {
-        const int id = cd + lane;
-        const bool vd = id < d.ndon;
-        const Int4 D = d.don[vd ? id : d.ndon - 1];
-        const real n1x = L.px[D.x], n1y = L.py[D.x], n1z = L.pz[D.x];
-        const real n2x = L.px[D.y], n2y = L.py[D.y], n2z = L.pz[D.y];
-        const real* gam_row = d.gamma + (size_t)D.z * d.nres;
-        for (int ca = 0; ca < d.nacc; ca += 64) {
-            const int ial = ca + lane;
-            const Int4 A = d.acc[ial < d.nacc ? ial : d.nacc - 1];
-            const real a1x_l = L.px[A.x], a1y_l = L.py[A.x], a1z_l = L.pz[A.x];
-            const real a2x_l = L.px[A.y], a2y_l = L.py[A.y], a2z_l = L.pz[A.y];
-            // row-only factor 1/2 (1 + tanh(eta (|a1-a2| - d_i4))), computed once per acceptor by its lane
-            const real ex_l = a1x_l - a2x_l, ey_l = a1y_l - a2y_l, ez_l = a1z_l - a2z_l;
-            const real r3s_l = ex_l * ex_l + ey_l * ey_l + ez_l * ez_l, i3_l = M<real>::rsqrt(r3s_l);
-            const real arg3_l = d.eta2 * (r3s_l * i3_l - d.d_i4);
-            const real s3_l = sigmoid(arg3_l);
-            const int nrows = min(64, d.nacc - ca);
-            for (int k = wave; k < nrows; k += nw) {
-                if (bcast(arg3_l, k) < d.min_arg) continue;   // whole acceptor switched off (uniform branch)
-                const real a1x = bcast(a1x_l, k), a1y = bcast(a1y_l, k), a1z = bcast(a1z_l, k);
-                real ax = a1x - n1x, ay = a1y - n1y, az = a1z - n1z;
-                real r1s = ax * ax + ay * ay + az * az;
-                const int ares = bcast(A.z, k), dq = D.z - ares;
-                if (!(vd && r1s < d.cutoff2 && (dq <= d.band_lo || dq >= d.band_hi))) continue;
-                real c = gam_row[ares];   // -k * gamma[don_res][acc_res]
-                if (c == (real)0) continue;
-                real bx = bcast(a2x_l, k) - n2x, by = bcast(a2y_l, k) - n2y, bz = bcast(a2z_l, k) - n2z;
-                real r2s = bx * bx + by * by + bz * bz;
-                real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
-                real arg2 = d.eta2 * (d.r0 - r2s * i2);
-                if (arg2 < d.min_arg) continue;
-                real s1 = sigmoid(d.eta2 * (d.r0 - r1s * i1)), s2 = sigmoid(arg2), s3 = bcast(s3_l, k);
-                if (ENERGY) e += (double)(c * s1 * s2 * s3);
-                const int a1 = bcast(A.x, k), a2 = bcast(A.y, k);
-                pair_force(L, a1, D.x, ax, ay, az, c * d.eta2 * s1 * (one - s1) * s2 * s3 * i1);
-                pair_force(L, a2, D.y, bx, by, bz, c * s1 * d.eta2 * s2 * (one - s2) * s3 * i2);
-                pair_force(L, a1, a2, bcast(ex_l, k), bcast(ey_l, k), bcast(ez_l, k),
-                           -c * s1 * s2 * d.eta2 * s3 * (one - s3) * bcast(i3_l, k));
+    const ListView<real> lv = list_view(L, d.ls);
+    AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id + 1) {
+        const int idx = c0 + lane;
+        const bool v = idx < lv.count;
+        const unsigned ent = v ? lv.e[idx] : 0u;
+        const int i = ent & 0x3ff, j = (ent >> 10) & 0x3ff, ty = (ent >> 20) & 0x1ff, a = satom[i], b = satom[j];
+        const real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
+        const real r2 = dist2(dx, dy, dz);
+        const bool pass = v && (ent >> 31) && r2 < d.cutoff2;
+        if (__ballot(pass) == 0) continue;
+        const real ir = M<real>::rsqrt(pass ? r2 : one), r = r2 * ir;
+        const real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
+        const real s3 = sigmoid(d.eta2 * (r - d.rminII)), s4 = sigmoid(d.eta2 * (d.rmaxII - r));
+        const real th1 = s1 * s2, dth1 = d.eta2 * th1 * (s2 - s1);
+        const real th2 = s3 * s4, dth2 = d.eta2 * th2 * (s4 - s3);
+        const real si = L.rhov[i], sj = L.rhov[j], sw = si * sj;
+        real E, dEdr, dEdsw, fzi = 0, fzj = 0;
+        if (!zdep) {
+            const real gd = g0[ty], gp = g0[400 + ty], gw = g0[800 + ty];
+            const real med = sw * gw + (one - sw) * gp;
+            E = -d.k * (gd * th1 + th2 * med);
+            dEdr = -d.k * (gd * dth1 + dth2 * med);
+            dEdsw = -d.k * th2 * (gw - gp);
+        } else {
+            const real med0 = sw * g0[800 + ty] + (one - sw) * g0[400 + ty];
+            const real med1 = sw * g1[800 + ty] + (one - sw) * g1[400 + ty];
+            const real W = -d.k * (g0[ty] * th1 + th2 * med0), Mm = -d.k * (g1[ty] * th1 + th2 * med1);
+            const real dW = -d.k * (g0[ty] * dth1 + dth2 * med0), dM = -d.k * (g1[ty] * dth1 + dth2 * med1);
+            const real ai = L.alpha[i], aj = L.alpha[j], aa = ai * aj;
+            E = (one - aa) * W + aa * Mm;
+            dEdr = (one - aa) * dW + aa * dM;
+            dEdsw = -d.k * th2 * ((one - aa) * (g0[800 + ty] - g0[400 + ty]) + aa * (g1[800 + ty] - g1[400 + ty]));
+            fzi = -(Mm - W) * aj * L.dalpha[i];
+            fzj = -(Mm - W) * ai * L.dalpha[j];
+        }
+        if (pass) {
+            if (ENERGY) e += (double)E;
+            pair_force(L, a, b, dx, dy, dz, -dEdr * ir);
+            atomicAdd(&L.drho[i], to_fixed(dEdsw * sj * (-d.eta_s2 * si * (one - si))));
+            atomicAdd(&L.drho[j], to_fixed(dEdsw * si * (-d.eta_s2 * sj * (one - sj))));
+            if (zdep) {
+                atomicAdd(&L.fz[a], to_fixed(fzi));
+                atomicAdd(&L.fz[b], to_fixed(fzj));
             }
         }
+    }
+    flush_energy<ENERGY>(L, d.group, e);
+}
+// pass 3: chain rule through the densities: F_j += (dE/drho_i + dE/drho_j) theta_I'(r) (x_i - x_j)/r
+template <class real> __device__ void contact_chain_rule(const ContactD<real>& d, const Lds<real>& L, const int* satom) {
+    AWSEM_WAVE_VARS;
+    const ListView<real> lv = list_view(L, d.ls);
+    AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id + 2) {
+        const int idx = c0 + lane;
+        const bool v = idx < lv.count;
+        const unsigned ent = v ? lv.e[idx] : 0u;
+        const int i = ent & 0x3ff, j = (ent >> 10) & 0x3ff, a = satom[i], b = satom[j];
+        const real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
+        const real r2 = dist2(dx, dy, dz);
+        const bool pass = v && (ent & 0x40000000u) && r2 < d.cutoff2;
+        if (__ballot(pass) == 0) continue;
+        const real ir = M<real>::rsqrt(pass ? r2 : (real)1), r = r2 * ir;
+        const real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
+        const real g = (real)(fixed_to_double(L.drho[i]) + fixed_to_double(L.drho[j]));
+        if (pass) pair_force(L, a, b, dx, dy, dz, -g * d.eta2 * s1 * s2 * (s2 - s1) * ir);
+    }
+}
+
+// ---- acceptor x donor terms (CustomHbondForce shape)
+// In fp32 the lists use a conservative pre-screen (Gaussian factors below e^-30 of their maximum are skipped, far
+// under fp32 resolution); the fp64 check mode applies only the reference's cutoff.
+template <class real, class Desc> __device__ void build_hbond(const Desc& d, const real* __restrict__ table, const Lds<real>& L, int* status) {
+    AWSEM_WAVE_VARS;
+    unsigned* e = L.lists + d.ls.list_off;
+    unsigned* cnt = &L.lcount[d.ls.list_id];
+    const int resw = Desc::res_slot;   // which Int4 component carries the residue index
+    for (int a0 = 0; a0 < d.nacc; a0 += 64) {
+        const int ia = a0 + lane;
+        const bool va = ia < d.nacc;
+        const Int4 A = d.acc[va ? ia : 0];
+        const real ax = L.px[A.x], ay = L.py[A.x], az = L.pz[A.x];
+        const int ares = resw == 3 ? A.w : A.z;
+        const int q0 = (va ? ia : 0) % d.ndon;
+        for (int dd = wave; dd < d.ndon; dd += nw) {
+            int q = q0 + dd;
+            q = q >= d.ndon ? q - d.ndon : q;
+            const Int4 D = d.don[q];
+            const int dres = resw == 3 ? D.w : D.z, dq = dres - ares;
+            const real r2 = dist2(ax - L.px[D.x], ay - L.py[D.x], az - L.pz[D.x]);
+            bool pass = va && r2 < d.list_rc2 && (dq <= d.band_lo || dq >= d.band_hi);
+            if (pass) pass = table[(size_t)dres * d.nres + ares] != (real)0;
+            list_append(e, cnt, d.ls.list_cap, status, pass, ((unsigned)ia << 16) | (unsigned)q);
+        }
+    }
+}
+
+template <bool ENERGY, class real> __device__ void eval_beta(const BetaD<real>& d, const Lds<real>& L) {
+    AWSEM_WAVE_VARS;
+    Energy e;
+    const ListView<real> lv = list_view(L, d.ls);
+    AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id) {
+        const int idx = c0 + lane;
+        if (idx >= lv.count) continue;
+        const unsigned ent = lv.e[idx];
+        const Int4 A = d.acc[ent >> 16], D = d.don[ent & 0xffff];
+        const real ox = L.px[A.x], oy = L.py[A.x], oz = L.pz[A.x];
+        const real ax = ox - L.px[D.x], ay = oy - L.py[D.x], az = oz - L.pz[D.x];
+        const real r1s = dist2(ax, ay, az);
+        if (!(r1s < d.screen2)) continue;
+        const real bx = ox - L.px[D.y], by = oy - L.py[D.y], bz = oz - L.pz[D.y];
+        const real r2s = dist2(bx, by, bz);
+        const real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
+        const real da = r1s * i1 - d.r_ON, db = r2s * i2 - d.r_OH;
+        const real ex1 = (real)0.5 * (da * da * d.inv_sNO2 + db * db * d.inv_sHO2);
+        if (ex1 > d.max_expo) continue;
+        const real c = d.lambda[(size_t)D.w * d.nres + A.w];   // -k * lambda[don_res][acc_res]
+        const real th1 = M<real>::exp(-ex1), g1 = -th1 * da * d.inv_sNO2, g2 = -th1 * db * d.inv_sHO2;
+        if (!d.two_theta) {
+            if (ENERGY) e += (double)(c * th1);
+            pair_force(L, A.x, D.x, ax, ay, az, -c * g1 * i1);
+            pair_force(L, A.x, D.y, bx, by, bz, -c * g2 * i2);
+        } else {
+            const real px = L.px[D.z], py = L.py[D.z], pz = L.pz[D.z];
+            const real cx = px - L.px[A.y], cy = py - L.py[A.y], cz = pz - L.pz[A.y];
+            const real ex = px - L.px[A.z], ey = py - L.py[A.z], ez = pz - L.pz[A.z];
+            const real r3s = dist2(cx, cy, cz), r4s = dist2(ex, ey, ez);
+            const real i3 = M<real>::rsqrt(r3s), i4 = M<real>::rsqrt(r4s);
+            real h1, h2;
+            const real th2 = hb_theta(r3s * i3, r4s * i4, d.r_ON, d.r_OH, d.inv_sNO2, d.inv_sHO2, h1, h2);
+            if (ENERGY) e += (double)(c * th1 * th2);
+            pair_force(L, A.x, D.x, ax, ay, az, -c * g1 * th2 * i1);
+            pair_force(L, A.x, D.y, bx, by, bz, -c * g2 * th2 * i2);
+            pair_force(L, D.z, A.y, cx, cy, cz, -c * th1 * h1 * i3);
+            pair_force(L, D.z, A.z, ex, ey, ez, -c * th1 * h2 * i4);
+        }
+    }
+    flush_energy<ENERGY>(L, d.group, e);
+}
+
+template <bool ENERGY, class real> __device__ void eval_pap(const PapD<real>& d, const Lds<real>& L) {
+    AWSEM_WAVE_VARS;
+    Energy e;
+    const real one = (real)1;
+    const ListView<real> lv = list_view(L, d.ls);
+    AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id) {
+        const int idx = c0 + lane;
+        if (idx >= lv.count) continue;
+        const unsigned ent = lv.e[idx];
+        const Int4 A = d.acc[ent >> 16], D = d.don[ent & 0xffff];
+        const real a1x = L.px[A.x], a1y = L.py[A.x], a1z = L.pz[A.x];
+        const real ax = a1x - L.px[D.x], ay = a1y - L.py[D.x], az = a1z - L.pz[D.x];
+        const real r1s = dist2(ax, ay, az);
+        if (!(r1s < d.cutoff2)) continue;
+        const real a2x = L.px[A.y], a2y = L.py[A.y], a2z = L.pz[A.y];
+        const real ex = a1x - a2x, ey = a1y - a2y, ez = a1z - a2z;
+        const real r3s = dist2(ex, ey, ez), i3 = M<real>::rsqrt(r3s);
+        const real arg3 = d.eta2 * (r3s * i3 - d.d_i4);
+        if (arg3 < d.min_arg) continue;
+        const real bx = a2x - L.px[D.y], by = a2y - L.py[D.y], bz = a2z - L.pz[D.y];
+        const real r2s = dist2(bx, by, bz);
+        const real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
+        const real arg2 = d.eta2 * (d.r0 - r2s * i2);
+        if (arg2 < d.min_arg) continue;
+        const real c = d.gamma[(size_t)D.z * d.nres + A.z];   // -k * gamma[don_res][acc_res]
+        const real s1 = sigmoid(d.eta2 * (d.r0 - r1s * i1)), s2 = sigmoid(arg2), s3 = sigmoid(arg3);
+        if (ENERGY) e += (double)(c * s1 * s2 * s3);
+        pair_force(L, A.x, D.x, ax, ay, az, c * d.eta2 * s1 * (one - s1) * s2 * s3 * i1);
+        pair_force(L, A.y, D.y, bx, by, bz, c * s1 * d.eta2 * s2 * (one - s2) * s3 * i2);
+        pair_force(L, A.x, A.y, ex, ey, ez, -c * s1 * s2 * d.eta2 * s3 * (one - s3) * i3);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
@@ -654,63 +638,94 @@ template <class real> __device__ void redistribute_forces(const DevSys<real>& S,
     }
 }
 
-// Evaluate every term whose group is in `mask`.  Forces accumulate into L.f* (must be zeroed by the caller and
-// be visible: call after a __syncthreads()); ends with all contributions visible to the whole workgroup.
+// Once per launch: contact site -> atom tables and (when the system has a single contact term) its gamma tables.
 template <class real> __device__ void stage_contact_gamma(const ContactD<real>& d, const Lds<real>& L) {
     if (d.flags & 2) return;
     const int ng = (d.flags & 1) ? 2400 : 1200;
     const real* src = d.gamma + ((d.flags & 1) ? 0 : d.env * 1200);
     for (int i = threadIdx.x; i < ng; i += blockDim.x) L.gamma[i] = src[i];
 }
-// `stage_gamma`: copy the contact gamma tables to LDS before use; a caller that evaluates a system with a single
-// contact term many times (the step kernel) stages them once itself and passes false.
-template <bool ENERGY, class real> __device__ void evaluate_terms(const DevSys<real>& S, const Lds<real>& L, unsigned mask, bool stage_gamma = true) {
-#define ON(d) ((mask >> (d).group) & 1u)
-    for (int t = 0; t < S.n_harm; t++) if (ON(S.harm[t])) term_harmonic<ENERGY>(S.harm[t], L);
-    for (int t = 0; t < S.n_fm; t++) if (ON(S.fm[t])) term_fm<ENERGY>(S.fm[t], L);
-    for (int t = 0; t < S.n_chi; t++) if (ON(S.chi[t])) term_chi<ENERGY>(S.chi[t], L);
-    for (int t = 0; t < S.n_rama; t++) if (ON(S.rama[t])) term_rama<ENERGY>(S.rama[t], L);
-    for (int t = 0; t < S.n_helical; t++) if (ON(S.helical[t])) term_helical<ENERGY>(S.helical[t], L);
-    for (int t = 0; t < S.n_memb; t++) if (ON(S.memb[t])) term_memb<ENERGY>(S.memb[t], L);
-    for (int t = 0; t < S.n_dh; t++) if (ON(S.dh[t])) term_dh<ENERGY>(S.dh[t], L);
-    for (int t = 0; t < S.n_excl; t++) if (ON(S.excl[t])) term_excl<ENERGY>(S.excl[t], L);
-    for (int t = 0; t < S.n_beta; t++) if (ON(S.beta[t])) term_beta<ENERGY>(S.beta[t], L);
-    for (int t = 0; t < S.n_pap; t++) if (ON(S.pap[t])) term_pap<ENERGY>(S.pap[t], L);
-    // contact terms: three passes separated by workgroup barriers (uniform control flow: S and mask are uniform)
+template <class real> __device__ void stage_tables(const DevSys<real>& S, const Lds<real>& L) {
+    for (int t = 0; t < S.n_contact; t++)
+        for (int i = threadIdx.x; i < S.contact[t].nsites; i += blockDim.x) L.satom[t * S.max_contact_sites + i] = S.contact[t].atom[i];
+    if (S.n_contact == 1) stage_contact_gamma(S.contact[0], L);
+}
+
+#define AWSEM_ON(d) ((mask >> (d).group) & 1u)
+// (Re)build the pair list of every pair term in `mask` from the current LDS positions.  The caller zeroes
+// L.lcount before (and synchronises), and synchronises after.
+template <class real> __device__ void build_lists(const DevSys<real>& S, const Lds<real>& L, unsigned mask) {
+    for (int t = 0; t < S.n_contact; t++) if (AWSEM_ON(S.contact[t])) build_contact(S.contact[t], L, L.satom + t * S.max_contact_sites, S.status);
+    for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) build_excl(S.excl[t], L, S.status);
+    for (int t = 0; t < S.n_beta; t++) if (AWSEM_ON(S.beta[t])) build_hbond(S.beta[t], S.beta[t].lambda, L, S.status);
+    for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) build_hbond(S.pap[t], S.pap[t].gamma, L, S.status);
+}
+
+// Evaluate every term whose group is in `mask` from the current pair lists.  Forces accumulate into L.f* (zeroed by
+// the caller and visible: call after a __syncthreads()); ends with all contributions visible to the workgroup.
+template <bool ENERGY, class real> __device__ void evaluate_terms(const DevSys<real>& S, const Lds<real>& L, unsigned mask) {
+    // the contact passes are separated by workgroup barriers; the other terms are issued in between so that waves
+    // which reach a barrier late have less to wait for
+    const bool multi = S.n_contact > 1;
     for (int t = 0; t < S.n_contact; t++) {
         const ContactD<real>& d = S.contact[t];
-        if (!ON(d)) continue;
-        __syncthreads();   // previous user of the contact scratch (or previous contact term) is done
-        for (int i = threadIdx.x; i < d.nsites; i += blockDim.x) L.rho[i] = 0;
-        if (stage_gamma) stage_contact_gamma(d, L);
-        __syncthreads();
-        contact_density(d, L);
-        __syncthreads();
-        contact_single<ENERGY>(d, L);
-        __syncthreads();
-        if (!(d.flags & 2)) {
-            contact_pairs<ENERGY>(d, L);
+        if (!AWSEM_ON(d)) continue;   // uniform: S and mask are
+        const int* satom = L.satom + t * S.max_contact_sites;
+        if (multi) {   // the density scratch and the gamma staging area are shared between contact terms
             __syncthreads();
+            stage_contact_gamma(d, L);
         }
-        contact_chain_rule(d, L);
+        for (int i = threadIdx.x; i < d.nsites; i += blockDim.x) L.rho[i] = 0;
+        __syncthreads();
+        contact_density(d, L, satom);
+        if (t == 0) {
+            for (int u = 0; u < S.n_fm; u++) if (AWSEM_ON(S.fm[u])) term_fm<ENERGY>(S.fm[u], L);
+        }
+        __syncthreads();
+        contact_single<ENERGY>(d, L, satom);
+        if (t == 0) {
+            for (int u = 0; u < S.n_harm; u++) if (AWSEM_ON(S.harm[u])) term_harmonic<ENERGY>(S.harm[u], L);
+            for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L);
+        }
+        __syncthreads();
+        if (!(d.flags & 2)) contact_pairs<ENERGY>(d, L, satom);
+        if (t == 0) {
+            for (int u = 0; u < S.n_beta; u++) if (AWSEM_ON(S.beta[u])) eval_beta<ENERGY>(S.beta[u], L);
+        }
+        __syncthreads();
+        contact_chain_rule(d, L, satom);
     }
-#undef ON
+    const bool first_contact_on = S.n_contact > 0 && AWSEM_ON(S.contact[0]);
+    if (!first_contact_on) {
+        for (int u = 0; u < S.n_fm; u++) if (AWSEM_ON(S.fm[u])) term_fm<ENERGY>(S.fm[u], L);
+        for (int u = 0; u < S.n_harm; u++) if (AWSEM_ON(S.harm[u])) term_harmonic<ENERGY>(S.harm[u], L);
+        for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L);
+        for (int u = 0; u < S.n_beta; u++) if (AWSEM_ON(S.beta[u])) eval_beta<ENERGY>(S.beta[u], L);
+    }
+    for (int t = 0; t < S.n_chi; t++) if (AWSEM_ON(S.chi[t])) term_chi<ENERGY>(S.chi[t], L);
+    for (int t = 0; t < S.n_helical; t++) if (AWSEM_ON(S.helical[t])) term_helical<ENERGY>(S.helical[t], L);
+    for (int t = 0; t < S.n_memb; t++) if (AWSEM_ON(S.memb[t])) term_memb<ENERGY>(S.memb[t], L);
+    for (int t = 0; t < S.n_dh; t++) if (AWSEM_ON(S.dh[t])) term_dh<ENERGY>(S.dh[t], L);
+    for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) eval_excl<ENERGY>(S.excl[t], L);
+    for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) eval_pap<ENERGY>(S.pap[t], L);
     __syncthreads();
 }
 
 // ------------------------------------------------------------------ LDS carve-up
-template <class real> __host__ __device__ inline size_t lds_bytes(int natoms, int nsites, bool with_vel) {
+template <class real> __host__ __device__ inline size_t lds_bytes(int natoms, int nsites, int ncontact, bool with_vel) {
     size_t b = 0;
     b += (size_t)3 * natoms * sizeof(u64);            // forces
     b += (size_t)2 * nsites * sizeof(u64);            // rho, drho
     b += AWSEM_NGROUPS * sizeof(u64);                 // group energies
     b += (size_t)3 * natoms * sizeof(real);           // positions
-    if (with_vel) b += (size_t)3 * natoms * sizeof(real);
-    b += (size_t)4 * nsites * sizeof(real);           // rhov, drhov, alpha, dalpha
+    if (with_vel) b += (size_t)6 * natoms * sizeof(real);   // velocities, pair-list reference positions
+    b += (size_t)3 * nsites * sizeof(real);           // rhov, alpha, dalpha
     b += (size_t)2400 * sizeof(real);                 // gamma staging
+    b += (size_t)(ncontact > 0 ? ncontact : 1) * nsites * sizeof(int);   // contact site -> atom
+    b += (AWSEM_MAX_LISTS + 4) * sizeof(unsigned);    // list counters, flags
     return (b + 15) & ~(size_t)15;
 }
-template <class real> __device__ inline Lds<real> carve_lds(unsigned char* base, int natoms, int nsites, bool with_vel) {
+template <class real> __device__ inline Lds<real> carve_lds(unsigned char* base, int natoms, int nsites, int ncontact, bool with_vel) {
     Lds<real> L;
     u64* q = (u64*)base;
     L.fx = q; q += natoms; L.fy = q; q += natoms; L.fz = q; q += natoms;
@@ -718,10 +733,18 @@ template <class real> __device__ inline Lds<real> carve_lds(unsigned char* base,
     L.eg = q; q += AWSEM_NGROUPS;
     real* r = (real*)q;
     L.px = r; r += natoms; L.py = r; r += natoms; L.pz = r; r += natoms;
-    if (with_vel) { L.vx = r; r += natoms; L.vy = r; r += natoms; L.vz = r; r += natoms; }
-    else { L.vx = L.vy = L.vz = nullptr; }
-    L.rhov = r; r += nsites; L.drhov = r; r += nsites; L.alpha = r; r += nsites; L.dalpha = r; r += nsites;
-    L.gamma = r;
+    if (with_vel) {
+        L.vx = r; r += natoms; L.vy = r; r += natoms; L.vz = r; r += natoms;
+        L.rx = r; r += natoms; L.ry = r; r += natoms; L.rz = r; r += natoms;
+    } else {
+        L.vx = L.vy = L.vz = L.rx = L.ry = L.rz = nullptr;
+    }
+    L.rhov = r; r += nsites; L.alpha = r; r += nsites; L.dalpha = r; r += nsites;
+    L.gamma = r; r += 2400;
+    L.satom = (int*)r;
+    L.lcount = (unsigned*)(L.satom + (ncontact > 0 ? ncontact : 1) * nsites);
+    L.flag = L.lcount + AWSEM_MAX_LISTS;
+    L.lists = nullptr;
     return L;
 }
 
@@ -736,10 +759,15 @@ __global__ void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__
                                   double* __restrict__ e_out /* [R][32] or null */, double* __restrict__ f_out /* [R][natoms][3] or null */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = blockIdx.x;
-    Lds<real> L = carve_lds<real>(smem, natoms, S.max_contact_sites, false);
+    Lds<real> L = carve_lds<real>(smem, natoms, S.max_contact_sites, S.n_contact, false);
+    L.lists = S.lists + (size_t)rep * S.list_stride;
     load_positions(pos + (size_t)rep * 3 * natoms, L, natoms);
     for (int i = threadIdx.x; i < natoms; i += blockDim.x) { L.fx[i] = 0; L.fy[i] = 0; L.fz[i] = 0; }
     if (threadIdx.x < AWSEM_NGROUPS) L.eg[threadIdx.x] = 0;
+    if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
+    stage_tables(S, L);
+    __syncthreads();
+    build_lists(S, L, mask);
     __syncthreads();
     evaluate_terms<ENERGY>(S, L, mask);
     if (f_out) {
@@ -750,6 +778,22 @@ __global__ void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__
         }
     }
     if (ENERGY && e_out && threadIdx.x < AWSEM_NGROUPS) e_out[(size_t)rep * AWSEM_NGROUPS + threadIdx.x] = fixed_to_double(L.eg[threadIdx.x]);
+}
+
+// Pair-list dump for awsem_neighbors: builds the lists of the terms in `mask` and writes the per-list counts.
+template <class real>
+__global__ void awsem_list_kernel(const DevSys<real> S, const real* __restrict__ pos, unsigned mask, unsigned* __restrict__ counts /* [R][AWSEM_MAX_LISTS] */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int natoms = S.natoms, rep = blockIdx.x;
+    Lds<real> L = carve_lds<real>(smem, natoms, S.max_contact_sites, S.n_contact, false);
+    L.lists = S.lists + (size_t)rep * S.list_stride;
+    load_positions(pos + (size_t)rep * 3 * natoms, L, natoms);
+    if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
+    stage_tables(S, L);
+    __syncthreads();
+    build_lists(S, L, mask);
+    __syncthreads();
+    if (threadIdx.x < AWSEM_MAX_LISTS) counts[(size_t)rep * AWSEM_MAX_LISTS + threadIdx.x] = L.lcount[threadIdx.x];
 }
 
 // ------------------------------------------------------------------ Philox4x32-10 Gaussian stream (shared with the oracle)
@@ -816,14 +860,16 @@ __global__ void awsem_vsite_kernel(const DevSys<real> S, real* __restrict__ pos)
 
 // ------------------------------------------------------------------ fused multi-step Langevin kernel
 // OpenMM LangevinIntegrator update (see oracle/awsem_oracle.c: awsem_oracle_step) with the state LDS-resident:
-// per step: virtual sites -> forces (all groups) -> virtual-site force redistribution -> v, x update.
+// per step: virtual sites -> [pair lists, if an atom moved more than skin/2] -> forces (all groups) -> virtual-site
+// force redistribution -> v, x update.
 template <class real>
 __global__ void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, real* __restrict__ vel,
                                   const double* __restrict__ T, int nsteps, double dt, double friction, unsigned long long seed,
                                   long long step0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = blockIdx.x;
-    Lds<real> L = carve_lds<real>(smem, natoms, S.max_contact_sites, true);
+    Lds<real> L = carve_lds<real>(smem, natoms, S.max_contact_sites, S.n_contact, true);
+    L.lists = S.lists + (size_t)rep * S.list_stride;
     real* gp = pos + (size_t)rep * 3 * natoms;
     real* gv = vel + (size_t)rep * 3 * natoms;
     load_positions(gp, L, natoms);
@@ -831,15 +877,34 @@ __global__ void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, 
     const double a_d = ::exp(-friction * dt);
     const real a = (real)a_d, fs = (real)(friction == 0.0 ? dt : (1.0 - a_d) / friction);
     const real ns = (real)::sqrt(AWSEM_KB * T[rep] * (1.0 - a_d * a_d)), dtr = (real)dt;
-    const bool stage_each_step = S.n_contact != 1;
-    if (!stage_each_step) stage_contact_gamma(S.contact[0], L);
+    stage_tables(S, L);
+    if (threadIdx.x == 0) L.flag[0] = 0;
     __syncthreads();
     for (int s = 0; s < nsteps; s++) {
         compute_virtual_sites(S, L);
-        for (int i = threadIdx.x; i < natoms; i += blockDim.x) { L.fx[i] = 0; L.fy[i] = 0; L.fz[i] = 0; }
         __syncthreads();
-        evaluate_terms<false>(S, L, 0xffffffffu, stage_each_step);
+        {   // zero the accumulators; how far has any atom (virtual sites included) moved since the lists were built?
+            real m = 0;
+            for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
+                L.fx[i] = 0; L.fy[i] = 0; L.fz[i] = 0;
+                if (s > 0) m = fmax(m, dist2(L.px[i] - L.rx[i], L.py[i] - L.ry[i], L.pz[i] - L.rz[i]));
+            }
+            if (s > 0) {
+                for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off));
+                if ((threadIdx.x & 63) == 0) atomicMax(&L.flag[0], __float_as_uint((float)m));   // non-negative floats order like their bits
+            }
+        }
+        __syncthreads();
+        if (s == 0 || __uint_as_float(L.flag[0]) > (float)S.skin_half2) {   // uniform across the workgroup
+            if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
+            for (int i = threadIdx.x; i < natoms; i += blockDim.x) { L.rx[i] = L.px[i]; L.ry[i] = L.py[i]; L.rz[i] = L.pz[i]; }
+            __syncthreads();
+            build_lists(S, L, 0xffffffffu);
+            __syncthreads();
+        }
+        evaluate_terms<false>(S, L, 0xffffffffu);
         redistribute_forces(S, L);
+        if (threadIdx.x == 0) L.flag[0] = 0;   // every thread has read it; the next atomicMax comes after two more barriers
         __syncthreads();
         for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
             real im = S.inv_mass[i];

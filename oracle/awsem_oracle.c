@@ -65,6 +65,7 @@ typedef struct awsem_oracle_ctx {
     double* vel;
     int64_t step;
     int nthreads;
+    int precision;   /* 0 = fp32, 1 = fp64: only awsem_oracle_neighbors looks at it (distance screen in that precision) */
 } ctx_t;
 
 static __thread char g_err[512];
@@ -95,7 +96,7 @@ static int add_term(ctx_t* c, int kind, void* p) {
     if ((group) < 0 || (group) >= NGROUPS) return fail(-1, "force group out of range 0..31");
 
 int awsem_oracle_create(int natoms, int nrep, int device, int precision, ctx_t** out) {
-    (void)device; (void)precision;
+    (void)device;
     if (natoms <= 0 || nrep <= 0 || !out) return fail(-1, "awsem_create: natoms and n_replicas must be positive");
     ctx_t* c = calloc(1, sizeof(ctx_t));
     c->natoms = natoms; c->nrep = nrep;
@@ -104,6 +105,7 @@ int awsem_oracle_create(int natoms, int nrep, int device, int precision, ctx_t**
     c->pos = calloc((size_t)nrep * natoms * 3, sizeof(double));
     c->vel = calloc((size_t)nrep * natoms * 3, sizeof(double));
     c->nthreads = 1;
+    c->precision = precision;
     *out = c;
     return 0;
 }
@@ -755,5 +757,72 @@ int awsem_oracle_step(ctx_t* c, int nsteps, const double* T, double dt, double f
 }
 int64_t awsem_oracle_step_count(ctx_t* c) { return c ? c->step : -1; }
 int awsem_oracle_set_step_count(ctx_t* c, int64_t s) { if (!c) return fail(-1, "null handle"); c->step = s; return 0; }
+
+/* ------------------------------------------------------------------ brute-force pair sets (include/awsem_hip.h: awsem_neighbors)
+ * O(N^2) scan with the distance screen evaluated exactly as the engine's list builder does it: coordinates rounded
+ * to the handle's precision, r^2 = fma(dz,dz,fma(dy,dy,dx*dx)), compared with (real)((cutoff+skin)^2). */
+static int below(const ctx_t* c, const double* x, int a, int b, double rc) {
+    if (c->precision == 0) {
+        float dx = (float)x[3 * a] - (float)x[3 * b], dy = (float)x[3 * a + 1] - (float)x[3 * b + 1], dz = (float)x[3 * a + 2] - (float)x[3 * b + 2];
+        return fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < (float)(rc * rc);
+    }
+    double dx = x[3 * a] - x[3 * b], dy = x[3 * a + 1] - x[3 * b + 1], dz = x[3 * a + 2] - x[3 * b + 2];
+    return fma(dz, dz, fma(dy, dy, dx * dx)) < rc * rc;
+}
+static int cmp_pair(const void* a, const void* b) {
+    const int *p = a, *q = b;
+    return p[0] != q[0] ? (p[0] < q[0] ? -1 : 1) : (p[1] < q[1] ? -1 : (p[1] > q[1]));
+}
+int awsem_oracle_neighbors(ctx_t* c, int rep, int kind, int index, double skin, int* pairs, int capacity, int* n_pairs) {
+    CHECK_RUN(c);
+    if (rep < 0 || rep >= c->nrep || capacity < 0 || (capacity && !pairs) || !n_pairs || !(skin >= 0)) return fail(-1, "neighbors: bad arguments");
+    static const int want[4] = {T_EXCL, T_CONTACT, T_BETA, T_PAP};
+    if (kind < 0 || kind > 3) return fail(-1, "neighbors: bad kind");
+    void* term = NULL;
+    for (int t = 0, k = 0; t < c->nterms; t++) if (c->terms[t].kind == want[kind]) { if (k++ == index) { term = c->terms[t].p; break; } }
+    if (!term) return fail(-1, "neighbors: no such term");
+    const double* x = c->pos + (size_t)rep * c->natoms * 3;
+    int n = 0, cap = 1024;
+    int* out = malloc(sizeof(int) * 2 * cap);
+#define PUSH(p, q) do { if (n == cap) { cap *= 2; out = realloc(out, sizeof(int) * 2 * cap); } out[2 * n] = (p); out[2 * n + 1] = (q); n++; } while (0)
+    if (kind == 0) {
+        const excl_t* t = term;
+        for (int i = 0; i < t->nsites; i++) for (int j = i + 1; j < t->nsites; j++) {
+            if (t->cls[i] != t->cls[j]) continue;
+            int a = t->atom[i], b = t->atom[j], ex = 0;
+            if (a == b || !below(c, x, a, b, t->r0 + skin)) continue;
+            for (int q = 0; q < t->nexcl && !ex; q++) ex = (t->excl[2 * q] == a && t->excl[2 * q + 1] == b) || (t->excl[2 * q] == b && t->excl[2 * q + 1] == a);
+            if (!ex) PUSH(a < b ? a : b, a < b ? b : a);
+        }
+    } else if (kind == 1) {
+        const contact_t* t = term;
+        const double cutoff = (t->flags & 4) ? 1e15 : t->p[8];
+        for (int i = 0; i < t->nsites; i++) for (int j = i + 1; j < t->nsites; j++)
+        {
+            int dres = abs(t->resid[i] - t->resid[j]);
+            int pair_e = !(t->flags & 2) && (t->chain[i] != t->chain[j] || dres >= t->min_seq_sep);
+            if ((dres >= 2 || pair_e) && below(c, x, t->atom[i], t->atom[j], cutoff + skin)) PUSH(i, j);
+        }
+    } else if (kind == 2) {
+        const beta_t* t = term;
+        double base = t->cutoff;
+        if (c->precision == 0) {
+            double rs = t->r_ON + sqrt(60.0) * t->s_NO, s2 = t->cutoff * t->cutoff < rs * rs ? t->cutoff * t->cutoff : rs * rs;
+            base = sqrt((double)(float)s2);
+        } else base = sqrt(t->cutoff * t->cutoff);
+        for (int a = 0; a < t->nacc; a++) for (int q = 0; q < t->ndon; q++)
+            if (t->lambda[(size_t)t->don_res[q] * t->nres + t->acc_res[a]] != 0.0 && below(c, x, t->acc_atoms[3 * a], t->don_atoms[3 * q], base + skin)) PUSH(a, q);
+    } else {
+        const pap_t* t = term;
+        for (int a = 0; a < t->nacc; a++) for (int q = 0; q < t->ndon; q++)
+            if (t->gamma[(size_t)t->don_res[q] * t->nres + t->acc_res[a]] != 0.0 && below(c, x, t->acc_atoms[2 * a], t->don_atoms[2 * q], t->cutoff + skin)) PUSH(a, q);
+    }
+#undef PUSH
+    qsort(out, n, 2 * sizeof(int), cmp_pair);
+    for (int k = 0; k < n && k < capacity; k++) { pairs[2 * k] = out[2 * k]; pairs[2 * k + 1] = out[2 * k + 1]; }
+    free(out);
+    *n_pairs = n;
+    return 0;
+}
 int awsem_oracle_last_kernel_ms(ctx_t* c, double* ms) { (void)c; if (ms) *ms = 0; return 0; }
 int awsem_oracle_synchronize(ctx_t* c) { (void)c; return 0; }

@@ -162,3 +162,49 @@ def test_bad_arguments_are_rejected_with_messages():
     ctx.finalize()
     with pytest.raises(_capi.AwsemError, match="already finalized"):
         ctx.add_harmonic_bonds(20, [(0, 1)], [0.1], [1.0])
+
+
+@pytest.mark.parametrize("precision", [FP32, FP64])
+@pytest.mark.parametrize("protein", ["1brs", "2lyz"])
+def test_pair_lists_equal_brute_force_bit_exactly(protein, precision):
+    """The engine's list builder (diagonal enumeration + wave compaction) against the oracle's O(N^2) scan with the
+    distance screen evaluated in the same precision and operation order: identical sorted pair sets, with and
+    without a skin.  The reference keeps OpenMM's neighbour lists private, so there is no fixture: parity unpinned."""
+    oa, traj, _ = golden_system(protein)
+    gpu = _gpu(oa, 2, precision)
+    cpu = _capi.Context(awsem_oracle.load(), oa.natoms, 2, precision=precision)
+    oa.system.upload(cpu)
+    for ctx in (gpu, cpu):
+        ctx.set_positions(traj[0], replica=0)
+        ctx.set_positions(traj[7], replica=1)
+    n_terms = {_capi.LIST_EXCL: 1, _capi.LIST_CONTACT: 1, _capi.LIST_BETA: 3, _capi.LIST_PAP: 2}
+    total = 0
+    for kind, count in n_terms.items():
+        for index in range(count):
+            for replica in (0, 1):
+                for skin in (0.0, 0.15):
+                    a = gpu.neighbors(kind, index, replica, skin)
+                    b = cpu.neighbors(kind, index, replica, skin)
+                    assert a.shape == b.shape and np.array_equal(a, b), f"kind {kind} term {index} replica {replica} skin {skin}"
+                    total += len(a)
+    assert total > 1000
+
+
+def test_trajectory_does_not_depend_on_list_skin(monkeypatch):
+    """The evaluators re-apply the exact cutoffs and all sums are fixed point, so a trajectory must be bit-identical
+    whatever the Verlet skin (= whenever the lists happen to be rebuilt): 0.02 nm rebuilds almost every step."""
+    oa, traj, _ = golden_system("1ubq")
+    out = []
+    for skin in ("0.02", "0.15", "0.4"):
+        monkeypatch.setenv("AWSEM_SKIN", skin)
+        gpu = _gpu(oa, 3, FP32)
+        gpu.set_positions(traj[3], replica=-1)
+        T = np.array([300.0, 600.0, 800.0])
+        gpu.set_velocities_to_temperature(T, 5)
+        for chunk in (120, 80):
+            gpu.step(chunk, T, 0.002, 1.0, 77)
+        out.append(np.stack([gpu.get_positions(r) for r in range(3)]))
+        gpu.close()
+    assert np.isfinite(out[0]).all()
+    assert np.abs(out[0][2] - traj[3]).max() > 0.05          # the chain really moved further than the small skins
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
