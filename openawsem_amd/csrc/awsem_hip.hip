@@ -237,6 +237,43 @@ private:
     size_t lds_list_ = 0;
 };
 
+// Order static items (bonds, dihedrals, virtual sites ...) so that the 64 items one wave handles in one
+// instruction touch pairwise different atoms wherever the topology allows it: the fixed-point force accumulation is
+// an LDS atomic, and lanes of one atomic instruction that hit the same address serialise (measured ~4 clk per extra
+// lane; a factory's natural order -- all bonds of atom i next to each other -- gives 10-fold conflicts).
+// Returns a permutation: position k of the new order holds item perm[k].  Aligned groups of 64 are filled greedily;
+// a group that cannot be filled with multiplicity m is topped up with multiplicity m+1.
+static std::vector<int> spread_order(int n, int width, const int* atoms, int natoms) {
+    std::vector<int> perm;
+    perm.reserve(n);
+    std::vector<int> remaining(n), next;
+    for (int i = 0; i < n; i++) remaining[i] = i;
+    std::vector<int> used(natoms, 0);
+    while (!remaining.empty()) {
+        int in_group = 0;
+        std::vector<int> touched;
+        for (int m = 1; in_group < 64 && !remaining.empty(); m++) {
+            next.clear();
+            for (int it : remaining) {
+                bool ok = in_group < 64;
+                for (int k = 0; ok && k < width; k++) { int a = atoms[(size_t)it * width + k]; ok = a < 0 || used[a] < m; }
+                if (ok) {
+                    perm.push_back(it); in_group++;
+                    for (int k = 0; k < width; k++) { int a = atoms[(size_t)it * width + k]; if (a >= 0) { used[a]++; touched.push_back(a); } }
+                } else next.push_back(it);
+            }
+            remaining.swap(next);
+        }
+        for (int a : touched) used[a] = 0;
+    }
+    return perm;
+}
+template <class T> static std::vector<T> permuted(const std::vector<T>& v, const std::vector<int>& perm, int width = 1) {
+    std::vector<T> out(v.size());
+    for (size_t k = 0; k < perm.size(); k++) for (int w = 0; w < width; w++) out[k * width + w] = v[(size_t)perm[k] * width + w];
+    return out;
+}
+
 // Largest band of diagonals q - p around 0 on which the nres x nres table t[q][p] is identically zero:
 // t[q][p] == 0 for all lo < q - p < hi.
 static void zero_band(const std::vector<double>& t, int nres, int* lo, int* hi) {
@@ -268,16 +305,18 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         S.inv_mass = upload(im);
         S.sqrt_inv_mass = upload(sim);
         S.nvs = (int)H.vs_site.size();
+        const std::vector<int> perm = spread_order(S.nvs, 3, H.vs_par.data(), natoms_);   // force redistribution adds to the parents
         std::vector<Int4> vs(S.nvs);
-        for (int i = 0; i < S.nvs; i++) vs[i] = Int4{H.vs_site[i], H.vs_par[3 * i], H.vs_par[3 * i + 1], H.vs_par[3 * i + 2]};
+        for (int i = 0; i < S.nvs; i++) { int o = perm[i]; vs[i] = Int4{H.vs_site[o], H.vs_par[3 * o], H.vs_par[3 * o + 1], H.vs_par[3 * o + 2]}; }
         S.vs = upload(vs);
-        S.vs_w = upload_real(H.vs_w);
+        S.vs_w = upload_real(permuted(H.vs_w, perm, 3));
     }
     {   // harmonic
         std::vector<HarmD<real>> D;
         for (auto& h : H.harm) {
             std::vector<HarmItem<real>> it(h.r0.size());
-            for (size_t b = 0; b < it.size(); b++) it[b] = HarmItem<real>{h.pairs[2 * b], h.pairs[2 * b + 1], (real)h.r0[b], (real)h.k[b]};
+            const std::vector<int> perm = spread_order((int)it.size(), 2, h.pairs.data(), natoms_);
+            for (size_t b = 0; b < it.size(); b++) { int o = perm[b]; it[b] = HarmItem<real>{h.pairs[2 * o], h.pairs[2 * o + 1], (real)h.r0[o], (real)h.k[o]}; }
             D.push_back(HarmD<real>{h.group, (int)it.size(), upload(it)});
         }
         if (D.size() > AWSEM_MAX_HARM) throw std::string("too many harm terms: at most " + std::to_string(AWSEM_MAX_HARM) + " per system");
@@ -287,7 +326,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         std::vector<ChiD<real>> D;
         for (auto& h : H.chi) {
             std::vector<Int4> a(h.atoms.size() / 4);
-            for (size_t b = 0; b < a.size(); b++) a[b] = Int4{h.atoms[4 * b], h.atoms[4 * b + 1], h.atoms[4 * b + 2], h.atoms[4 * b + 3]};
+            const std::vector<int> perm = spread_order((int)a.size(), 4, h.atoms.data(), natoms_);
+            for (size_t b = 0; b < a.size(); b++) { int o = perm[b]; a[b] = Int4{h.atoms[4 * o], h.atoms[4 * o + 1], h.atoms[4 * o + 2], h.atoms[4 * o + 3]}; }
             D.push_back(ChiD<real>{h.group, (int)a.size(), upload(a), (real)h.k, (real)h.chi0});
         }
         if (D.size() > AWSEM_MAX_CHI) throw std::string("too many chi terms: at most " + std::to_string(AWSEM_MAX_CHI) + " per system");
@@ -300,11 +340,12 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             memset(&d, 0, sizeof d);
             d.group = h.group; d.n = (int)(h.atoms.size() / 5); d.nwell = h.nwell;
             std::vector<Int5> a(d.n);
-            for (int b = 0; b < d.n; b++) for (int k = 0; k < 5; k++) a[b].a[k] = h.atoms[5 * b + k];
+            const std::vector<int> perm = spread_order(d.n, 5, h.atoms.data(), natoms_);
+            for (int b = 0; b < d.n; b++) for (int k = 0; k < 5; k++) a[b].a[k] = h.atoms[5 * perm[b] + k];
             d.atoms = upload(a);
             std::vector<real> bw((size_t)d.n * h.nwell);
             for (int b = 0; b < d.n; b++) for (int w = 0; w < h.nwell; w++)
-                bw[(size_t)b * h.nwell + w] = (real)(-h.k * h.wp[6 * w] * h.bw[(size_t)b * h.nwell + w]);
+                bw[(size_t)b * h.nwell + w] = (real)(-h.k * h.wp[6 * w] * h.bw[(size_t)perm[b] * h.nwell + w]);
             d.bw = upload(bw);
             for (int w = 0; w < h.nwell; w++) {
                 const double* p = &h.wp[6 * w];
@@ -433,7 +474,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         std::vector<HelicalD<real>> D;
         for (auto& h : H.helical) {
             std::vector<HelicalItem<real>> it(h.coef.size());
-            for (size_t b = 0; b < it.size(); b++) it[b] = HelicalItem<real>{h.atoms[3 * b], h.atoms[3 * b + 1], h.atoms[3 * b + 2], (real)h.coef[b]};
+            const std::vector<int> perm = spread_order((int)it.size(), 3, h.atoms.data(), natoms_);
+            for (size_t b = 0; b < it.size(); b++) { int o = perm[b]; it[b] = HelicalItem<real>{h.atoms[3 * o], h.atoms[3 * o + 1], h.atoms[3 * o + 2], (real)h.coef[o]}; }
             D.push_back(HelicalD<real>{h.group, (int)it.size(), upload(it), (real)h.r_ON, (real)h.r_OH, (real)(1.0 / (h.s_NO * h.s_NO)), (real)(1.0 / (h.s_HO * h.s_HO))});
         }
         if (D.size() > AWSEM_MAX_HELICAL) throw std::string("too many helical terms: at most " + std::to_string(AWSEM_MAX_HELICAL) + " per system");
@@ -443,10 +485,11 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         std::vector<FmD<real>> D;
         for (auto& h : H.fm) {
             const int nb = (int)(h.pairs.size() / 2);
+            const std::vector<int> perm = spread_order(nb, 2, h.pairs.data(), natoms_);
             std::vector<real2_t<real>> t2((size_t)nb * (h.ntab - 1));
             for (int b = 0; b < nb; b++) for (int i = 0; i + 1 < h.ntab; i++)
-                t2[(size_t)b * (h.ntab - 1) + i] = real2_t<real>{(real)h.table[(size_t)b * h.ntab + i], (real)h.table[(size_t)b * h.ntab + i + 1]};
-            D.push_back(FmD<real>{h.group, nb, h.ntab, upload(h.pairs), upload(t2), (real)h.k, (real)h.dr, (real)(1.0 / h.dr)});
+                t2[(size_t)b * (h.ntab - 1) + i] = real2_t<real>{(real)h.table[(size_t)perm[b] * h.ntab + i], (real)h.table[(size_t)perm[b] * h.ntab + i + 1]};
+            D.push_back(FmD<real>{h.group, nb, h.ntab, upload(permuted(h.pairs, perm, 2)), upload(t2), (real)h.k, (real)h.dr, (real)(1.0 / h.dr)});
         }
         if (D.size() > AWSEM_MAX_FM) throw std::string("too many fm terms: at most " + std::to_string(AWSEM_MAX_FM) + " per system");
         S.n_fm = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.fm[t] = D[t];
@@ -465,7 +508,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         std::vector<DhD<real>> D;
         for (auto& h : H.dh) {
             std::vector<DhItem<real>> it(h.qq.size());
-            for (size_t b = 0; b < it.size(); b++) it[b] = DhItem<real>{h.pairs[2 * b], h.pairs[2 * b + 1], (real)h.qq[b], (real)0};
+            const std::vector<int> perm = spread_order((int)it.size(), 2, h.pairs.data(), natoms_);
+            for (size_t b = 0; b < it.size(); b++) { int o = perm[b]; it[b] = DhItem<real>{h.pairs[2 * o], h.pairs[2 * o + 1], (real)h.qq[o], (real)0}; }
             D.push_back(DhD<real>{h.group, (int)it.size(), upload(it), (real)h.k, (real)(1.0 / h.lam)});
         }
         if (D.size() > AWSEM_MAX_DH) throw std::string("too many dh terms: at most " + std::to_string(AWSEM_MAX_DH) + " per system");

@@ -214,6 +214,9 @@ template <bool ENERGY, class real> __device__ void term_fm(const FmD<real>& d, c
     Energy e;
     constexpr int U = 4;
     const int stride = blockDim.x;
+#ifdef AWSEM_EXP_FM_NOATOMIC
+    real dummy = 0;
+#endif
     for (int b0 = threadIdx.x; b0 < d.n; b0 += U * stride) {
         int ai[U], aj[U], i1[U];
         real dx[U], dy[U], dz[U], ir[U], r[U], v1[U], v2[U];
@@ -234,17 +237,28 @@ template <bool ENERGY, class real> __device__ void term_fm(const FmD<real>& d, c
             real fi = M<real>::floor(r[u] * d.inv_dr);
             fi -= (r[u] - fi * d.dr < (real)0) ? (real)1 : (real)0;   // r*inv_dr may round up across a bin edge: keep r >= fi*dr
             i1[u] = fi > (real)(d.ntab - 2) ? d.ntab - 2 : (int)fi;
+#ifdef AWSEM_EXP_FM_NOGATHER
+            v1[u] = r[u]; v2[u] = r[u] + (real)1;
+#else
             const real2_t<real> v = d.table2[(size_t)b * (d.ntab - 1) + i1[u]];   // (t[i], t[i+1]) in one load
             v1[u] = v.x; v2[u] = v.y;
+#endif
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (!ok[u]) continue;
             real slope = (v2[u] - v1[u]) * d.inv_dr;
             if (ENERGY) e += (double)(-d.k * (v1[u] + slope * (r[u] - d.dr * (real)i1[u])));
+#ifdef AWSEM_EXP_FM_NOATOMIC
+            dummy += d.k * slope * ir[u] * (dx[u] + dy[u] + dz[u]);
+#else
             pair_force(L, ai[u], aj[u], dx[u], dy[u], dz[u], d.k * slope * ir[u]);
+#endif
         }
     }
+#ifdef AWSEM_EXP_FM_NOATOMIC
+    if (dummy == (real)123.456) L.fx[0] = 1;
+#endif
     flush_energy<ENERGY>(L, d.group, e);
 }
 

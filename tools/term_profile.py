@@ -19,10 +19,12 @@ def main():
     ap.add_argument("--replicas", type=int, default=1024)
     ap.add_argument("--md-steps", type=int, default=50)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", default=None, help="comma separated list of configurations to time (e.g. none,all,12:fragment_memory)")
+    ap.add_argument("--lib", default=None, help="alternative libawsem_hip.so (experiments)")
     ap.add_argument("--collapse-steps", type=int, default=0, help="run this many steps with all terms first and reuse the state")
     args = ap.parse_args()
     oa = workloads.build_1r69()
-    api = _capi.load_hip_library()
+    api = _capi.load_hip_library(args.lib)
     R = args.replicas
     T = np.full(R, 600.0)
     x0 = v0 = None
@@ -39,6 +41,8 @@ def main():
         ctx.close()
     names = ["none", "all"] + [f"{i}:{f.kind}" for i, f in enumerate(oa.system.forces)]
     print(f"{'term':24s} {'ms/launch':>10s} {'us/replica-step':>16s}")
+    if args.only:
+        names = [n for n in names if n in args.only.split(",")]
     for name in names:
         sysm = System(oa.system.masses.copy())
         sysm.virtual_sites = dict(oa.system.virtual_sites)
