@@ -36,6 +36,7 @@ template <class real> struct HarmItem { int i, j; real r0, k; };
 template <class real> struct HelicalItem { int o, n, h; real coef; };
 template <class real> struct DhItem { int i, j; real qq, pad; };
 template <class real> struct MembItem { int atom; real scale; };
+template <class real> struct alignas(16) MassiveItem { int atom; real inv_mass, sqrt_inv_mass, pad; };
 struct Int4 { int x, y, z, w; };
 template <class real> struct alignas(2 * sizeof(real)) real2_t { real x, y; };
 struct Int5 { int a[5]; };
@@ -103,6 +104,8 @@ template <class real> struct DevSys {
     const real* vs_w;                     // 3 per site
     const real* inv_mass;                 // natoms (0 for massless)
     const real* sqrt_inv_mass;
+    const MassiveItem<real>* massive;     // the nmassive particles the integrator moves
+    int nmassive;
     int n_harm, n_chi, n_rama, n_excl, n_contact, n_beta, n_pap, n_helical, n_fm, n_memb, n_dh;
     HarmD<real> harm[AWSEM_MAX_HARM]; ChiD<real> chi[AWSEM_MAX_CHI]; RamaD<real> rama[AWSEM_MAX_RAMA];
     ExclD<real> excl[AWSEM_MAX_EXCL]; ContactD<real> contact[AWSEM_MAX_CONTACT]; BetaD<real> beta[AWSEM_MAX_BETA];
@@ -115,5 +118,6 @@ template <class real> struct DevSys {
     int n_lists;
     real skin_half2;                      // (skin/2)^2: lists are rebuilt once an atom has moved further than skin/2
     int* status;                          // device error word: bit 0 = a pair list overflowed
+    long long* prof;                      // 16 phase-cycle accumulators (written by -DAWSEM_PROF builds only)
 };
 static_assert(sizeof(DevSys<double>) <= 4000, "DevSys must fit the 4 KB kernarg segment");

@@ -95,6 +95,17 @@ public:
     }
     ~Engine() override {
         (void)hipSetDevice(device_);
+        if (getenv("AWSEM_PROF_DUMP") && dsys_.prof) {   // phase cycles of -DAWSEM_PROF experiment builds
+            long long p[16] = {0};
+            (void)hipDeviceSynchronize();
+            if (hipMemcpy(p, dsys_.prof, sizeof p, hipMemcpyDeviceToHost) == hipSuccess) {
+                static const char* names[10] = {"vsites", "zero+displacement", "list rebuild", "rho zero", "density+fm", "single+harm+rama",
+                                                "pairs+beta", "chain+chi+dh+excl+pap", "redistribute", "integrate"};
+                long long tot = 0;
+                for (int k = 0; k < 10; k++) tot += p[k];
+                if (tot > 0) for (int k = 0; k < 10; k++) fprintf(stderr, "[awsem prof] %-24s %14lld cycles  %5.1f %%\n", names[k], p[k], 100.0 * p[k] / tot);
+            }
+        }
         for (void* p : allocs_) (void)hipFree(p);
         if (ev0_) (void)hipEventDestroy(ev0_);
         if (ev1_) (void)hipEventDestroy(ev1_);
@@ -304,6 +315,10 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         }
         S.inv_mass = upload(im);
         S.sqrt_inv_mass = upload(sim);
+        std::vector<MassiveItem<real>> mv;
+        for (int i = 0; i < natoms_; i++) if (H.mass[i] > 0) mv.push_back(MassiveItem<real>{i, im[i], sim[i], (real)0});
+        S.massive = upload(mv);
+        S.nmassive = (int)mv.size();
         S.nvs = (int)H.vs_site.size();
         const std::vector<int> perm = spread_order(S.nvs, 3, H.vs_par.data(), natoms_);   // force redistribution adds to the parents
         std::vector<Int4> vs(S.nvs);
@@ -570,6 +585,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         HIP_TRY(hipMemset(dstatus_, 0, sizeof(int)));
         S.status = dstatus_;
         dcounts_ = dalloc<unsigned>((size_t)nrep_ * AWSEM_MAX_LISTS);
+        S.prof = dalloc<long long>(16);
+        HIP_TRY(hipMemset(S.prof, 0, 16 * sizeof(long long)));
     }
     dsys_ = S;
 

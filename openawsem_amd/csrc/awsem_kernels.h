@@ -15,6 +15,23 @@
 
 typedef unsigned long long u64;
 
+// Phase timing of the step kernel (experiment builds only: -DAWSEM_PROF): thread 0 of every workgroup adds the
+// cycles between consecutive stamps to DevSys::prof[phase]; dumped by the host when AWSEM_PROF_DUMP is set.
+#ifdef AWSEM_PROF
+struct AwsemProf { long long last, acc[10]; };
+#define AWSEM_STAMP(S, k) do { long long _t = __builtin_readcyclecounter(); awsem_prof.acc[k] += _t - awsem_prof.last; awsem_prof.last = _t; } while (0)
+#define AWSEM_STAMP_INIT AwsemProf awsem_prof; awsem_prof.last = __builtin_readcyclecounter(); for (int _k = 0; _k < 10; _k++) awsem_prof.acc[_k] = 0
+#define AWSEM_STAMP_FLUSH(S) do { if (threadIdx.x == 0) for (int _k = 0; _k < 10; _k++) atomicAdd((unsigned long long*)&(S).prof[_k], (unsigned long long)awsem_prof.acc[_k]); } while (0)
+#define AWSEM_STAMP_ARG , AwsemProf& awsem_prof
+#define AWSEM_STAMP_PASS , awsem_prof
+#else
+#define AWSEM_STAMP(S, k) do { } while (0)
+#define AWSEM_STAMP_INIT do { } while (0)
+#define AWSEM_STAMP_FLUSH(S) do { } while (0)
+#define AWSEM_STAMP_ARG
+#define AWSEM_STAMP_PASS
+#endif
+
 // ------------------------------------------------------------------ scalar helpers
 template <class real> struct M;
 template <> struct M<float> {
@@ -24,7 +41,8 @@ template <> struct M<float> {
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
     static __device__ __forceinline__ float floor(float x) { return floorf(x); }
     static __device__ __forceinline__ float log(float x) { return __logf(x); }
-    static __device__ __forceinline__ void sincos2pi(float u, float* s, float* c) { *s = sinpif(2.0f * u); *c = cospif(2.0f * u); }
+    // v_sin_f32 / v_cos_f32 take their argument in revolutions: sin(2 pi u) for u in [0,1) in one instruction each
+    static __device__ __forceinline__ void sincos2pi(float u, float* s, float* c) { *s = __builtin_amdgcn_sinf(u); *c = __builtin_amdgcn_cosf(u); }
 };
 template <> struct M<double> {
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
@@ -94,10 +112,25 @@ template <bool ENERGY, class real> __device__ __forceinline__ void flush_energy(
 // it keeps full relative accuracy in the tails where 1+tanh cancels, and costs one exp + one rcp.
 template <class real> __device__ __forceinline__ real sigmoid(real x) { return M<real>::rcp((real)1 + M<real>::exp(-x)); }
 
+// Item loops are block-strided; `rot` shifts which wave takes the first 64 items, so that the short terms of one
+// phase (a few dozen dihedrals, the per-site contact pass ...) land on different waves instead of all on wave 0.
+__device__ __forceinline__ int rot_tid(int rot) {
+    int t = (int)threadIdx.x + 64 * rot;
+    return t >= (int)blockDim.x ? t - (int)blockDim.x : t;
+}
+struct Rotor {   // hands out starting waves: each job continues where the previous one stopped
+    int acc = 0;
+    __device__ __forceinline__ int next(int nitems) {
+        const int nw = blockDim.x >> 6, r = acc % nw;
+        acc += (nitems + 63) >> 6;
+        return r;
+    }
+};
+
 // ------------------------------------------------------------------ bonded terms
-template <bool ENERGY, class real> __device__ void term_harmonic(const HarmD<real>& d, const Lds<real>& L) {
+template <bool ENERGY, class real> __device__ void term_harmonic(const HarmD<real>& d, const Lds<real>& L, int rot = 0) {
     Energy e;
-    for (int b = threadIdx.x; b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
         HarmItem<real> it = d.items[b];
         real dx = L.px[it.i] - L.px[it.j], dy = L.py[it.i] - L.py[it.j], dz = L.pz[it.i] - L.pz[it.j];
         real r2 = dx * dx + dy * dy + dz * dz, ir = M<real>::rsqrt(r2), r = r2 * ir, dr = r - it.r0;
@@ -107,9 +140,9 @@ template <bool ENERGY, class real> __device__ void term_harmonic(const HarmD<rea
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-template <bool ENERGY, class real> __device__ void term_chi(const ChiD<real>& d, const Lds<real>& L) {
+template <bool ENERGY, class real> __device__ void term_chi(const ChiD<real>& d, const Lds<real>& L, int rot = 0) {
     Energy e;
-    for (int b = threadIdx.x; b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
         Int4 a = d.atoms[b];   // CA, C, N, CB
         real ux = L.px[a.x] - L.px[a.y], uy = L.py[a.x] - L.py[a.y], uz = L.pz[a.x] - L.pz[a.y];
         real vx = L.px[a.z] - L.px[a.x], vy = L.py[a.z] - L.py[a.x], vz = L.pz[a.z] - L.pz[a.x];
@@ -156,9 +189,9 @@ template <class real> __device__ __forceinline__ void dihedral(const Lds<real>& 
     }
 }
 
-template <bool ENERGY, class real> __device__ void term_rama(const RamaD<real>& d, const Lds<real>& L) {
+template <bool ENERGY, class real> __device__ void term_rama(const RamaD<real>& d, const Lds<real>& L, int rot = 0) {
     Energy e;
-    for (int b = threadIdx.x; b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
         Int5 a = d.atoms[b];
         Dihedral<real> P, S;
         dihedral(L, a.a[0], a.a[1], a.a[2], a.a[3], P);
@@ -192,9 +225,9 @@ template <class real> __device__ __forceinline__ real hb_theta(real r1, real r2,
     return th;
 }
 
-template <bool ENERGY, class real> __device__ void term_helical(const HelicalD<real>& d, const Lds<real>& L) {
+template <bool ENERGY, class real> __device__ void term_helical(const HelicalD<real>& d, const Lds<real>& L, int rot = 0) {
     Energy e;
-    for (int b = threadIdx.x; b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
         HelicalItem<real> it = d.items[b];
         real ax = L.px[it.o] - L.px[it.n], ay = L.py[it.o] - L.py[it.n], az = L.pz[it.o] - L.pz[it.n];
         real bx = L.px[it.o] - L.px[it.h], by = L.py[it.o] - L.py[it.h], bz = L.pz[it.o] - L.pz[it.h];
@@ -210,14 +243,14 @@ template <bool ENERGY, class real> __device__ void term_helical(const HelicalD<r
 
 // Fragment memory: per bond two neighbouring floats of an L2-resident table row.  Four bonds are kept in flight per
 // thread so that the dependent chain (pair indices -> LDS coordinates -> table gather) overlaps across bonds.
-template <bool ENERGY, class real> __device__ void term_fm(const FmD<real>& d, const Lds<real>& L) {
+template <bool ENERGY, class real> __device__ void term_fm(const FmD<real>& d, const Lds<real>& L, int rot = 0) {
     Energy e;
     constexpr int U = 4;
     const int stride = blockDim.x;
 #ifdef AWSEM_EXP_FM_NOATOMIC
     real dummy = 0;
 #endif
-    for (int b0 = threadIdx.x; b0 < d.n; b0 += U * stride) {
+    for (int b0 = rot_tid(rot); b0 < d.n; b0 += U * stride) {
         int ai[U], aj[U], i1[U];
         real dx[U], dy[U], dz[U], ir[U], r[U], v1[U], v2[U];
         bool ok[U];
@@ -262,9 +295,9 @@ template <bool ENERGY, class real> __device__ void term_fm(const FmD<real>& d, c
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-template <bool ENERGY, class real> __device__ void term_memb(const MembD<real>& d, const Lds<real>& L) {
+template <bool ENERGY, class real> __device__ void term_memb(const MembD<real>& d, const Lds<real>& L, int rot = 0) {
     Energy e;
-    for (int b = threadIdx.x; b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
         MembItem<real> it = d.items[b];
         real z = L.pz[it.atom] - d.center;
         // 1/2 tanh(u) + 1/2 tanh(v) = sig(2u) + sig(2v) - 1
@@ -276,9 +309,9 @@ template <bool ENERGY, class real> __device__ void term_memb(const MembD<real>& 
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-template <bool ENERGY, class real> __device__ void term_dh(const DhD<real>& d, const Lds<real>& L) {
+template <bool ENERGY, class real> __device__ void term_dh(const DhD<real>& d, const Lds<real>& L, int rot = 0) {
     Energy e;
-    for (int b = threadIdx.x; b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
         DhItem<real> it = d.items[b];
         real dx = L.px[it.i] - L.px[it.j], dy = L.py[it.i] - L.py[it.j], dz = L.pz[it.i] - L.pz[it.j];
         real r2 = dx * dx + dy * dy + dz * dz, ir = M<real>::rsqrt(r2), r = r2 * ir;
@@ -421,9 +454,9 @@ template <class real> __device__ void contact_density(const ContactD<real>& d, c
 }
 // Between pass 1 and 2: evaluate the burial wells (single-particle energy), seed dE/drho, and precompute the
 // per-site water switch s_i = sig(-2 eta_s (rho_i - rho0)) (sigma_water_ij = s_i s_j) into L.rhov.
-template <bool ENERGY, class real> __device__ void contact_single(const ContactD<real>& d, const Lds<real>& L, const int* satom) {
+template <bool ENERGY, class real> __device__ void contact_single(const ContactD<real>& d, const Lds<real>& L, const int* satom, int rot = 0) {
     Energy e;
-    for (int i = threadIdx.x; i < d.nsites; i += blockDim.x) {
+    for (int i = rot_tid(rot); i < d.nsites; i += blockDim.x) {
         real rho = (real)fixed_to_double(L.rho[i]);
         L.rhov[i] = sigmoid(-d.eta_s2 * (rho - d.rho0));
         real dE = 0;
@@ -675,54 +708,63 @@ template <class real> __device__ void build_lists(const DevSys<real>& S, const L
     for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) build_hbond(S.pap[t], S.pap[t].gamma, L, S.status);
 }
 
-// Evaluate every term whose group is in `mask` from the current pair lists.  Forces accumulate into L.f* (zeroed by
-// the caller and visible: call after a __syncthreads()); ends with all contributions visible to the workgroup.
-template <bool ENERGY, class real> __device__ void evaluate_terms(const DevSys<real>& S, const Lds<real>& L, unsigned mask) {
-    // the contact passes are separated by workgroup barriers; the other terms are issued in between so that waves
-    // which reach a barrier late have less to wait for
+// Evaluate every term whose group is in `mask` from the current pair lists.  Forces accumulate into L.f* and the
+// density of the first contact term into L.rho: both zeroed by the caller and visible (call after a __syncthreads());
+// ends with all contributions visible to the workgroup.
+// The contact passes need workgroup barriers between them, which cuts the evaluation into four phases; every other
+// term is issued in one of the phases so that each phase keeps all waves busy.
+template <bool ENERGY, class real> __device__ void evaluate_terms(const DevSys<real>& S, const Lds<real>& L, unsigned mask AWSEM_STAMP_ARG) {
+    int first = -1;   // the contact term whose passes define the phases
+    for (int t = S.n_contact - 1; t >= 0; t--) if (AWSEM_ON(S.contact[t])) first = t;
+    const ContactD<real>* c0 = first >= 0 ? &S.contact[first] : nullptr;
+    const int* satom0 = L.satom + (first >= 0 ? first : 0) * S.max_contact_sites;
     const bool multi = S.n_contact > 1;
-    for (int t = 0; t < S.n_contact; t++) {
+    if (c0 && multi) { stage_contact_gamma(*c0, L); __syncthreads(); }
+    Rotor rotor;
+    // phase A
+    if (c0) contact_density(*c0, L, satom0);
+    for (int u = 0; u < S.n_fm; u++) if (AWSEM_ON(S.fm[u])) term_fm<ENERGY>(S.fm[u], L, rotor.next(S.fm[u].n));
+    for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
+    for (int u = 0; u < S.n_chi; u++) if (AWSEM_ON(S.chi[u])) term_chi<ENERGY>(S.chi[u], L, rotor.next(S.chi[u].n));
+    if (c0) __syncthreads();
+    AWSEM_STAMP(S, 4);
+    // phase B
+    rotor.acc = 0;
+    if (c0) contact_single<ENERGY>(*c0, L, satom0, rotor.next(c0->nsites));
+    for (int u = 0; u < S.n_harm; u++) if (AWSEM_ON(S.harm[u])) term_harmonic<ENERGY>(S.harm[u], L, rotor.next(S.harm[u].n));
+    for (int u = 0; u < S.n_dh; u++) if (AWSEM_ON(S.dh[u])) term_dh<ENERGY>(S.dh[u], L, rotor.next(S.dh[u].n));
+    for (int u = 0; u < S.n_helical; u++) if (AWSEM_ON(S.helical[u])) term_helical<ENERGY>(S.helical[u], L, rotor.next(S.helical[u].n));
+    for (int u = 0; u < S.n_memb; u++) if (AWSEM_ON(S.memb[u])) term_memb<ENERGY>(S.memb[u], L, rotor.next(S.memb[u].n));
+    if (c0) __syncthreads();
+    AWSEM_STAMP(S, 5);
+    // phase C
+    if (c0 && !(c0->flags & 2)) contact_pairs<ENERGY>(*c0, L, satom0);
+    for (int u = 0; u < S.n_beta; u++) if (AWSEM_ON(S.beta[u])) eval_beta<ENERGY>(S.beta[u], L);
+    if (c0) __syncthreads();
+    AWSEM_STAMP(S, 6);
+    // phase D
+    if (c0) contact_chain_rule(*c0, L, satom0);
+    for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) eval_excl<ENERGY>(S.excl[t], L);
+    for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) eval_pap<ENERGY>(S.pap[t], L);
+    // further contact terms (e.g. a standalone burial term next to the contact term) reuse the density scratch
+    for (int t = first + 1; first >= 0 && t < S.n_contact; t++) {
         const ContactD<real>& d = S.contact[t];
         if (!AWSEM_ON(d)) continue;   // uniform: S and mask are
         const int* satom = L.satom + t * S.max_contact_sites;
-        if (multi) {   // the density scratch and the gamma staging area are shared between contact terms
-            __syncthreads();
-            stage_contact_gamma(d, L);
-        }
+        __syncthreads();
+        stage_contact_gamma(d, L);
         for (int i = threadIdx.x; i < d.nsites; i += blockDim.x) L.rho[i] = 0;
         __syncthreads();
         contact_density(d, L, satom);
-        if (t == 0) {
-            for (int u = 0; u < S.n_fm; u++) if (AWSEM_ON(S.fm[u])) term_fm<ENERGY>(S.fm[u], L);
-        }
         __syncthreads();
         contact_single<ENERGY>(d, L, satom);
-        if (t == 0) {
-            for (int u = 0; u < S.n_harm; u++) if (AWSEM_ON(S.harm[u])) term_harmonic<ENERGY>(S.harm[u], L);
-            for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L);
-        }
         __syncthreads();
         if (!(d.flags & 2)) contact_pairs<ENERGY>(d, L, satom);
-        if (t == 0) {
-            for (int u = 0; u < S.n_beta; u++) if (AWSEM_ON(S.beta[u])) eval_beta<ENERGY>(S.beta[u], L);
-        }
         __syncthreads();
         contact_chain_rule(d, L, satom);
     }
-    const bool first_contact_on = S.n_contact > 0 && AWSEM_ON(S.contact[0]);
-    if (!first_contact_on) {
-        for (int u = 0; u < S.n_fm; u++) if (AWSEM_ON(S.fm[u])) term_fm<ENERGY>(S.fm[u], L);
-        for (int u = 0; u < S.n_harm; u++) if (AWSEM_ON(S.harm[u])) term_harmonic<ENERGY>(S.harm[u], L);
-        for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L);
-        for (int u = 0; u < S.n_beta; u++) if (AWSEM_ON(S.beta[u])) eval_beta<ENERGY>(S.beta[u], L);
-    }
-    for (int t = 0; t < S.n_chi; t++) if (AWSEM_ON(S.chi[t])) term_chi<ENERGY>(S.chi[t], L);
-    for (int t = 0; t < S.n_helical; t++) if (AWSEM_ON(S.helical[t])) term_helical<ENERGY>(S.helical[t], L);
-    for (int t = 0; t < S.n_memb; t++) if (AWSEM_ON(S.memb[t])) term_memb<ENERGY>(S.memb[t], L);
-    for (int t = 0; t < S.n_dh; t++) if (AWSEM_ON(S.dh[t])) term_dh<ENERGY>(S.dh[t], L);
-    for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) eval_excl<ENERGY>(S.excl[t], L);
-    for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) eval_pap<ENERGY>(S.pap[t], L);
     __syncthreads();
+    AWSEM_STAMP(S, 7);
 }
 
 // ------------------------------------------------------------------ LDS carve-up
@@ -777,13 +819,15 @@ __global__ void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__
     L.lists = S.lists + (size_t)rep * S.list_stride;
     load_positions(pos + (size_t)rep * 3 * natoms, L, natoms);
     for (int i = threadIdx.x; i < natoms; i += blockDim.x) { L.fx[i] = 0; L.fy[i] = 0; L.fz[i] = 0; }
+    for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
     if (threadIdx.x < AWSEM_NGROUPS) L.eg[threadIdx.x] = 0;
     if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
     stage_tables(S, L);
     __syncthreads();
     build_lists(S, L, mask);
     __syncthreads();
-    evaluate_terms<ENERGY>(S, L, mask);
+    AWSEM_STAMP_INIT;
+    evaluate_terms<ENERGY>(S, L, mask AWSEM_STAMP_PASS);
     if (f_out) {
         if (redistribute) { redistribute_forces(S, L); __syncthreads(); }
         double* f = f_out + (size_t)rep * 3 * natoms;
@@ -894,11 +938,14 @@ __global__ void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, 
     stage_tables(S, L);
     if (threadIdx.x == 0) L.flag[0] = 0;
     __syncthreads();
+    AWSEM_STAMP_INIT;
     for (int s = 0; s < nsteps; s++) {
         compute_virtual_sites(S, L);
         __syncthreads();
+        AWSEM_STAMP(S, 0);
         {   // zero the accumulators; how far has any atom (virtual sites included) moved since the lists were built?
             real m = 0;
+            for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
             for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
                 L.fx[i] = 0; L.fy[i] = 0; L.fz[i] = 0;
                 if (s > 0) m = fmax(m, dist2(L.px[i] - L.rx[i], L.py[i] - L.ry[i], L.pz[i] - L.rz[i]));
@@ -909,23 +956,26 @@ __global__ void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, 
             }
         }
         __syncthreads();
+        AWSEM_STAMP(S, 1);
         if (s == 0 || __uint_as_float(L.flag[0]) > (float)S.skin_half2) {   // uniform across the workgroup
             if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
             for (int i = threadIdx.x; i < natoms; i += blockDim.x) { L.rx[i] = L.px[i]; L.ry[i] = L.py[i]; L.rz[i] = L.pz[i]; }
             __syncthreads();
             build_lists(S, L, 0xffffffffu);
             __syncthreads();
+            AWSEM_STAMP(S, 2);
         }
-        evaluate_terms<false>(S, L, 0xffffffffu);
+        evaluate_terms<false>(S, L, 0xffffffffu AWSEM_STAMP_PASS);
         redistribute_forces(S, L);
         if (threadIdx.x == 0) L.flag[0] = 0;   // every thread has read it; the next atomicMax comes after two more barriers
         __syncthreads();
-        for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
-            real im = S.inv_mass[i];
-            if (im == (real)0) continue;
+        AWSEM_STAMP(S, 8);
+        for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {   // compact list: no lane idles on a virtual site
+            const MassiveItem<real> mi = S.massive[k];
+            const int i = mi.atom;
+            const real im = mi.inv_mass, sq = mi.sqrt_inv_mass;
             real g[3];
             gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, i, g);
-            real sq = S.sqrt_inv_mass[i];
             real fx = (real)fixed_to_double(L.fx[i]), fy = (real)fixed_to_double(L.fy[i]), fz = (real)fixed_to_double(L.fz[i]);
             real vx = a * L.vx[i] + fs * im * fx + ns * sq * g[0];
             real vy = a * L.vy[i] + fs * im * fy + ns * sq * g[1];
@@ -934,7 +984,9 @@ __global__ void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, 
             L.px[i] += dtr * vx; L.py[i] += dtr * vy; L.pz[i] += dtr * vz;
         }
         __syncthreads();
+        AWSEM_STAMP(S, 9);
     }
+    AWSEM_STAMP_FLUSH(S);
     compute_virtual_sites(S, L);
     __syncthreads();
     for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
