@@ -162,6 +162,12 @@ public:
         check_status();
     }
     void step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) override {
+        if (!step_ok_) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "dynamics of %d atoms needs %zu bytes of LDS per replica in this precision; the replica-resident path is limited to %zu",
+                     natoms_, lds_step_, lds_max_);
+            throw std::string(msg);
+        }
         HIP_TRY(hipSetDevice(device_));
         upload_T(T);
         HIP_TRY(hipEventRecord(ev0_, stream_));
@@ -245,7 +251,8 @@ private:
     int* dstatus_ = nullptr;
     unsigned* dcounts_ = nullptr;
     double skin_ = 0.15;
-    size_t lds_list_ = 0;
+    size_t lds_list_ = 0, lds_max_ = 0;
+    bool step_ok_ = false;
 };
 
 // Order static items (bonds, dihedrals, virtual sites ...) so that the 64 items one wave handles in one
@@ -604,15 +611,17 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
     HIP_TRY(hipGetDeviceProperties(&prop, device_));
     size_t lds_max = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
     if (prop.maxSharedMemoryPerMultiProcessor > lds_max) lds_max = prop.maxSharedMemoryPerMultiProcessor;
-    if (lds_step_ > lds_max) {
+    if (lds_eval_ > lds_max) {
         char msg[256];
         snprintf(msg, sizeof msg, "system of %d atoms needs %zu bytes of LDS per replica; the replica-resident path is limited to %zu",
-                 natoms_, lds_step_, lds_max);
+                 natoms_, lds_eval_, lds_max);
         throw std::string(msg);
     }
+    step_ok_ = lds_step_ <= lds_max;   // energies/forces need less LDS than dynamics (no velocities, no list reference positions)
+    lds_max_ = lds_max;
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<true, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<false, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
-    HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
+    if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_list_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     block_ = natoms_ > 1024 ? 512 : 256;
     if (const char* env = getenv("AWSEM_BLOCK")) {

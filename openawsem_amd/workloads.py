@@ -46,13 +46,43 @@ def default_forces(oa):
     ]
 
 
-def build_1r69(quiet=True):
+def _fragment_memory(oa, mem_file):
+    tmp = f"/tmp/frags-{os.getpid()}.npz"
+    fm = templateTerms.fragment_memory_term(oa, frag_file_list_file=mem_file, npy_frag_table=tmp, UseSavedFragTable=False)
+    if os.path.exists(tmp):
+        os.remove(tmp)
+    return fm
+
+
+def build_1r69(quiet=True, fragment_library=False):
     """1r69 (63 residues, 368 atoms) from its extended-chain openmmawsem.pdb with the default forces_setup.py terms:
-    BASELINE.json configs[0]/[1]."""
+    BASELINE.json configs[0]/[1].  fragment_library=True swaps the single native memory for the reference's
+    examples/1r69/frags.mem (1100 memories over 614 fragment files, trimmed to the atoms the term reads by
+    tools/make_workload_fixtures.py): the many-memory stress named in BASELINE.json configs[2]."""
     folder = str(data_path.data / "1r69")
     with _cwd(folder), contextlib.redirect_stdout(io.StringIO() if quiet else None):
         oa = OpenMMAWSEMSystem("1r69-openmmawsem.pdb", k_awsem=1.0, seqFromPdb=read_fasta("1r69.fasta"))
-        oa.addForcesWithDefaultForceGroup(default_forces(oa))
+        forces = default_forces(oa)
+        if fragment_library:
+            forces[12] = _fragment_memory(oa, "./frags.mem")
+        oa.addForcesWithDefaultForceGroup(forces)
+    tmp = f"/tmp/single_frags-{os.getpid()}.npz"
+    if os.path.exists(tmp):
+        os.remove(tmp)
+    return oa
+
+
+def build_t0958(quiet=True):
+    """T0958 (96 residues, 559 atoms): default terms + helical_term, fragment memory from single_frags.mem (the
+    reference's examples/T0958 ships no fragment library, so the memory is its own native structure, see
+    tools/make_workload_fixtures.py); pap terms read the project's ssweight: BASELINE.json configs[2]."""
+    folder = str(data_path.data / "T0958")
+    with _cwd(folder), contextlib.redirect_stdout(io.StringIO() if quiet else None):
+        oa = OpenMMAWSEMSystem("t0958-openmmawsem.pdb", k_awsem=1.0, seqFromPdb=read_fasta("t0958.fasta"))
+        forces = default_forces(oa)
+        forces.append(hydrogenBondTerms.helical_term(oa))
+        forces.append(basicTerms.rama_ssweight_term(oa, k_rama_ssweight=2 * 8.368, ssweight_file="ssweight"))
+        oa.addForcesWithDefaultForceGroup(forces)
     tmp = f"/tmp/single_frags-{os.getpid()}.npz"
     if os.path.exists(tmp):
         os.remove(tmp)
