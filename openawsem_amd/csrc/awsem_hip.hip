@@ -18,6 +18,7 @@
 
 #include "../../include/awsem_hip.h"
 #include "awsem_kernels.h"
+#include "awsem_cell.h"
 
 namespace {
 
@@ -114,13 +115,14 @@ public:
 
     void finalize(const HostSystem& H) override;
 
-    void set_positions(int rep, const double* xyz) override { set_state(pos_, rep, xyz); }
+    void set_positions(int rep, const double* xyz) override { set_state(pos_, rep, xyz); cell_stale_ = true; }
     void get_positions(int rep, double* xyz) override { get_state(pos_, rep, xyz); }
     void set_velocities(int rep, const double* v) override { set_state(vel_, rep, v); }
     void get_velocities(int rep, double* v) override { get_state(vel_, rep, v); }
 
     void compute_virtual_sites() override {
         HIP_TRY(hipSetDevice(device_));
+        cell_stale_ = true;
         hipLaunchKernelGGL(awsem_vsite_kernel<real>, dim3(nrep_), dim3(64), 0, stream_, dsys_, pos_);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream_));
@@ -141,6 +143,7 @@ public:
     }
     void energy_by_group(unsigned mask, double* e) override {
         HIP_TRY(hipSetDevice(device_));
+        if (cell_mode_) { cell_evaluate(true, mask, 0, e, nullptr); return; }
         HIP_TRY(hipEventRecord(ev0_, stream_));
         hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, dsys_, pos_, mask, 0, dE_, (double*)nullptr);
         HIP_TRY(hipGetLastError());
@@ -152,6 +155,7 @@ public:
     }
     void forces(unsigned mask, int redistribute, double* f) override {
         HIP_TRY(hipSetDevice(device_));
+        if (cell_mode_) { cell_evaluate(false, mask, redistribute, nullptr, f); return; }
         HIP_TRY(hipEventRecord(ev0_, stream_));
         hipLaunchKernelGGL((awsem_eval_kernel<false, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, dsys_, pos_, mask, redistribute, (double*)nullptr, dF_);
         HIP_TRY(hipGetLastError());
@@ -162,6 +166,7 @@ public:
         check_status();
     }
     void step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) override {
+        if (cell_mode_) { cell_step(nsteps, T, dt, friction, seed, step0); return; }
         if (!step_ok_) {
             char msg[256];
             snprintf(msg, sizeof msg, "dynamics of %d atoms needs %zu bytes of LDS per replica in this precision; the replica-resident path is limited to %zu",
@@ -210,6 +215,10 @@ private:
         HIP_TRY(hipMemcpy(&st, dstatus_, sizeof st, hipMemcpyDeviceToHost));
         if (st) {
             HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
+            if (st & 2) {
+                cell_stale_ = true;
+                throw std::string("neighbour list overflow on the cell-list path during dynamics: raise AWSEM_CELL_NEIGHBORS (pairs reserved per site, default 128)");
+            }
             throw std::string("pair list overflow on the device (internal error: list capacity below the candidate pair count)");
         }
     }
@@ -253,6 +262,22 @@ private:
     double skin_ = 0.15;
     size_t lds_list_ = 0, lds_max_ = 0;
     bool step_ok_ = false;
+
+    // ---- cell-list path (awsem_cell.h): systems that do not fit one CU's LDS
+    void cell_setup(DevSys<real>& S, const HostSystem& H);
+    void cell_alloc_lists();
+    void cell_refresh(const CellSys<real>& C, real rc2c, real rc2x);
+    void cell_forces_pass(bool energy, unsigned mask);
+    void cell_evaluate(bool energy, unsigned mask, int redistribute, double* e, double* f);
+    void cell_step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0);
+    int cell_neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity);
+    dim3 cell_grid(long long n) const { long long b = (n + 255) / 256; return dim3((unsigned)std::max(1LL, std::min(b, 2048LL)), nrep_); }
+    bool cell_mode_ = false, cell_stale_ = true;
+    CellSys<real> cell_;
+    const CellJob* cell_jobs_ = nullptr;
+    int cell_njobs_ = 0, cell_per_site_ = 128;
+    double cell_rc_contact_ = 0, cell_rc_excl_ = 0;
+    std::vector<int> excl_sorted_atom_, excl_sorted_cls_;   // class-sorted site table of excl term 0
 };
 
 // Order static items (bonds, dihedrals, virtual sites ...) so that the 64 items one wave handles in one
@@ -397,8 +422,10 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             d.class_start[ncls] = (int)atom.size();
             std::vector<Int4> partners(atom.size(), Int4{-1, -1, -1, -1});
             std::vector<int> count(atom.size(), 0);
+            std::vector<std::vector<int>> slots_of(natoms_);   // an atom may be listed as a site more than once
+            for (size_t s = 0; s < atom.size(); s++) slots_of[atom[s]].push_back((int)s);
             auto add_partner = [&](int a, int b) {
-                for (size_t s = 0; s < atom.size(); s++) if (atom[s] == a) {
+                for (int s : slots_of[a]) {
                     int* q = &partners[s].x;
                     if (count[s] >= 4) throw std::string("excl: more than 4 excluded partners for one atom");
                     q[count[s]++] = b;
@@ -406,6 +433,11 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             };
             for (size_t q = 0; q + 1 < h.excl.size(); q += 2) { add_partner(h.excl[q], h.excl[q + 1]); add_partner(h.excl[q + 1], h.excl[q]); }
             d.atom = upload(atom); d.partners = upload(partners);
+            if (D.empty()) {
+                excl_sorted_atom_ = atom;
+                excl_sorted_cls_.assign(atom.size(), 0);
+                for (int c = 0; c < ncls; c++) for (int q = d.class_start[c]; q < d.class_start[c + 1]; q++) excl_sorted_cls_[q] = c;
+            }
             D.push_back(d);
         }
         if (D.size() > AWSEM_MAX_EXCL) throw std::string("too many excl terms: at most " + std::to_string(AWSEM_MAX_EXCL) + " per system");
@@ -542,7 +574,25 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         double v = atof(env);
         if (v >= 0.0 && v <= 1.0) skin_ = v;
     }
+    dstatus_ = dalloc<int>(1);
+    HIP_TRY(hipMemset(dstatus_, 0, sizeof(int)));
+    S.status = dstatus_;
+    S.prof = dalloc<long long>(16);
+    HIP_TRY(hipMemset(S.prof, 0, 16 * sizeof(long long)));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_));
+    size_t lds_max = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
+    if (prop.maxSharedMemoryPerMultiProcessor > lds_max) lds_max = prop.maxSharedMemoryPerMultiProcessor;
+    lds_max_ = lds_max;
+    lds_eval_ = lds_bytes<real>(natoms_, S.max_contact_sites, S.n_contact, false);
+    lds_step_ = lds_bytes<real>(natoms_, S.max_contact_sites, S.n_contact, true);
     {
+        const char* force = getenv("AWSEM_FORCE_CELL");
+        cell_mode_ = lds_eval_ > lds_max || (force && atoi(force) != 0);
+    }
+    if (cell_mode_) {
+        cell_setup(S, H);
+    } else {
         if (natoms_ > 65535) throw std::string("the replica-resident path addresses atoms with 16 bits: at most 65535 atoms");
         long long off = 0;
         int id = 0;
@@ -588,12 +638,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         }
         S.lists = dalloc<unsigned>((size_t)S.list_stride * nrep_);
         S.skin_half2 = (real)(0.25 * skin_ * skin_ * 0.999);
-        dstatus_ = dalloc<int>(1);
-        HIP_TRY(hipMemset(dstatus_, 0, sizeof(int)));
-        S.status = dstatus_;
         dcounts_ = dalloc<unsigned>((size_t)nrep_ * AWSEM_MAX_LISTS);
-        S.prof = dalloc<long long>(16);
-        HIP_TRY(hipMemset(S.prof, 0, 16 * sizeof(long long)));
     }
     dsys_ = S;
 
@@ -604,21 +649,13 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
     HIP_TRY(hipMemset(vel_, 0, nstate * sizeof(real)));
     dT_ = dalloc<double>(nrep_); dE_ = dalloc<double>((size_t)nrep_ * AWSEM_NGROUPS); dF_ = dalloc<double>(nstate);
 
-    // launch geometry: one workgroup per replica, LDS sized by the system
-    lds_eval_ = lds_bytes<real>(natoms_, S.max_contact_sites, S.n_contact, false);
-    lds_step_ = lds_bytes<real>(natoms_, S.max_contact_sites, S.n_contact, true);
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device_));
-    size_t lds_max = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
-    if (prop.maxSharedMemoryPerMultiProcessor > lds_max) lds_max = prop.maxSharedMemoryPerMultiProcessor;
-    if (lds_eval_ > lds_max) {
-        char msg[256];
-        snprintf(msg, sizeof msg, "system of %d atoms needs %zu bytes of LDS per replica; the replica-resident path is limited to %zu",
-                 natoms_, lds_eval_, lds_max);
-        throw std::string(msg);
+    if (cell_mode_) {   // the cell-list kernels use no dynamic LDS
+        cell_.f = dalloc<u64>(nstate);
+        cell_.ref = dalloc<real>(nstate);
+        return;
     }
+    // launch geometry: one workgroup per replica, LDS sized by the system
     step_ok_ = lds_step_ <= lds_max;   // energies/forces need less LDS than dynamics (no velocities, no list reference positions)
-    lds_max_ = lds_max;
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<true, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<false, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
@@ -633,6 +670,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
 // Pair set of one pair term: rebuild that term's list with cutoff + skin and decode the entries.
 template <class real> int Engine<real>::neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) {
     HIP_TRY(hipSetDevice(device_));
+    if (cell_mode_) return cell_neighbors(rep, kind, index, skin, pairs, capacity);
     DevSys<real> S = dsys_;
     ListSlot ls;
     int group;
@@ -667,6 +705,185 @@ template <class real> int Engine<real>::neighbors(int rep, int kind, int index, 
         if (kind == AWSEM_LIST_CONTACT) out[k] = {(int)(e[k] & 0x3ff), (int)((e[k] >> 10) & 0x3ff)};
         else out[k] = {(int)(e[k] >> 16), (int)(e[k] & 0xffff)};
         if (kind == AWSEM_LIST_EXCL && out[k].first > out[k].second) std::swap(out[k].first, out[k].second);
+    }
+    std::sort(out.begin(), out.end());
+    for (unsigned k = 0; k < n && (int)k < capacity; k++) { pairs[2 * k] = out[k].first; pairs[2 * k + 1] = out[k].second; }
+    return (int)n;
+}
+
+// ------------------------------------------------------------------------------------------------ cell-list path
+template <class real> void Engine<real>::cell_setup(DevSys<real>& S, const HostSystem& H) {
+    if (S.n_beta || S.n_pap)
+        throw std::string("this system does not fit the LDS of one CU, and the hydrogen-bond terms (dense nres x nres tables) are "
+                          "only available on the replica-resident path: the cell-list path takes contact/burial, excluded volume and the bonded terms");
+    if (S.n_contact > 1 || S.n_excl > 1) throw std::string("cell-list path: at most one contact and one excluded-volume term");
+    if (S.n_contact && (H.contact[0].flags & AWSEM_CONTACT_NOCUTOFF)) throw std::string("cell-list path: the contact term needs a cutoff");
+    if (S.n_contact && S.contact[0].nsites >= (1 << 24)) throw std::string("cell-list path: at most 2^24 contact sites");
+    if (const char* env = getenv("AWSEM_CELL_NEIGHBORS")) { int v = atoi(env); if (v >= 8 && v <= 4096) cell_per_site_ = v; }
+    CellSys<real>& C = cell_;
+    memset(&C, 0, sizeof C);
+    C.natoms = natoms_; C.nrep = nrep_; C.nsites = S.n_contact ? S.contact[0].nsites : 0;
+    std::vector<int> c_site(natoms_, -1), x_slot(natoms_, -1), x_cls(natoms_, -1);
+    if (S.n_contact) for (int i = 0; i < C.nsites; i++) c_site[H.contact[0].atom[i]] = i;
+    if (S.n_excl) for (size_t q = 0; q < excl_sorted_atom_.size(); q++) { x_slot[excl_sorted_atom_[q]] = (int)q; x_cls[excl_sorted_atom_[q]] = excl_sorted_cls_[q]; }
+    C.c_site = upload(c_site); C.x_slot = upload(x_slot); C.x_cls = upload(x_cls);
+    cell_rc_contact_ = S.n_contact ? H.contact[0].p[AWSEM_CP_CUTOFF] : 0.0;
+    cell_rc_excl_ = S.n_excl ? H.excl[0].r0 : 0.0;
+    C.rc_cell = (real)(std::max(cell_rc_contact_, cell_rc_excl_) + skin_);
+    C.skin_half2 = (real)(0.25 * skin_ * skin_ * 0.999);
+    C.status = dstatus_;
+    const size_t R = nrep_;
+    C.bbox = dalloc<int>(R * 8); C.grid = dalloc<real>(R * 4); C.dims = dalloc<int>(R * 4);
+    C.cell_count = dalloc<int>(R * AWSEM_CELL_MAXCELLS); C.cell_start = dalloc<int>(R * (AWSEM_CELL_MAXCELLS + 1));
+    C.cell_of = dalloc<int>(R * natoms_); C.cell_atoms = dalloc<int>(R * natoms_);
+    C.counts = dalloc<unsigned>(R * 2);
+    HIP_TRY(hipMemset(C.counts, 0, R * 2 * sizeof(unsigned)));
+    C.eg = dalloc<u64>(R * AWSEM_NGROUPS);
+    const size_t ns = std::max(1, C.nsites);
+    C.rho = dalloc<u64>(R * ns); C.drho = dalloc<u64>(R * ns);
+    C.rhov = dalloc<real>(R * ns); C.alpha = dalloc<real>(R * ns); C.dalpha = dalloc<real>(R * ns);
+    C.flag = dalloc<unsigned>(R * 2);
+    HIP_TRY(hipMemset(C.flag, 0, R * 2 * sizeof(unsigned)));
+    cell_alloc_lists();
+    // bonded terms: one job per 256 items
+    std::vector<CellJob> jobs;
+    auto add = [&](int kind, int term, int n) { for (int f = 0; f < n; f += 256) jobs.push_back(CellJob{kind, term, f}); };
+    for (int t = 0; t < S.n_harm; t++) add(CJ_HARM, t, S.harm[t].n);
+    for (int t = 0; t < S.n_chi; t++) add(CJ_CHI, t, S.chi[t].n);
+    for (int t = 0; t < S.n_rama; t++) add(CJ_RAMA, t, S.rama[t].n);
+    for (int t = 0; t < S.n_helical; t++) add(CJ_HELICAL, t, S.helical[t].n);
+    for (int t = 0; t < S.n_fm; t++) add(CJ_FM, t, S.fm[t].n);
+    for (int t = 0; t < S.n_memb; t++) add(CJ_MEMB, t, S.memb[t].n);
+    for (int t = 0; t < S.n_dh; t++) add(CJ_DH, t, S.dh[t].n);
+    cell_njobs_ = (int)jobs.size();
+    cell_jobs_ = upload(jobs);
+    S.lists = nullptr; S.list_stride = 0; S.n_lists = 0; S.skin_half2 = C.skin_half2;
+}
+template <class real> void Engine<real>::cell_alloc_lists() {
+    CellSys<real>& C = cell_;
+    C.ccap = std::max<long long>(1024, (long long)C.nsites * cell_per_site_);
+    C.xcap = std::max<long long>(1024, (long long)excl_sorted_atom_.size() * std::max(16, cell_per_site_ / 2));
+    if (C.ccap > 0x7fffffffLL || C.xcap > 0x7fffffffLL) throw std::string("cell-list path: neighbour list capacity exceeds 2^31 entries per replica");
+    C.clist = dalloc<u64>((size_t)C.ccap * nrep_);
+    C.xlist = dalloc<u64>((size_t)C.xcap * nrep_);
+    cell_stale_ = true;
+}
+// displacement test and, for the replicas that need it, the whole list build (kernels of other replicas exit at once)
+template <class real> void Engine<real>::cell_refresh(const CellSys<real>& C, real rc2c, real rc2x) {
+    const dim3 ga = cell_grid(natoms_), b(256);
+    hipLaunchKernelGGL(cell_displacement_kernel<real>, ga, b, 0, stream_, C, pos_, cell_stale_ ? 1 : 0);
+    hipLaunchKernelGGL(cell_decide_kernel<real>, dim3((nrep_ + 63) / 64), dim3(64), 0, stream_, C);
+    hipLaunchKernelGGL(cell_bbox_kernel<real>, ga, b, 0, stream_, C, pos_);
+    hipLaunchKernelGGL(cell_grid_kernel<real>, dim3(AWSEM_CELL_MAXCELLS / 256, nrep_), b, 0, stream_, C);
+    hipLaunchKernelGGL(cell_count_kernel<real>, ga, b, 0, stream_, C, pos_);
+    hipLaunchKernelGGL(cell_scan_kernel<real>, dim3(nrep_), dim3(1024), 0, stream_, C);
+    hipLaunchKernelGGL(cell_fill_kernel<real>, ga, b, 0, stream_, C);
+    hipLaunchKernelGGL(cell_list_kernel<real>, ga, b, 0, stream_, dsys_, C, pos_, rc2c, rc2x);
+    HIP_TRY(hipGetLastError());
+    cell_stale_ = false;
+}
+template <class real> void Engine<real>::cell_forces_pass(bool energy, unsigned mask) {
+    const CellSys<real>& C = cell_;
+    const DevSys<real>& S = dsys_;
+    const size_t R = nrep_;
+    const dim3 b(256);
+    HIP_TRY(hipMemsetAsync(C.f, 0, R * 3 * natoms_ * sizeof(u64), stream_));
+    if (energy) HIP_TRY(hipMemsetAsync(C.eg, 0, R * AWSEM_NGROUPS * sizeof(u64), stream_));
+    if (cell_njobs_) {
+        if (energy) hipLaunchKernelGGL((cell_bonded_kernel<true, real>), dim3(cell_njobs_, nrep_), b, 0, stream_, S, C, pos_, cell_jobs_, mask);
+        else hipLaunchKernelGGL((cell_bonded_kernel<false, real>), dim3(cell_njobs_, nrep_), b, 0, stream_, S, C, pos_, cell_jobs_, mask);
+    }
+    if (S.n_contact && ((mask >> S.contact[0].group) & 1u)) {
+        HIP_TRY(hipMemsetAsync(C.rho, 0, R * C.nsites * sizeof(u64), stream_));
+        const dim3 gl = cell_grid(C.ccap / 4), gs = cell_grid(C.nsites);
+        hipLaunchKernelGGL(cell_density_kernel<real>, gl, b, 0, stream_, S, C, pos_);
+        if (energy) hipLaunchKernelGGL((cell_single_kernel<true, real>), gs, b, 0, stream_, S, C, pos_);
+        else hipLaunchKernelGGL((cell_single_kernel<false, real>), gs, b, 0, stream_, S, C, pos_);
+        if (!(S.contact[0].flags & 2)) {
+            if (energy) hipLaunchKernelGGL((cell_pairs_kernel<true, real>), gl, b, 0, stream_, S, C, pos_);
+            else hipLaunchKernelGGL((cell_pairs_kernel<false, real>), gl, b, 0, stream_, S, C, pos_);
+        }
+        hipLaunchKernelGGL(cell_chain_kernel<real>, gl, b, 0, stream_, S, C, pos_);
+    }
+    if (S.n_excl && ((mask >> S.excl[0].group) & 1u)) {
+        const dim3 gx = cell_grid(C.xcap / 4);
+        if (energy) hipLaunchKernelGGL((cell_excl_kernel<true, real>), gx, b, 0, stream_, S, C, pos_);
+        else hipLaunchKernelGGL((cell_excl_kernel<false, real>), gx, b, 0, stream_, S, C, pos_);
+    }
+    HIP_TRY(hipGetLastError());
+}
+template <class real> void Engine<real>::cell_evaluate(bool energy, unsigned mask, int redistribute, double* e, double* f) {
+    auto rc2 = [&](double cutoff) { double r = cutoff + skin_; return cutoff > 0 ? (real)(r * r) : (real)-1; };
+    for (int attempt = 0;; attempt++) {
+        HIP_TRY(hipEventRecord(ev0_, stream_));
+        cell_refresh(cell_, rc2(cell_rc_contact_), rc2(cell_rc_excl_));
+        cell_forces_pass(energy, mask);
+        if (f && redistribute) hipLaunchKernelGGL(cell_redistribute_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, cell_, pos_);
+        hipLaunchKernelGGL(cell_output_kernel<real>, cell_grid(natoms_), dim3(256), 0, stream_, cell_, f ? dF_ : (double*)nullptr, e ? dE_ : (double*)nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev1_, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        record_ms();
+        int st = 0;
+        HIP_TRY(hipMemcpy(&st, dstatus_, sizeof st, hipMemcpyDeviceToHost));
+        if (!(st & 2)) break;
+        HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
+        if (attempt >= 4) throw std::string("cell-list path: neighbour lists keep overflowing (more than 2048 pairs per site)");
+        cell_per_site_ *= 2;   // denser than expected: reserve more and rebuild
+        cell_alloc_lists();
+    }
+    if (e) HIP_TRY(hipMemcpy(e, dE_, sizeof(double) * nrep_ * AWSEM_NGROUPS, hipMemcpyDeviceToHost));
+    if (f) HIP_TRY(hipMemcpy(f, dF_, sizeof(double) * 3 * natoms_ * nrep_, hipMemcpyDeviceToHost));
+}
+template <class real> void Engine<real>::cell_step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) {
+    HIP_TRY(hipSetDevice(device_));
+    upload_T(T);
+    auto rc2 = [&](double cutoff) { double r = cutoff + skin_; return cutoff > 0 ? (real)(r * r) : (real)-1; };
+    const real rc2c = rc2(cell_rc_contact_), rc2x = rc2(cell_rc_excl_);
+    HIP_TRY(hipEventRecord(ev0_, stream_));
+    for (int s = 0; s < nsteps; s++) {
+        hipLaunchKernelGGL(awsem_vsite_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, pos_);
+        cell_refresh(cell_, rc2c, rc2x);
+        cell_forces_pass(false, 0xffffffffu);
+        hipLaunchKernelGGL(cell_redistribute_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, cell_, pos_);
+        hipLaunchKernelGGL(cell_integrate_kernel<real>, cell_grid(dsys_.nmassive), dim3(256), 0, stream_, dsys_, cell_, pos_, vel_, dT_, dt, friction,
+                           (unsigned long long)seed, (long long)(step0 + s));
+    }
+    hipLaunchKernelGGL(awsem_vsite_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, pos_);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev1_, stream_));
+    timing_pending_ = true;
+}
+template <class real> int Engine<real>::cell_neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) {
+    if (index != 0 || (kind != AWSEM_LIST_EXCL && kind != AWSEM_LIST_CONTACT)) throw std::string("neighbors (cell-list path): kind must be AWSEM_LIST_EXCL or AWSEM_LIST_CONTACT, index 0");
+    if ((kind == AWSEM_LIST_EXCL && !dsys_.n_excl) || (kind == AWSEM_LIST_CONTACT && !dsys_.n_contact)) throw std::string("neighbors: no such term");
+    const double cutoff = kind == AWSEM_LIST_EXCL ? cell_rc_excl_ : cell_rc_contact_, r = cutoff + skin;
+    std::vector<u64> ent;
+    for (int attempt = 0;; attempt++) {
+        CellSys<real> C = cell_;
+        C.rc_cell = (real)std::max((double)C.rc_cell, r);
+        cell_stale_ = true;
+        cell_refresh(C, kind == AWSEM_LIST_CONTACT ? (real)(r * r) : (real)-1, kind == AWSEM_LIST_EXCL ? (real)(r * r) : (real)-1);
+        cell_stale_ = true;   // the lists now hold a non-standard cutoff: rebuild before the next evaluation
+        HIP_TRY(hipStreamSynchronize(stream_));
+        int st = 0;
+        HIP_TRY(hipMemcpy(&st, dstatus_, sizeof st, hipMemcpyDeviceToHost));
+        if (!(st & 2)) break;
+        HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
+        if (attempt >= 4) throw std::string("cell-list path: neighbour lists keep overflowing");
+        cell_per_site_ *= 2;
+        cell_alloc_lists();
+    }
+    unsigned counts[2];
+    HIP_TRY(hipMemcpy(counts, cell_.counts + 2 * (size_t)rep, sizeof counts, hipMemcpyDeviceToHost));
+    const unsigned n = counts[kind == AWSEM_LIST_EXCL ? 1 : 0];
+    ent.resize(n);
+    const u64* src = kind == AWSEM_LIST_EXCL ? cell_.xlist + (size_t)rep * cell_.xcap : cell_.clist + (size_t)rep * cell_.ccap;
+    if (n) HIP_TRY(hipMemcpy(ent.data(), src, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
+    std::vector<std::pair<int, int>> out(n);
+    for (unsigned k = 0; k < n; k++) {
+        if (kind == AWSEM_LIST_CONTACT) out[k] = {(int)(ent[k] & 0xffffff), (int)((ent[k] >> 24) & 0xffffff)};
+        else out[k] = {(int)(ent[k] & 0xffffffffu), (int)(ent[k] >> 32)};
     }
     std::sort(out.begin(), out.end());
     for (unsigned k = 0; k < n && (int)k < capacity; k++) { pairs[2 * k] = out[k].first; pairs[2 * k + 1] = out[k].second; }

@@ -385,23 +385,25 @@ template <class real> __device__ void build_excl(const ExclD<real>& d, const Lds
         }
     }
 }
+// one candidate pair per lane (v = lane holds a pair); shared by the replica-resident and the cell-list path
+template <bool ENERGY, class real> __device__ __forceinline__ void excl_body(const ExclD<real>& d, const Lds<real>& L, int a, int b, bool v, Energy& e) {
+    const real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
+    const real r2 = dist2(dx, dy, dz);
+    if (v && r2 < d.r0 * d.r0) {   // clashes are rare: divergent body
+        const real ir = M<real>::rsqrt(r2), dr = r2 * ir - d.r0;
+        if (ENERGY) e += (double)(d.k * dr * dr);
+        pair_force(L, a, b, dx, dy, dz, (real)-2 * d.k * dr * ir);
+    }
+}
 template <bool ENERGY, class real> __device__ void eval_excl(const ExclD<real>& d, const Lds<real>& L) {
     AWSEM_WAVE_VARS;
     Energy e;
     const ListView<real> lv = list_view(L, d.ls);
-    const real r02 = d.r0 * d.r0;
     AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id) {
         const int idx = c0 + lane;
         const bool v = idx < lv.count;
         const unsigned ent = v ? lv.e[idx] : 0u;
-        const int a = ent >> 16, b = ent & 0xffff;
-        const real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
-        const real r2 = dist2(dx, dy, dz);
-        if (v && r2 < r02) {   // clashes are rare: divergent body
-            const real ir = M<real>::rsqrt(r2), dr = r2 * ir - d.r0;
-            if (ENERGY) e += (double)(d.k * dr * dr);
-            pair_force(L, a, b, dx, dy, dz, (real)-2 * d.k * dr * ir);
-        }
+        excl_body<ENERGY>(d, L, ent >> 16, ent & 0xffff, v, e);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
@@ -432,6 +434,18 @@ template <class real> __device__ void build_contact(const ContactD<real>& d, con
     }
 }
 // pass 1: density rho_i = sum_j theta_I(r_ij) inside the cutoff
+template <class real> __device__ __forceinline__ void density_body(const ContactD<real>& d, const Lds<real>& L, int i, int j, int a, int b, bool v) {
+    const real r2 = dist2(L.px[a] - L.px[b], L.py[a] - L.py[b], L.pz[a] - L.pz[b]);
+    const bool pass = v && r2 < d.cutoff2;
+    if (__ballot(pass) == 0) return;
+    const real r = M<real>::sqrt(r2);
+    const real th = sigmoid(d.eta2 * (r - d.rmin)) * sigmoid(d.eta2 * (d.rmax - r));
+    if (pass) {
+        const u64 t = to_fixed(th);
+        atomicAdd(&L.rho[i], t);
+        atomicAdd(&L.rho[j], t);
+    }
+}
 template <class real> __device__ void contact_density(const ContactD<real>& d, const Lds<real>& L, const int* satom) {
     AWSEM_WAVE_VARS;
     const ListView<real> lv = list_view(L, d.ls);
@@ -439,105 +453,110 @@ template <class real> __device__ void contact_density(const ContactD<real>& d, c
         const int idx = c0 + lane;
         const bool v = idx < lv.count;
         const unsigned ent = v ? lv.e[idx] : 0u;
-        const int i = ent & 0x3ff, j = (ent >> 10) & 0x3ff, a = satom[i], b = satom[j];
-        const real r2 = dist2(L.px[a] - L.px[b], L.py[a] - L.py[b], L.pz[a] - L.pz[b]);
-        const bool pass = v && (ent & 0x40000000u) && r2 < d.cutoff2;
-        if (__ballot(pass) == 0) continue;
-        const real r = M<real>::sqrt(r2);
-        const real th = sigmoid(d.eta2 * (r - d.rmin)) * sigmoid(d.eta2 * (d.rmax - r));
-        if (pass) {
-            const u64 t = to_fixed(th);
-            atomicAdd(&L.rho[i], t);
-            atomicAdd(&L.rho[j], t);
-        }
+        const int i = ent & 0x3ff, j = (ent >> 10) & 0x3ff;
+        density_body(d, L, i, j, satom[i], satom[j], v && (ent & 0x40000000u));
     }
 }
 // Between pass 1 and 2: evaluate the burial wells (single-particle energy), seed dE/drho, and precompute the
 // per-site water switch s_i = sig(-2 eta_s (rho_i - rho0)) (sigma_water_ij = s_i s_j) into L.rhov.
-template <bool ENERGY, class real> __device__ void contact_single(const ContactD<real>& d, const Lds<real>& L, const int* satom, int rot = 0) {
-    Energy e;
-    for (int i = rot_tid(rot); i < d.nsites; i += blockDim.x) {
-        real rho = (real)fixed_to_double(L.rho[i]);
-        L.rhov[i] = sigmoid(-d.eta_s2 * (rho - d.rho0));
-        real dE = 0;
-        if (d.has_burial) {
-            int t = (d.info[i] >> 27) & 31;
+template <bool ENERGY, class real> __device__ __forceinline__ void single_body(const ContactD<real>& d, const Lds<real>& L, int i, int atom, Energy& e) {
+    real rho = (real)fixed_to_double(L.rho[i]);
+    L.rhov[i] = sigmoid(-d.eta_s2 * (rho - d.rho0));
+    real dE = 0;
+    if (d.has_burial) {
+        int t = (d.info[i] >> 27) & 31;
 #pragma unroll
-            for (int m = 0; m < 3; m++) {
-                real gb = d.bgamma[t * 3 + m];
-                // tanh(a) + tanh(b) = 2 (sig(2a) + sig(2b) - 1)
-                real sa = sigmoid(d.kappa2 * (rho - d.rho_lo[m])), sb = sigmoid(d.kappa2 * (d.rho_hi[m] - rho));
-                if (ENERGY) e += (double)(-d.kb * gb * (sa + sb - (real)1));
-                dE += -d.kb * gb * d.kappa2 * (sa * ((real)1 - sa) - sb * ((real)1 - sb));
-            }
-        }
-        L.drho[i] = to_fixed(dE);
-        if (d.flags & 1) {
-            real z = L.pz[satom[i]] - d.zc;
-            real su = sigmoid(d.eta_sw2 * (z + d.z_m)), sv = sigmoid(d.eta_sw2 * (d.z_m - z));
-            L.alpha[i] = su + sv - (real)1;
-            L.dalpha[i] = d.eta_sw2 * (su * ((real)1 - su) - sv * ((real)1 - sv));
+        for (int m = 0; m < 3; m++) {
+            real gb = d.bgamma[t * 3 + m];
+            // tanh(a) + tanh(b) = 2 (sig(2a) + sig(2b) - 1)
+            real sa = sigmoid(d.kappa2 * (rho - d.rho_lo[m])), sb = sigmoid(d.kappa2 * (d.rho_hi[m] - rho));
+            if (ENERGY) e += (double)(-d.kb * gb * (sa + sb - (real)1));
+            dE += -d.kb * gb * d.kappa2 * (sa * ((real)1 - sa) - sb * ((real)1 - sb));
         }
     }
+    L.drho[i] = to_fixed(dE);
+    if (d.flags & 1) {
+        real z = L.pz[atom] - d.zc;
+        real su = sigmoid(d.eta_sw2 * (z + d.z_m)), sv = sigmoid(d.eta_sw2 * (d.z_m - z));
+        L.alpha[i] = su + sv - (real)1;
+        L.dalpha[i] = d.eta_sw2 * (su * ((real)1 - su) - sv * ((real)1 - sv));
+    }
+}
+template <bool ENERGY, class real> __device__ void contact_single(const ContactD<real>& d, const Lds<real>& L, const int* satom, int rot = 0) {
+    Energy e;
+    for (int i = rot_tid(rot); i < d.nsites; i += blockDim.x) single_body<ENERGY>(d, L, i, satom[i], e);
     flush_energy<ENERGY>(L, d.group, e);
 }
 // pass 2: pair energy (direct + mediated), its explicit radial force, and dE/drho through sigma_water
-template <bool ENERGY, class real> __device__ void contact_pairs(const ContactD<real>& d, const Lds<real>& L, const int* satom) {
-    AWSEM_WAVE_VARS;
-    Energy e;
+template <bool ENERGY, class real> __device__ __forceinline__ void pairs_body(const ContactD<real>& d, const Lds<real>& L, int i, int j, int ty, int a, int b, bool v, Energy& e) {
     const bool zdep = d.flags & 1;
     const real* g0 = L.gamma;
     const real* g1 = L.gamma + 1200;
     const real one = (real)1;
+    const real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
+    const real r2 = dist2(dx, dy, dz);
+    const bool pass = v && r2 < d.cutoff2;
+    if (__ballot(pass) == 0) return;
+    const real ir = M<real>::rsqrt(pass ? r2 : one), r = r2 * ir;
+    const real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
+    const real s3 = sigmoid(d.eta2 * (r - d.rminII)), s4 = sigmoid(d.eta2 * (d.rmaxII - r));
+    const real th1 = s1 * s2, dth1 = d.eta2 * th1 * (s2 - s1);
+    const real th2 = s3 * s4, dth2 = d.eta2 * th2 * (s4 - s3);
+    const real si = L.rhov[i], sj = L.rhov[j], sw = si * sj;
+    real E, dEdr, dEdsw, fzi = 0, fzj = 0;
+    if (!zdep) {
+        const real gd = g0[ty], gp = g0[400 + ty], gw = g0[800 + ty];
+        const real med = sw * gw + (one - sw) * gp;
+        E = -d.k * (gd * th1 + th2 * med);
+        dEdr = -d.k * (gd * dth1 + dth2 * med);
+        dEdsw = -d.k * th2 * (gw - gp);
+    } else {
+        const real med0 = sw * g0[800 + ty] + (one - sw) * g0[400 + ty];
+        const real med1 = sw * g1[800 + ty] + (one - sw) * g1[400 + ty];
+        const real W = -d.k * (g0[ty] * th1 + th2 * med0), Mm = -d.k * (g1[ty] * th1 + th2 * med1);
+        const real dW = -d.k * (g0[ty] * dth1 + dth2 * med0), dM = -d.k * (g1[ty] * dth1 + dth2 * med1);
+        const real ai = L.alpha[i], aj = L.alpha[j], aa = ai * aj;
+        E = (one - aa) * W + aa * Mm;
+        dEdr = (one - aa) * dW + aa * dM;
+        dEdsw = -d.k * th2 * ((one - aa) * (g0[800 + ty] - g0[400 + ty]) + aa * (g1[800 + ty] - g1[400 + ty]));
+        fzi = -(Mm - W) * aj * L.dalpha[i];
+        fzj = -(Mm - W) * ai * L.dalpha[j];
+    }
+    if (pass) {
+        if (ENERGY) e += (double)E;
+        pair_force(L, a, b, dx, dy, dz, -dEdr * ir);
+        atomicAdd(&L.drho[i], to_fixed(dEdsw * sj * (-d.eta_s2 * si * (one - si))));
+        atomicAdd(&L.drho[j], to_fixed(dEdsw * si * (-d.eta_s2 * sj * (one - sj))));
+        if (zdep) {
+            atomicAdd(&L.fz[a], to_fixed(fzi));
+            atomicAdd(&L.fz[b], to_fixed(fzj));
+        }
+    }
+}
+template <bool ENERGY, class real> __device__ void contact_pairs(const ContactD<real>& d, const Lds<real>& L, const int* satom) {
+    AWSEM_WAVE_VARS;
+    Energy e;
     const ListView<real> lv = list_view(L, d.ls);
     AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id + 1) {
         const int idx = c0 + lane;
         const bool v = idx < lv.count;
         const unsigned ent = v ? lv.e[idx] : 0u;
-        const int i = ent & 0x3ff, j = (ent >> 10) & 0x3ff, ty = (ent >> 20) & 0x1ff, a = satom[i], b = satom[j];
-        const real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
-        const real r2 = dist2(dx, dy, dz);
-        const bool pass = v && (ent >> 31) && r2 < d.cutoff2;
-        if (__ballot(pass) == 0) continue;
-        const real ir = M<real>::rsqrt(pass ? r2 : one), r = r2 * ir;
-        const real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
-        const real s3 = sigmoid(d.eta2 * (r - d.rminII)), s4 = sigmoid(d.eta2 * (d.rmaxII - r));
-        const real th1 = s1 * s2, dth1 = d.eta2 * th1 * (s2 - s1);
-        const real th2 = s3 * s4, dth2 = d.eta2 * th2 * (s4 - s3);
-        const real si = L.rhov[i], sj = L.rhov[j], sw = si * sj;
-        real E, dEdr, dEdsw, fzi = 0, fzj = 0;
-        if (!zdep) {
-            const real gd = g0[ty], gp = g0[400 + ty], gw = g0[800 + ty];
-            const real med = sw * gw + (one - sw) * gp;
-            E = -d.k * (gd * th1 + th2 * med);
-            dEdr = -d.k * (gd * dth1 + dth2 * med);
-            dEdsw = -d.k * th2 * (gw - gp);
-        } else {
-            const real med0 = sw * g0[800 + ty] + (one - sw) * g0[400 + ty];
-            const real med1 = sw * g1[800 + ty] + (one - sw) * g1[400 + ty];
-            const real W = -d.k * (g0[ty] * th1 + th2 * med0), Mm = -d.k * (g1[ty] * th1 + th2 * med1);
-            const real dW = -d.k * (g0[ty] * dth1 + dth2 * med0), dM = -d.k * (g1[ty] * dth1 + dth2 * med1);
-            const real ai = L.alpha[i], aj = L.alpha[j], aa = ai * aj;
-            E = (one - aa) * W + aa * Mm;
-            dEdr = (one - aa) * dW + aa * dM;
-            dEdsw = -d.k * th2 * ((one - aa) * (g0[800 + ty] - g0[400 + ty]) + aa * (g1[800 + ty] - g1[400 + ty]));
-            fzi = -(Mm - W) * aj * L.dalpha[i];
-            fzj = -(Mm - W) * ai * L.dalpha[j];
-        }
-        if (pass) {
-            if (ENERGY) e += (double)E;
-            pair_force(L, a, b, dx, dy, dz, -dEdr * ir);
-            atomicAdd(&L.drho[i], to_fixed(dEdsw * sj * (-d.eta_s2 * si * (one - si))));
-            atomicAdd(&L.drho[j], to_fixed(dEdsw * si * (-d.eta_s2 * sj * (one - sj))));
-            if (zdep) {
-                atomicAdd(&L.fz[a], to_fixed(fzi));
-                atomicAdd(&L.fz[b], to_fixed(fzj));
-            }
-        }
+        const int i = ent & 0x3ff, j = (ent >> 10) & 0x3ff, ty = (ent >> 20) & 0x1ff;
+        pairs_body<ENERGY>(d, L, i, j, ty, satom[i], satom[j], v && (ent >> 31), e);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
 // pass 3: chain rule through the densities: F_j += (dE/drho_i + dE/drho_j) theta_I'(r) (x_i - x_j)/r
+template <class real> __device__ __forceinline__ void chain_body(const ContactD<real>& d, const Lds<real>& L, int i, int j, int a, int b, bool v) {
+    const real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
+    const real r2 = dist2(dx, dy, dz);
+    const bool pass = v && r2 < d.cutoff2;
+    if (__ballot(pass) == 0) return;
+    const real ir = M<real>::rsqrt(pass ? r2 : (real)1), r = r2 * ir;
+    const real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
+    const real g = (real)(fixed_to_double(L.drho[i]) + fixed_to_double(L.drho[j]));
+    if (pass) pair_force(L, a, b, dx, dy, dz, -g * d.eta2 * s1 * s2 * (s2 - s1) * ir);
+}
 template <class real> __device__ void contact_chain_rule(const ContactD<real>& d, const Lds<real>& L, const int* satom) {
     AWSEM_WAVE_VARS;
     const ListView<real> lv = list_view(L, d.ls);
@@ -545,15 +564,8 @@ template <class real> __device__ void contact_chain_rule(const ContactD<real>& d
         const int idx = c0 + lane;
         const bool v = idx < lv.count;
         const unsigned ent = v ? lv.e[idx] : 0u;
-        const int i = ent & 0x3ff, j = (ent >> 10) & 0x3ff, a = satom[i], b = satom[j];
-        const real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
-        const real r2 = dist2(dx, dy, dz);
-        const bool pass = v && (ent & 0x40000000u) && r2 < d.cutoff2;
-        if (__ballot(pass) == 0) continue;
-        const real ir = M<real>::rsqrt(pass ? r2 : (real)1), r = r2 * ir;
-        const real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
-        const real g = (real)(fixed_to_double(L.drho[i]) + fixed_to_double(L.drho[j]));
-        if (pass) pair_force(L, a, b, dx, dy, dz, -g * d.eta2 * s1 * s2 * (s2 - s1) * ir);
+        const int i = ent & 0x3ff, j = (ent >> 10) & 0x3ff;
+        chain_body(d, L, i, j, satom[i], satom[j], v && (ent & 0x40000000u));
     }
 }
 

@@ -107,6 +107,48 @@ def build_2xov(quiet=True):
     return oa
 
 
+def build_synthetic(n_chains=122, seed=2026, spacing_nm=5.5, quiet=True):
+    """Synthetic multi-chain system of BASELINE.json configs[4]: `n_chains` copies of the 164-residue 2lzm chain
+    (tests/golden/2lzm-openmmawsem.pdb: one of the reference's own test structures) on a jittered cubic lattice with
+    random rigid rotations (seeded), 122 chains = 20008 residues / 118k atoms.  Terms: con, chain, chi, excl, rama,
+    rama_proline, contact (with burial) -- the hydrogen-bond and fragment-memory terms are left out, as the config
+    says (contact/burial cell-list scaling)."""
+    import numpy as np
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "2lzm-openmmawsem.pdb")
+    atoms = [ln for ln in open(src) if ln.startswith("ATOM")]
+    xyz = np.array([[float(ln[30:38]), float(ln[38:46]), float(ln[46:54])] for ln in atoms])
+    xyz -= xyz.mean(0)
+    rng = np.random.default_rng(seed)
+    side = int(np.ceil(n_chains ** (1.0 / 3.0)))
+    ids = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789"
+    path = f"/tmp/awsem-synthetic-{n_chains}-{seed}-{os.getpid()}.pdb"
+    with open(path, "w") as fh:
+        serial = 0
+        for c in range(n_chains):
+            q = rng.normal(size=4)
+            q /= np.linalg.norm(q)
+            w, x, y, z = q
+            rot = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                            [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                            [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+            cell = np.array([c % side, (c // side) % side, c // (side * side)], dtype=float)
+            shift = (cell + rng.uniform(-0.1, 0.1, size=3)) * spacing_nm * 10.0
+            pos = xyz @ rot.T + shift
+            for ln, p in zip(atoms, pos):
+                serial += 1
+                fh.write("ATOM  %5d %s%s%s%8.3f%8.3f%8.3f%s" % (serial % 100000, ln[12:21], ids[c % len(ids)], ln[22:30], p[0], p[1], p[2], ln[54:]))
+            fh.write("TER\n")
+        fh.write("END\n")
+    seq1 = read_fasta(os.path.join(os.path.dirname(src), "2lzm-crystal_structure.fasta"))
+    with contextlib.redirect_stdout(io.StringIO() if quiet else None):
+        oa = OpenMMAWSEMSystem(path, k_awsem=1.0, seqFromPdb=seq1 * n_chains)
+        oa.addForcesWithDefaultForceGroup([
+            basicTerms.con_term(oa), basicTerms.chain_term(oa), basicTerms.chi_term(oa), basicTerms.excl_term(oa, periodic=False),
+            basicTerms.rama_term(oa), basicTerms.rama_proline_term(oa), contactTerms.contact_term(oa)])
+    os.remove(path)
+    return oa
+
+
 def algorithmic_bytes_per_replica_step(oa):
     """fp32 state read+write (x, v: 12 B each way per massive particle = 48 B) plus two
     adjacent fragment-memory table floats per bond (8 B)."""

@@ -1,0 +1,144 @@
+"""Cell-list path (awsem_cell.h) against the replica-resident path, the fp64 oracle and the oracle's brute-force pair
+sets.  Small systems are pushed onto the cell-list path with AWSEM_FORCE_CELL=1; the synthetic multi-chain system
+(BASELINE.json configs[4]) takes it by itself because it does not fit the LDS of a CU.
+
+The per-pair arithmetic is shared by both paths and every sum is fixed point, so energies and forces of the two
+paths agree to fp rounding of single contributions (the compiler may contract an a*b+c differently in the two
+kernels): |dF| <= 1e-4 kJ/mol/nm in fp32, 1e-9 in fp64 -- far inside the tolerance against the oracle.  No reference fixture exists for neighbour lists or for systems of this size
+("parity unpinned"): the oracle's O(N^2) scan is the checker.
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+import openawsem_amd as oa_pkg
+from openawsem_amd import _capi, workloads
+from openawsem_amd.forces import System
+from oracle import awsem_oracle
+from tests.common import golden_system
+
+pytestmark = pytest.mark.gpu
+
+CELL_KINDS = ("harmonic", "chi", "rama", "excl", "contact", "fragment_memory", "debye_huckel", "helical", "membrane")
+
+
+def _without_hbonds(oa):
+    s = System(oa.system.masses.copy())
+    s.virtual_sites = dict(oa.system.virtual_sites)
+    s.forces = [f for f in oa.system.forces if f.kind in CELL_KINDS]
+    assert any(f.kind == "contact" for f in s.forces) and any(f.kind == "excl" for f in s.forces)
+    return s
+
+
+def _ctx(system, R, precision, cell, monkeypatch):
+    if cell:
+        monkeypatch.setenv("AWSEM_FORCE_CELL", "1")
+    else:
+        monkeypatch.delenv("AWSEM_FORCE_CELL", raising=False)
+    ctx = _capi.Context(_capi.load_hip_library(), system.getNumParticles(), n_replicas=R, precision=precision)
+    system.upload(ctx)
+    return ctx
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("protein", ["1brs", "2lzm"])
+def test_cell_path_equals_resident_path(protein, precision, monkeypatch):
+    oa, traj, _ = golden_system(protein)
+    system = _without_hbonds(oa)
+    frames = [0, 6, 11]
+    a = _ctx(system, len(frames), precision, False, monkeypatch)
+    b = _ctx(system, len(frames), precision, True, monkeypatch)
+    for r, f in enumerate(frames):
+        a.set_positions(traj[f], replica=r)
+        b.set_positions(traj[f], replica=r)
+    atol = 1e-4 if precision == 0 else 1e-9
+    ea, eb = a.energy_by_group(), b.energy_by_group()
+    assert np.abs(ea).sum() > 0 and np.abs(ea - eb).max() <= atol, np.abs(ea - eb).max()
+    for redistribute in (False, True):
+        fa, fb = a.forces(redistribute=redistribute), b.forces(redistribute=redistribute)
+        assert np.abs(fa - fb).max() <= atol, np.abs(fa - fb).max()
+    # single group masks take the same route
+    assert np.abs(a.energy(1 << 22) - b.energy(1 << 22)).max() <= atol
+    # the cell path itself is deterministic although its list order is not
+    assert np.array_equal(fb, b.forces(redistribute=True)) and np.array_equal(eb, b.energy_by_group())
+    # and against the fp64 oracle
+    cpu = awsem_oracle.make_context(system, n_replicas=len(frames), threads=3)
+    for r, f in enumerate(frames):
+        cpu.set_positions(traj[f], replica=r)
+    ec, fc = cpu.energy_by_group(), cpu.forces(redistribute=True)
+    tol_e, tol_f = (1e-4, 3e-3) if precision == 0 else (1e-7, 1e-7)   # energies are 2^-32 fixed-point sums
+    assert (np.abs(eb - ec) / np.maximum(np.abs(ec), 1.0)).max() <= tol_e
+    assert np.linalg.norm(fb - fc) <= tol_f * np.linalg.norm(fc)
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_cell_neighbour_lists_equal_brute_force(precision, monkeypatch):
+    oa, traj, _ = golden_system("1brs")
+    system = _without_hbonds(oa)
+    gpu = _ctx(system, 2, precision, True, monkeypatch)
+    cpu = _capi.Context(awsem_oracle.load(), oa.natoms, 2, precision=precision)
+    system.upload(cpu)
+    for ctx in (gpu, cpu):
+        ctx.set_positions(traj[1], replica=0)
+        ctx.set_positions(traj[9], replica=1)
+    for kind in (_capi.LIST_EXCL, _capi.LIST_CONTACT):
+        for replica in (0, 1):
+            for skin in (0.0, 0.15, 0.4):
+                a, b = gpu.neighbors(kind, 0, replica, skin), cpu.neighbors(kind, 0, replica, skin)
+                assert len(b) > 20 and np.array_equal(a, b), f"kind {kind} replica {replica} skin {skin}: {len(a)} vs {len(b)}"
+    # an evaluation after a neighbour query rebuilds the lists with the standard cutoff
+    e = gpu.energy_by_group()
+    assert np.isfinite(e).all()
+
+
+def test_cell_dynamics_tracks_resident_path(monkeypatch):
+    oa, traj, _ = golden_system("1ubq")
+    system = _without_hbonds(oa)
+    T = np.array([300.0, 700.0])
+    out = []
+    for cell in (False, True):
+        ctx = _ctx(system, 2, 1, cell, monkeypatch)     # fp64: differences are summation-order noise only
+        ctx.set_positions(traj[2], replica=-1)
+        ctx.set_velocities_to_temperature(T, 4)
+        for chunk in (30, 70):
+            ctx.step(chunk, T, 0.002, 1.0, 21)
+        ctx.synchronize()
+        out.append((np.stack([ctx.get_positions(r) for r in range(2)]), np.stack([ctx.get_velocities(r) for r in range(2)])))
+    assert np.abs(out[0][0][1] - traj[2]).max() > 0.05
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-9 and np.abs(out[0][1] - out[1][1]).max() < 1e-7
+
+
+def test_hydrogen_bond_terms_are_refused_on_the_cell_path(monkeypatch):
+    oa, _, _ = golden_system("1ubq")
+    monkeypatch.setenv("AWSEM_FORCE_CELL", "1")
+    ctx = _capi.Context(_capi.load_hip_library(), oa.natoms, 1)
+    with pytest.raises(_capi.AwsemError, match="hydrogen-bond terms"):
+        oa.system.upload(ctx)
+
+
+def test_synthetic_multichain_system_takes_the_cell_path():
+    """~2600 residues (16 chains): too large for LDS, small enough for the O(N^2) oracle in seconds."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        oa = workloads.build_synthetic(n_chains=16, seed=3)
+    assert oa.nres == 16 * 164
+    gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, 1, precision=0)
+    oa.system.upload(gpu)
+    cpu = _capi.Context(awsem_oracle.load(), oa.natoms, 1, precision=0)
+    oa.system.upload(cpu)
+    cpu._call("set_threads", 8)
+    for ctx in (gpu, cpu):
+        ctx.set_positions(oa.pdb.positions)
+    for kind in (_capi.LIST_EXCL, _capi.LIST_CONTACT):
+        a, b = gpu.neighbors(kind, 0, 0, 0.15), cpu.neighbors(kind, 0, 0, 0.15)
+        assert len(b) > 1000 and np.array_equal(a, b)
+    eg, ec = gpu.energy_by_group(), cpu.energy_by_group()
+    assert (np.abs(eg - ec) / np.maximum(np.abs(ec), 1.0)).max() <= 1e-4
+    fg, fc = gpu.forces(), cpu.forces()
+    assert np.linalg.norm(fg - fc) <= 1e-3 * np.linalg.norm(fc)
+    # dynamics: lists are rebuilt on the device as the chains move; energies stay finite and change
+    gpu.set_velocities_to_temperature([300.0], 1)
+    gpu.step(200, [300.0], 0.002, 1.0, 1)
+    e2 = gpu.energy_by_group()
+    assert np.isfinite(e2).all() and not np.array_equal(e2, eg)
