@@ -42,7 +42,7 @@ template <class real> struct CellSys {
     real *rhov, *alpha, *dalpha;
     // list validity
     real* ref;                  // [R][3][natoms] positions at the last build
-    unsigned* flag;             // [R][2]: [0] largest squared displacement (float bits), [1] != 0 -> rebuild
+    unsigned* flag;             // [R][2]: [0] != 0 -> an atom moved further than skin/2, [1] != 0 -> rebuild in progress
     real rc_cell;               // minimum cell edge = largest (cutoff + skin)
     real skin_half2;
     int* status;                // bit 1: neighbour list overflow
@@ -80,21 +80,17 @@ template <class real> __global__ void cell_displacement_kernel(CellSys<real> C, 
     const int rep = blockIdx.y, n = C.natoms;
     const real* p = pos + (size_t)rep * 3 * n;
     const real* q = C.ref + (size_t)rep * 3 * n;
-    float m = 0;
+    bool moved = force != 0;
     if (!force)
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-            m = fmaxf(m, (float)dist2(p[i] - q[i], p[n + i] - q[n + i], p[2 * n + i] - q[2 * n + i]));
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
-    if ((threadIdx.x & 63) == 0) {
-        if (force) atomicMax(&C.flag[2 * rep], 0x7f800000u);   // +inf
-        else if (m > 0) atomicMax(&C.flag[2 * rep], __float_as_uint(m));
-    }
+            moved |= (float)dist2(p[i] - q[i], p[n + i] - q[n + i], p[2 * n + i] - q[2 * n + i]) > (float)C.skin_half2;
+    if (__ballot(moved) && (threadIdx.x & 63) == 0) C.flag[2 * rep] = 1u;   // same value from every writer: no atomic needed
 }
 // one thread per replica: decide, and reset what a rebuild accumulates into
 template <class real> __global__ void cell_decide_kernel(CellSys<real> C) {
     const int rep = blockIdx.x * blockDim.x + threadIdx.x;
     if (rep >= C.nrep) return;
-    const bool rebuild = __uint_as_float(C.flag[2 * rep]) > (float)C.skin_half2;
+    const bool rebuild = C.flag[2 * rep] != 0;
     C.flag[2 * rep + 1] = rebuild ? 1u : 0u;
     C.flag[2 * rep] = 0;
     if (rebuild) {
@@ -107,6 +103,9 @@ template <class real> __global__ void cell_bbox_kernel(CellSys<real> C, const re
     if (!C.flag[2 * rep + 1]) return;
     const real* p = pos + (size_t)rep * 3 * n;
     real* q = C.ref + (size_t)rep * 3 * n;
+    __shared__ int slo[3], shi[3];
+    if (threadIdx.x < 3) { slo[threadIdx.x] = 0x7fffffff; shi[threadIdx.x] = (int)0x80000000; }
+    __syncthreads();
     float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         for (int k = 0; k < 3; k++) {
@@ -116,8 +115,10 @@ template <class real> __global__ void cell_bbox_kernel(CellSys<real> C, const re
         }
     for (int k = 0; k < 3; k++) {
         for (int off = 32; off > 0; off >>= 1) { lo[k] = fminf(lo[k], __shfl_down(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_down(hi[k], off)); }
-        if ((threadIdx.x & 63) == 0) { atomicMin(&C.bbox[8 * rep + k], ordered_int(lo[k])); atomicMax(&C.bbox[8 * rep + 4 + k], ordered_int(hi[k])); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&slo[k], ordered_int(lo[k])); atomicMax(&shi[k], ordered_int(hi[k])); }
     }
+    __syncthreads();
+    if (threadIdx.x < 3) { atomicMin(&C.bbox[8 * rep + threadIdx.x], slo[threadIdx.x]); atomicMax(&C.bbox[8 * rep + 4 + threadIdx.x], shi[threadIdx.x]); }
 }
 // grid (ceil(MAXCELLS / block), R): grid geometry (every thread derives the same numbers) and zeroed cell counts
 template <class real> __global__ void cell_grid_kernel(CellSys<real> C) {
@@ -156,6 +157,7 @@ template <class real> __global__ void cell_count_kernel(CellSys<real> C, const r
     if (!C.flag[2 * rep + 1]) return;
     const real* p = pos + (size_t)rep * 3 * n;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (C.c_site[i] < 0 && C.x_cls[i] < 0) { C.cell_of[(size_t)rep * n + i] = -1; continue; }   // only atoms that are a site of a listed term
         int c[3];
         cell_coords(C, rep, p[i], p[n + i], p[2 * n + i], c);
         const int cell = (c[2] * C.dims[4 * rep + 1] + c[1]) * C.dims[4 * rep] + c[0];
@@ -191,6 +193,7 @@ template <class real> __global__ void cell_fill_kernel(CellSys<real> C) {
     if (!C.flag[2 * rep + 1]) return;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int cell = C.cell_of[(size_t)rep * n + i];
+        if (cell < 0) continue;
         const int slot = C.cell_start[(size_t)rep * (AWSEM_CELL_MAXCELLS + 1) + cell] + atomicAdd(&C.cell_count[(size_t)rep * AWSEM_CELL_MAXCELLS + cell], 1);
         C.cell_atoms[(size_t)rep * n + slot] = i;
     }
@@ -211,8 +214,9 @@ __device__ __forceinline__ void cell_append(u64* __restrict__ e, unsigned* cnt, 
     }
 }
 
-// One lane per atom: scan the 27 cells around it for partners with a larger index.  Both lists in one sweep.
-// rc2c / rc2x: (cutoff + skin)^2 of the contact / excluded-volume term (<= 0 disables that list).
+// One lane per binned atom, in cell order: scan the HALF shell of cells around it (the rest of its own cell and of
+// the x-row behind it, then the 4 rows of 3 cells "above"), so that every pair is met exactly once.  Both lists in
+// one sweep.  rc2c / rc2x: (cutoff + skin)^2 of the contact / excluded-volume term (<= 0 disables that list).
 template <class real> __global__ void cell_list_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos, real rc2c, real rc2x) {
     const int rep = blockIdx.y, n = C.natoms;
     if (!C.flag[2 * rep + 1]) return;
@@ -222,10 +226,11 @@ template <class real> __global__ void cell_list_kernel(DevSys<real> S, CellSys<r
     u64* cl = C.clist + (size_t)rep * C.ccap;
     u64* xl = C.xlist + (size_t)rep * C.xcap;
     const int nx = C.dims[4 * rep], ny = C.dims[4 * rep + 1], nz = C.dims[4 * rep + 2];
-    const int ntot = (n + 63) & ~63;   // whole waves: the appends are wave collectives
+    const int nb = cstart[C.dims[4 * rep + 3]];   // binned atoms
+    const int ntot = (nb + 63) & ~63;             // whole waves: the appends are wave collectives
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < ntot; k += gridDim.x * blockDim.x) {
-        const bool vi = k < n;
-        const int i = vi ? catoms[k] : 0;   // walk the atoms in cell order: the lanes of a wave scan the same few cells
+        const bool vi = k < nb;
+        const int i = vi ? catoms[k] : 0;
         const real xi = p[i], yi = p[n + i], zi = p[2 * n + i];
         const int si = vi && rc2c > (real)0 ? C.c_site[i] : -1;
         const int xi_cls = vi && rc2x > (real)0 ? C.x_cls[i] : -1;
@@ -235,25 +240,25 @@ template <class real> __global__ void cell_list_kernel(DevSys<real> S, CellSys<r
         Int4 part = {-1, -1, -1, -1};
         if (si >= 0) info_i = S.contact[0].info[si];
         if (xi_cls >= 0) part = S.excl[0].partners[C.x_slot[i]];
-        // the 27 neighbour cells as up to 9 contiguous runs of 3 cells in x
-        for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) {
+        for (int row = 0; row < 5; row++) {
+            // row 0: own row, from the entry after this atom to the end of cell x+1; rows 1..4: (dy,dz) = (1,0), (-1,1), (0,1), (1,1)
+            const int dy = row == 0 ? 0 : (row == 1 ? 1 : row - 3), dz = row < 2 ? 0 : 1;
             const int cz = c[2] + dz, cy = c[1] + dy;
-            const bool vrow = vi && (si >= 0 || xi_cls >= 0) && cz >= 0 && cz < nz && cy >= 0 && cy < ny;
+            const bool vrow = vi && (si >= 0 || xi_cls >= 0) && cz < nz && cy >= 0 && cy < ny;
             const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, nx - 1);
-            const int row = (cz * ny + cy) * nx;
-            int q = vrow ? cstart[row + x0] : 0;
-            const int qe = vrow ? cstart[row + x1 + 1] : 0;
+            const int base = (cz * ny + cy) * nx;
+            int q = vrow ? (row == 0 ? k + 1 : cstart[base + x0]) : 0;
+            const int qe = vrow ? cstart[base + x1 + 1] : 0;
             while (__ballot(q < qe)) {
                 const bool vq = q < qe;
                 const int j = vq ? catoms[q] : i;
                 q++;
                 const real r2 = dist2(xi - p[j], yi - p[n + j], zi - p[2 * n + j]);
-                // contact: site pairs in increasing site order
                 bool pc = false;
                 u64 ec = 0;
                 if (vq && si >= 0 && r2 < rc2c) {
                     const int sj = C.c_site[j];
-                    if (sj > si) {
+                    if (sj >= 0) {
                         const ContactD<real>& d = S.contact[0];
                         const int info_j = d.info[sj], dres = (info_j & 0xffff) - (info_i & 0xffff);
                         const bool in_rho = dres >= 2 || dres <= -2;
@@ -264,8 +269,7 @@ template <class real> __global__ void cell_list_kernel(DevSys<real> S, CellSys<r
                     }
                 }
                 cell_append(cl, &C.counts[2 * rep], C.ccap, C.status, pc, ec);
-                // excluded volume: same class, larger atom index, not a bonded partner
-                const bool px = vq && xi_cls >= 0 && j > i && r2 < rc2x && C.x_cls[j] == xi_cls &&
+                const bool px = vq && xi_cls >= 0 && r2 < rc2x && C.x_cls[j] == xi_cls &&
                                 part.x != j && part.y != j && part.z != j && part.w != j;
                 cell_append(xl, &C.counts[2 * rep + 1], C.xcap, C.status, px, (u64)(unsigned)i | ((u64)(unsigned)j << 32));
             }
@@ -358,6 +362,15 @@ template <bool ENERGY, class real> __global__ void cell_bonded_kernel(DevSys<rea
 }
 
 // ------------------------------------------------------------------ outputs, virtual sites, integrator
+template <class real> __global__ void cell_vsite_kernel(DevSys<real> S, real* __restrict__ pos) {
+    const int n = S.natoms;
+    real* p = pos + (size_t)blockIdx.y * 3 * n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S.nvs; i += gridDim.x * blockDim.x) {
+        const Int4 v = S.vs[i];
+        const real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
+        for (int k = 0; k < 3; k++) p[k * n + v.x] = w0 * p[k * n + v.y] + w1 * p[k * n + v.z] + w2 * p[k * n + v.w];
+    }
+}
 template <class real> __global__ void cell_redistribute_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos) {
     const int rep = blockIdx.y;
     const Lds<real> L = cell_view(S, C, pos, rep);

@@ -123,7 +123,8 @@ public:
     void compute_virtual_sites() override {
         HIP_TRY(hipSetDevice(device_));
         cell_stale_ = true;
-        hipLaunchKernelGGL(awsem_vsite_kernel<real>, dim3(nrep_), dim3(64), 0, stream_, dsys_, pos_);
+        if (cell_mode_) hipLaunchKernelGGL(cell_vsite_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, pos_);
+        else hipLaunchKernelGGL(awsem_vsite_kernel<real>, dim3(nrep_), dim3(64), 0, stream_, dsys_, pos_);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream_));
     }
@@ -842,14 +843,14 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
     const real rc2c = rc2(cell_rc_contact_), rc2x = rc2(cell_rc_excl_);
     HIP_TRY(hipEventRecord(ev0_, stream_));
     for (int s = 0; s < nsteps; s++) {
-        hipLaunchKernelGGL(awsem_vsite_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, pos_);
+        hipLaunchKernelGGL(cell_vsite_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, pos_);
         cell_refresh(cell_, rc2c, rc2x);
         cell_forces_pass(false, 0xffffffffu);
         hipLaunchKernelGGL(cell_redistribute_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, cell_, pos_);
         hipLaunchKernelGGL(cell_integrate_kernel<real>, cell_grid(dsys_.nmassive), dim3(256), 0, stream_, dsys_, cell_, pos_, vel_, dT_, dt, friction,
                            (unsigned long long)seed, (long long)(step0 + s));
     }
-    hipLaunchKernelGGL(awsem_vsite_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, pos_);
+    hipLaunchKernelGGL(cell_vsite_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, pos_);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1_, stream_));
     timing_pending_ = true;
@@ -884,6 +885,7 @@ template <class real> int Engine<real>::cell_neighbors(int rep, int kind, int in
     for (unsigned k = 0; k < n; k++) {
         if (kind == AWSEM_LIST_CONTACT) out[k] = {(int)(ent[k] & 0xffffff), (int)((ent[k] >> 24) & 0xffffff)};
         else out[k] = {(int)(ent[k] & 0xffffffffu), (int)(ent[k] >> 32)};
+        if (out[k].first > out[k].second) std::swap(out[k].first, out[k].second);   // the half-shell scan meets a pair in either order
     }
     std::sort(out.begin(), out.end());
     for (unsigned k = 0; k < n && (int)k < capacity; k++) { pairs[2 * k] = out[k].first; pairs[2 * k + 1] = out[k].second; }
