@@ -1,0 +1,122 @@
+"""awsem_run / awsem_analyze on the MI355X engine, driven exactly like the reference's command-line tools
+(openawsem/scripts/mm_run.py, mm_analyze.py): a project folder, a user forces_setup.py written against the
+reference's module names (`from openawsem.functionTerms import *`), files out.
+
+awsem_analyze is pinned by the reference's golden energies (tests/data/<p>_energies.csv, kJ/mol -> info.dat prints
+kcal/mol with 2 decimals).  awsem_run has no reference fixture (trajectories depend on OpenMM's RNG): its outputs are
+checked for presence, shape and physical sanity ("parity unpinned").
+"""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from openawsem_amd import data_path, dcd
+from tests.common import COLUMNS, GOLDEN, golden_system
+
+pytestmark = pytest.mark.gpu
+
+# the reference test's force list (tests/test_energies.py:56-75) as a user forces file in the reference's own idiom
+FORCES_SETUP = '''
+from openawsem.functionTerms import *
+from openawsem.helperFunctions.myFunctions import *
+
+try:
+    from openmm import Force
+    from openmm.unit import angstrom, Quantity
+except ModuleNotFoundError:
+    from simtk.openmm import Force
+    from simtk.unit import angstrom, Quantity
+from typing import List
+from openawsem.openAWSEM import OpenMMAWSEMSystem
+
+
+def set_up_forces(oa: OpenMMAWSEMSystem, computeQ: bool = False, submode: int = -1, contactParameterLocation: str = ".",
+                  membrane_center: Quantity = -0*angstrom) -> List[Force]:
+    forces = [
+        basicTerms.con_term(oa),
+        basicTerms.chain_term(oa),
+        basicTerms.chi_term(oa),
+        basicTerms.excl_term(oa, periodic=False),
+        basicTerms.rama_term(oa),
+        basicTerms.rama_proline_term(oa),
+        basicTerms.rama_ssweight_term(oa, k_rama_ssweight=2*8.368, ssweight_file="ssweight_for_rama"),
+        contactTerms.contact_term(oa),
+        hydrogenBondTerms.beta_term_1(oa),
+        hydrogenBondTerms.beta_term_2(oa),
+        hydrogenBondTerms.beta_term_3(oa),
+        hydrogenBondTerms.helical_term(oa),
+        hydrogenBondTerms.pap_term_1(oa),
+        hydrogenBondTerms.pap_term_2(oa),
+        templateTerms.fragment_memory_term(oa, frag_file_list_file="./single_frags.mem", npy_frag_table="./single_frags.npy", UseSavedFragTable=False),
+        debyeHuckelTerms.debye_huckel_term(oa, chargeFile="charge.txt"),
+    ]
+    return forces
+'''
+
+
+def _golden_project(tmp_path, protein):
+    d = tmp_path / protein
+    d.mkdir()
+    shutil.copy(os.path.join(GOLDEN, f"{protein}-openmmawsem.pdb"), d / f"{protein}-openmmawsem.pdb")
+    shutil.copy(os.path.join(GOLDEN, f"{protein}-crystal_structure.fasta"), d / "crystal_structure.fasta")
+    shutil.copy(os.path.join(GOLDEN, f"{protein}-crystal_structure.pdb"), d / "crystal_structure.pdb")
+    shutil.copy(os.path.join(GOLDEN, f"{protein}-movie.dcd"), d / "movie.dcd")
+    shutil.copy(os.path.join(GOLDEN, f"{protein}-single_frags.mem"), d / "single_frags.mem")
+    shutil.copy(os.path.join(GOLDEN, f"{protein}-charge.txt"), d / "charge.txt")
+    shutil.copy(os.path.join(GOLDEN, f"{protein}-ssweight"), d / "ssweight_for_rama")    # no file named "ssweight": pap terms see zeros, as in the reference test
+    for f in os.listdir(GOLDEN):
+        if f.startswith(protein + "_") and f.endswith(".gro"):
+            shutil.copy(os.path.join(GOLDEN, f), d / f)
+    (d / "forces_setup.py").write_text(FORCES_SETUP)
+    return d
+
+
+@pytest.mark.parametrize("protein", ["1ubq", "1brs"])
+def test_awsem_analyze_reproduces_golden_energies(protein, tmp_path, monkeypatch):
+    from openawsem_amd.scripts import mm_analyze
+    d = _golden_project(tmp_path, protein)
+    monkeypatch.chdir(d)
+    out = mm_analyze.main([protein, "-t", "movie.dcd", "-f", "forces_setup.py", "--noQ", "-p", "Reference"])
+    rows = [ln.split() for ln in open(out).read().strip().split("\n")]
+    header, data = rows[0], np.array(rows[1:], dtype=float)
+    assert header[:3] == ["Steps", "Q", "Rg"] and len(data) == 12
+    _, _, golden = golden_system(protein)
+    for c in COLUMNS:
+        col = header.index(c)
+        assert np.abs(data[:, col] - golden[c] / 4.184).max() <= 0.0051, c      # 2 printed decimals, kcal/mol
+    total = sum(golden[c] for c in COLUMNS)
+    dh = data[:, header.index("Debye_huckel")]
+    assert np.abs(data[:, header.index("Total")] - (total / 4.184 + dh)).max() <= 0.05
+
+
+def test_awsem_run_anneals_an_ensemble_and_writes_the_reference_files(tmp_path, monkeypatch):
+    from openawsem_amd.scripts import mm_run
+    src = data_path.data / "1r69"
+    d = tmp_path / "1r69"
+    shutil.copytree(src, d, ignore=shutil.ignore_patterns("fraglib", "frags.mem"))
+    shutil.copy(d / "1r69.fasta", d / "crystal_structure.fasta")
+    seq = "".join(ln.strip() for ln in open(d / "1r69.fasta") if not ln.startswith(">"))
+    # charge.txt as awsem_create writes it (mm_create_project.py: one "index charge" line per residue)
+    (d / "charge.txt").write_text("".join(f"{i} {1.0 if a in 'RK' else (-1.0 if a in 'DE' else 0.0)}\n" for i, a in enumerate(seq)))
+    monkeypatch.chdir(d)
+    out = tmp_path / "run0"
+    sim = mm_run.main(["1r69", "--to", str(out), "-s", "2000", "--tempStart", "600", "--tempEnd", "300", "--replicas", "8", "--seed", "7",
+                       "-f", os.path.join(os.path.dirname(mm_run.__file__), "forces_setup.py")])
+    for f in ("native.pdb", "movie.dcd", "output.log", "checkpnt.chk", "time.dat", "forces_setup.py", "ensemble_final.npz"):
+        assert (out / f).exists(), f
+    movie = dcd.load_dcd_nm(str(out / "movie.dcd"))
+    assert movie.shape == (2 + 400, 368, 3) and np.isfinite(movie).all()      # input + minimised + one frame per stage
+    log = np.loadtxt(out / "output.log", delimiter=",", skiprows=1)
+    assert log.shape == (400, 3) and log[-1, 0] == 2000
+    assert 150 < log[-20:, 2].mean() < 500                                     # kinetic temperature follows the schedule
+    assert log[0, 1] < 0 or log[:, 1].min() < log[0, 1]                        # minimised / annealed below the start energy
+    with np.load(out / "ensemble_final.npz") as z:
+        assert z["energies"].shape == (8,) and np.isfinite(z["energies"]).all()
+        assert np.abs(z["positions"][0] - z["positions"][1]).max() > 1e-3      # replicas are independent trajectories
+    # restart from the checkpoint the run left
+    monkeypatch.chdir(d)
+    sim2 = mm_run.main(["1r69", "--to", str(tmp_path / "run1"), "-s", "400", "-m", "0", "--tempStart", "300", "--replicas", "8",
+                        "--fromCheckPoint", str(out / "checkpnt.chk"), "-f", os.path.join(os.path.dirname(mm_run.__file__), "forces_setup.py")])
+    assert sim2.currentStep == 2000 + 400
