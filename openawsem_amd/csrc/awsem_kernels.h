@@ -36,8 +36,9 @@ struct AwsemProf { long long last, acc[10]; };
 template <class real> struct M;
 template <> struct M<float> {
     static __device__ __forceinline__ float exp(float x) { return __expf(x); }
-    static __device__ __forceinline__ float rsqrt(float x) { return rsqrtf(x); }
-    static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
+    // raw v_rsq_f32 / v_sqrt_f32 (1 ulp): the arguments are squared distances of distinct atoms, never denormal
+    static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
     static __device__ __forceinline__ float floor(float x) { return floorf(x); }
     static __device__ __forceinline__ float log(float x) { return __logf(x); }
@@ -54,13 +55,16 @@ template <> struct M<double> {
     static __device__ __forceinline__ void sincos2pi(double u, double* s, double* c) { *s = sinpi(2.0 * u); *c = cospi(2.0 * u); }
 };
 
-// value * 2^32 as a two's complement 64-bit integer.  fp32: floor + fraction split (5 VALU ops, exact for |v| < 2^31).
-__device__ __forceinline__ u64 to_fixed(float v) {
-    float fl = floorf(v);
-    int hi = (int)fl;
-    unsigned lo = (unsigned)((v - fl) * 4294967296.0f);
-    return ((u64)(unsigned)hi << 32) | (u64)lo;
+// value * 2^32 as a two's complement 64-bit integer.  fp32: adding the magic constant 1.5 * 2^52 in f64 leaves the
+// rounded (to nearest even) integer in the low mantissa bits; the constant's low word is zero, so only the high word
+// needs correcting.  to_fixed_scaled takes the value already multiplied by 2^32 (3 VALU ops: cvt, add, sub; callers
+// fold the scale into a factor they multiply by anyway).  Valid for |v| < 2^19 (5.2e5 kJ/mol/nm).
+__device__ __forceinline__ u64 to_fixed_scaled(float v32) {
+    const u64 b = (u64)__double_as_longlong((double)v32 + 6755399441055744.0);
+    return ((u64)((unsigned)(b >> 32) - 0x43380000u) << 32) | (u64)(unsigned)b;
 }
+__device__ __forceinline__ u64 to_fixed_scaled(double v32) { return (u64)(long long)v32; }
+__device__ __forceinline__ u64 to_fixed(float v) { return to_fixed_scaled(v * 4294967296.0f); }
 __device__ __forceinline__ u64 to_fixed(double v) { return (u64)(long long)(v * AWSEM_FIXED_SCALE); }
 __device__ __forceinline__ double fixed_to_double(u64 u) { return (double)(long long)u * (1.0 / AWSEM_FIXED_SCALE); }
 
@@ -80,6 +84,8 @@ template <class real> struct Lds {
     unsigned* lists;         // GLOBAL: this replica's pair-list entries
 };
 
+// ds_sub_u64 / global_atomic_sub_x2 (HIP's atomicSub negates and adds: two more VALU ops per component)
+__device__ __forceinline__ void fixed_sub(u64* p, u64 v) { (void)__hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class real> __device__ __forceinline__ void add_force(const Lds<real>& L, int a, real x, real y, real z) {
     atomicAdd(&L.fx[a], to_fixed(x));
     atomicAdd(&L.fy[a], to_fixed(y));
@@ -88,9 +94,10 @@ template <class real> __device__ __forceinline__ void add_force(const Lds<real>&
 // force of a pair potential: d = x_i - x_j, s = -dE/dr / r
 template <class real> __device__ __forceinline__ void pair_force(const Lds<real>& L, int i, int j, real dx, real dy, real dz, real s) {
     // one fixed-point conversion per component: +F on i (ds_add_u64), -F on j (ds_sub_u64)
-    const u64 X = to_fixed(s * dx), Y = to_fixed(s * dy), Z = to_fixed(s * dz);
+    const real t = s * (real)AWSEM_FIXED_SCALE;
+    const u64 X = to_fixed_scaled(t * dx), Y = to_fixed_scaled(t * dy), Z = to_fixed_scaled(t * dz);
     atomicAdd(&L.fx[i], X); atomicAdd(&L.fy[i], Y); atomicAdd(&L.fz[i], Z);
-    atomicSub(&L.fx[j], X); atomicSub(&L.fy[j], Y); atomicSub(&L.fz[j], Z);
+    fixed_sub(&L.fx[j], X); fixed_sub(&L.fy[j], Y); fixed_sub(&L.fz[j], Z);
 }
 
 // Energies are summed as 2^-32 fixed point from the first addition on (integer adds commute, so a sum does not
@@ -331,9 +338,9 @@ template <bool ENERGY, class real> __device__ void term_dh(const DhD<real>& d, c
 // coalesced store.  EVALUATE reads the list 64 entries per wave iteration with every lane busy, and books both
 // sides of the pair with fixed-point LDS atomics (conflict-light thanks to the diagonal order).  The evaluators
 // re-apply the exact cutoff of the reference, so the result does not depend on when a list was built.
-template <class real> __device__ __forceinline__ real dist2(real dx, real dy, real dz) {
-    return __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));   // fixed evaluation order: the pair set is bit-exact
-}
+// fixed evaluation order, fma in the handle's own precision (v_fma_f32 / v_fma_f64): the pair set is bit-exact
+__device__ __forceinline__ float dist2(float dx, float dy, float dz) { return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)); }
+__device__ __forceinline__ double dist2(double dx, double dy, double dz) { return __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx)); }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ void list_append(unsigned* __restrict__ e, unsigned* cnt, int cap, int* status, bool pass, unsigned entry) {
