@@ -355,7 +355,7 @@ template <bool ENERGY, class real> __global__ void cell_bonded_kernel(DevSys<rea
     case CJ_CHI: { ChiD<real> d = S.chi[job.term]; if (!AWSEM_ON(d)) return; d.atoms += f; d.n = min(256, d.n - f); term_chi<ENERGY>(d, L); } break;
     case CJ_RAMA: { RamaD<real> d = S.rama[job.term]; if (!AWSEM_ON(d)) return; d.atoms += f; d.bw += (size_t)f * d.nwell; d.n = min(256, d.n - f); term_rama<ENERGY>(d, L); } break;
     case CJ_HELICAL: { HelicalD<real> d = S.helical[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f); term_helical<ENERGY>(d, L); } break;
-    case CJ_FM: { FmD<real> d = S.fm[job.term]; if (!AWSEM_ON(d)) return; d.pairs += 2 * (size_t)f; d.table2 += (size_t)f * (d.ntab - 1); d.n = min(256, d.n - f); term_fm<ENERGY>(d, L); } break;
+    case CJ_FM: { FmD<real> d = S.fm[job.term]; if (!AWSEM_ON(d)) return; d.pairs2 += 2 * (size_t)f; d.table2 += (size_t)f * (d.ntab - 1); d.n = min(256, d.n - f); term_fm<ENERGY, false>(d, L); } break;
     case CJ_MEMB: { MembD<real> d = S.memb[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f); term_memb<ENERGY>(d, L); } break;
     case CJ_DH: { DhD<real> d = S.dh[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f); term_dh<ENERGY>(d, L); } break;
     }

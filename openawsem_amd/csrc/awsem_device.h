@@ -93,7 +93,8 @@ template <class real> struct PapD {
 };
 template <class real> struct HelicalD { int group, n; const HelicalItem<real>* items; real r_ON, r_OH, inv_sNO2, inv_sHO2; };
 // table2[b][i] = (t[b][i], t[b][i+1]) for i < ntab-1: the two interpolation nodes of a bin in one aligned load
-template <class real> struct FmD { int group, n, ntab; const int* pairs; const real2_t<real>* table2; real k, dr, inv_dr; };
+// pairs[b] = atom_i | atom_j << 16 on the replica-resident path (atoms < 65536); pairs2 = (atom_i, atom_j) for the cell path
+template <class real> struct FmD { int group, n, ntab; const unsigned* pairs; const int* pairs2; const real2_t<real>* table2; real k, dr, inv_dr; };
 template <class real> struct MembD { int group, n; const MembItem<real>* items; real k, k_m2, z_m, center; };
 template <class real> struct DhD { int group, n; const DhItem<real>* items; real k, inv_lam; };
 

@@ -544,7 +544,11 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             std::vector<real2_t<real>> t2((size_t)nb * (h.ntab - 1));
             for (int b = 0; b < nb; b++) for (int i = 0; i + 1 < h.ntab; i++)
                 t2[(size_t)b * (h.ntab - 1) + i] = real2_t<real>{(real)h.table[(size_t)perm[b] * h.ntab + i], (real)h.table[(size_t)perm[b] * h.ntab + i + 1]};
-            D.push_back(FmD<real>{h.group, nb, h.ntab, upload(permuted(h.pairs, perm, 2)), upload(t2), (real)h.k, (real)h.dr, (real)(1.0 / h.dr)});
+            const std::vector<int> pp = permuted(h.pairs, perm, 2);
+            std::vector<unsigned> packed(nb, 0u);
+            if (natoms_ <= 65535) for (int b = 0; b < nb; b++) packed[b] = (unsigned)pp[2 * b] | ((unsigned)pp[2 * b + 1] << 16);
+            if ((size_t)nb * (h.ntab - 1) >= (1ull << 31)) throw std::string("fragment memory: table too large (nbonds x ntab must stay below 2^31)");
+            D.push_back(FmD<real>{h.group, nb, h.ntab, upload(packed), upload(pp), upload(t2), (real)h.k, (real)h.dr, (real)(1.0 / h.dr)});
         }
         if (D.size() > AWSEM_MAX_FM) throw std::string("too many fm terms: at most " + std::to_string(AWSEM_MAX_FM) + " per system");
         S.n_fm = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.fm[t] = D[t];

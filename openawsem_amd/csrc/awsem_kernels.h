@@ -248,57 +248,56 @@ template <bool ENERGY, class real> __device__ void term_helical(const HelicalD<r
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-// Fragment memory: per bond two neighbouring floats of an L2-resident table row.  Four bonds are kept in flight per
-// thread so that the dependent chain (pair indices -> LDS coordinates -> table gather) overlaps across bonds.
-template <bool ENERGY, class real> __device__ void term_fm(const FmD<real>& d, const Lds<real>& L, int rot = 0) {
-    Energy e;
-    constexpr int U = 4;
-    const int stride = blockDim.x;
-#ifdef AWSEM_EXP_FM_NOATOMIC
-    real dummy = 0;
-#endif
-    for (int b0 = rot_tid(rot); b0 < d.n; b0 += U * stride) {
-        int ai[U], aj[U], i1[U];
-        real dx[U], dy[U], dz[U], ir[U], r[U], v1[U], v2[U];
-        bool ok[U];
+// Fragment memory: per bond two neighbouring floats of an L2-resident table row.  U bonds are kept in flight per
+// thread so that the dependent chain (pair word -> LDS coordinates -> table gather) overlaps across bonds; all index
+// arithmetic is unsigned 32-bit so that the loads use the scalar-base + 32-bit-offset addressing form.
+template <bool ENERGY, int U, bool PACKED, class real> __device__ __forceinline__ void fm_body(const FmD<real>& d, const Lds<real>& L, unsigned b0, unsigned stride, Energy& e) {
+    unsigned ai[U], aj[U], i1[U], bb[U];
+    real r[U], ir[U];
+    real2_t<real> v[U];
+    const unsigned nrow = (unsigned)d.ntab - 1u, n = (unsigned)d.n;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            int b = b0 + u * stride;
-            ok[u] = b < d.n;
-            b = ok[u] ? b : b0;
-            ai[u] = d.pairs[2 * b]; aj[u] = d.pairs[2 * b + 1];
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            int b = ok[u] ? b0 + u * stride : b0;
-            dx[u] = L.px[ai[u]] - L.px[aj[u]]; dy[u] = L.py[ai[u]] - L.py[aj[u]]; dz[u] = L.pz[ai[u]] - L.pz[aj[u]];
-            real r2 = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
-            ir[u] = M<real>::rsqrt(r2); r[u] = r2 * ir[u];
-            real fi = M<real>::floor(r[u] * d.inv_dr);
-            fi -= (r[u] - fi * d.dr < (real)0) ? (real)1 : (real)0;   // r*inv_dr may round up across a bin edge: keep r >= fi*dr
-            i1[u] = fi > (real)(d.ntab - 2) ? d.ntab - 2 : (int)fi;
-#ifdef AWSEM_EXP_FM_NOGATHER
-            v1[u] = r[u]; v2[u] = r[u] + (real)1;
-#else
-            const real2_t<real> v = d.table2[(size_t)b * (d.ntab - 1) + i1[u]];   // (t[i], t[i+1]) in one load
-            v1[u] = v.x; v2[u] = v.y;
-#endif
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (!ok[u]) continue;
-            real slope = (v2[u] - v1[u]) * d.inv_dr;
-            if (ENERGY) e += (double)(-d.k * (v1[u] + slope * (r[u] - d.dr * (real)i1[u])));
-#ifdef AWSEM_EXP_FM_NOATOMIC
-            dummy += d.k * slope * ir[u] * (dx[u] + dy[u] + dz[u]);
-#else
-            pair_force(L, ai[u], aj[u], dx[u], dy[u], dz[u], d.k * slope * ir[u]);
-#endif
+    for (int u = 0; u < U; u++) {
+        bb[u] = b0 + u * stride;
+        const unsigned b = bb[u] < n ? bb[u] : b0;   // lanes past the end re-read their first bond and skip the bookkeeping
+        if (PACKED) {
+            const unsigned w = d.pairs[b];           // atom_i | atom_j << 16
+            ai[u] = w & 0xffffu; aj[u] = w >> 16;
+        } else {
+            ai[u] = (unsigned)d.pairs2[2 * b]; aj[u] = (unsigned)d.pairs2[2 * b + 1];
         }
     }
-#ifdef AWSEM_EXP_FM_NOATOMIC
-    if (dummy == (real)123.456) L.fx[0] = 1;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const unsigned b = bb[u] < n ? bb[u] : b0;
+        const real dx = L.px[ai[u]] - L.px[aj[u]], dy = L.py[ai[u]] - L.py[aj[u]], dz = L.pz[ai[u]] - L.pz[aj[u]];
+        const real r2 = dx * dx + dy * dy + dz * dz;
+        ir[u] = M<real>::rsqrt(r2); r[u] = r2 * ir[u];
+        const unsigned bin = (unsigned)(int)(r[u] * d.inv_dr);   // r >= 0: truncation is floor
+        i1[u] = bin < nrow - 1u ? bin : nrow - 1u;
+#ifdef AWSEM_EXP_FM_NOGATHER
+        v[u].x = r[u]; v[u].y = r[u] + (real)1;
+#else
+        v[u] = d.table2[b * nrow + i1[u]];                       // (t[i], t[i+1]) in one load
 #endif
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        if (bb[u] >= n) continue;
+        const real slope = (v[u].y - v[u].x) * d.inv_dr;
+        if (ENERGY) e += (double)(-d.k * (v[u].x + slope * (r[u] - d.dr * (real)i1[u])));
+#ifdef AWSEM_EXP_FM_NOATOMIC
+        if (slope * ir[u] == (real)123.456) L.fx[0] = 1;
+#else
+        pair_force(L, ai[u], aj[u], L.px[ai[u]] - L.px[aj[u]], L.py[ai[u]] - L.py[aj[u]], L.pz[ai[u]] - L.pz[aj[u]], d.k * slope * ir[u]);
+#endif
+    }
+}
+template <bool ENERGY, bool PACKED = true, class real> __device__ void term_fm(const FmD<real>& d, const Lds<real>& L, int rot = 0) {
+    Energy e;
+    constexpr int U = 6;
+    const unsigned stride = blockDim.x, n = (unsigned)d.n;
+    for (unsigned b = (unsigned)rot_tid(rot); b < n; b += U * stride) fm_body<ENERGY, U, PACKED>(d, L, b, stride, e);
     flush_energy<ENERGY>(L, d.group, e);
 }
 
