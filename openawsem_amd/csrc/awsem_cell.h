@@ -51,15 +51,15 @@ template <class real> struct CellSys {
 __device__ __forceinline__ int ordered_int(float f) { int o = __float_as_int(f); return o >= 0 ? o : o ^ 0x7fffffff; }
 __device__ __forceinline__ float ordered_float(int o) { return __int_as_float(o >= 0 ? o : o ^ 0x7fffffff); }
 
-// Lds-shaped view of replica `rep` in global memory
-template <class real> __device__ inline Lds<real> cell_view(const DevSys<real>& S, const CellSys<real>& C, const real* pos, int rep) {
-    Lds<real> L;
+// View of replica `rep` in global memory (same API as the LDS views of awsem_kernels.h)
+template <class real> struct CellView : ViewCommon<real>, SoaOps<real> { typedef real real_t; };
+template <class real> __device__ inline CellView<real> cell_view(const DevSys<real>& S, const CellSys<real>& C, const real* pos, int rep) {
+    CellView<real> L;
     const size_t n = C.natoms;
     real* p = const_cast<real*>(pos) + (size_t)rep * 3 * n;
     L.px = p; L.py = p + n; L.pz = p + 2 * n;
     u64* f = C.f + (size_t)rep * 3 * n;
     L.fx = f; L.fy = f + n; L.fz = f + 2 * n;
-    L.vx = L.vy = L.vz = nullptr;
     const size_t so = (size_t)rep * C.nsites;
     L.rho = C.rho + so; L.drho = C.drho + so; L.rhov = C.rhov + so; L.alpha = C.alpha + so; L.dalpha = C.dalpha + so;
     L.gamma = nullptr;
@@ -69,7 +69,6 @@ template <class real> __device__ inline Lds<real> cell_view(const DevSys<real>& 
         L.satom = const_cast<int*>(d.atom);
     } else L.satom = nullptr;
     L.eg = C.eg + (size_t)rep * AWSEM_NGROUPS;
-    L.rx = L.ry = L.rz = nullptr;
     L.lcount = nullptr; L.flag = nullptr; L.lists = nullptr;
     return L;
 }
@@ -280,7 +279,7 @@ template <class real> __global__ void cell_list_kernel(DevSys<real> S, CellSys<r
 // ------------------------------------------------------------------ evaluation from the lists (grid (blocks, R))
 template <class real> __global__ void cell_density_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos) {
     const int rep = blockIdx.y;
-    const Lds<real> L = cell_view(S, C, pos, rep);
+    const CellView<real> L = cell_view(S, C, pos, rep);
     const ContactD<real>& d = S.contact[0];
     const u64* e = C.clist + (size_t)rep * C.ccap;
     const int count = (int)min((long long)C.counts[2 * rep], C.ccap), ntot = (count + 63) & ~63;
@@ -293,7 +292,7 @@ template <class real> __global__ void cell_density_kernel(DevSys<real> S, CellSy
 }
 template <bool ENERGY, class real> __global__ void cell_single_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos) {
     const int rep = blockIdx.y;
-    const Lds<real> L = cell_view(S, C, pos, rep);
+    const CellView<real> L = cell_view(S, C, pos, rep);
     const ContactD<real>& d = S.contact[0];
     Energy e;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.nsites; i += gridDim.x * blockDim.x) single_body<ENERGY>(d, L, i, L.satom[i], e);
@@ -301,7 +300,7 @@ template <bool ENERGY, class real> __global__ void cell_single_kernel(DevSys<rea
 }
 template <bool ENERGY, class real> __global__ void cell_pairs_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos) {
     const int rep = blockIdx.y;
-    const Lds<real> L = cell_view(S, C, pos, rep);
+    const CellView<real> L = cell_view(S, C, pos, rep);
     const ContactD<real>& d = S.contact[0];
     const u64* e = C.clist + (size_t)rep * C.ccap;
     const int count = (int)min((long long)C.counts[2 * rep], C.ccap), ntot = (count + 63) & ~63;
@@ -316,7 +315,7 @@ template <bool ENERGY, class real> __global__ void cell_pairs_kernel(DevSys<real
 }
 template <class real> __global__ void cell_chain_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos) {
     const int rep = blockIdx.y;
-    const Lds<real> L = cell_view(S, C, pos, rep);
+    const CellView<real> L = cell_view(S, C, pos, rep);
     const ContactD<real>& d = S.contact[0];
     const u64* e = C.clist + (size_t)rep * C.ccap;
     const int count = (int)min((long long)C.counts[2 * rep], C.ccap), ntot = (count + 63) & ~63;
@@ -329,7 +328,7 @@ template <class real> __global__ void cell_chain_kernel(DevSys<real> S, CellSys<
 }
 template <bool ENERGY, class real> __global__ void cell_excl_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos) {
     const int rep = blockIdx.y;
-    const Lds<real> L = cell_view(S, C, pos, rep);
+    const CellView<real> L = cell_view(S, C, pos, rep);
     const ExclD<real>& d = S.excl[0];
     const u64* e = C.xlist + (size_t)rep * C.xcap;
     const int count = (int)min((long long)C.counts[2 * rep + 1], C.xcap), ntot = (count + 63) & ~63;
@@ -347,7 +346,7 @@ struct CellJob { int kind, term, first; };
 enum { CJ_HARM, CJ_CHI, CJ_RAMA, CJ_HELICAL, CJ_FM, CJ_MEMB, CJ_DH };
 template <bool ENERGY, class real> __global__ void cell_bonded_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos, const CellJob* __restrict__ jobs, unsigned mask) {
     const int rep = blockIdx.y;
-    const Lds<real> L = cell_view(S, C, pos, rep);
+    const CellView<real> L = cell_view(S, C, pos, rep);
     const CellJob job = jobs[blockIdx.x];
     const int f = job.first;
     switch (job.kind) {
@@ -373,15 +372,16 @@ template <class real> __global__ void cell_vsite_kernel(DevSys<real> S, real* __
 }
 template <class real> __global__ void cell_redistribute_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos) {
     const int rep = blockIdx.y;
-    const Lds<real> L = cell_view(S, C, pos, rep);
+    const CellView<real> L = cell_view(S, C, pos, rep);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S.nvs; i += gridDim.x * blockDim.x) {
         const Int4 v = S.vs[i];
-        const real fx = (real)fixed_to_double(L.fx[v.x]), fy = (real)fixed_to_double(L.fy[v.x]), fz = (real)fixed_to_double(L.fz[v.x]);
-        L.fx[v.x] = 0; L.fy[v.x] = 0; L.fz[v.x] = 0;   // only this lane touches the accumulators of its virtual site here
+        const R3<real> F = L.force(v.x);
+        const real fx = F.x, fy = F.y, fz = F.z;
+        L.zero_force(v.x);   // only this lane touches the accumulators of its virtual site here
         const real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
-        add_force(L, v.y, w0 * fx, w0 * fy, w0 * fz);
-        add_force(L, v.z, w1 * fx, w1 * fy, w1 * fz);
-        add_force(L, v.w, w2 * fx, w2 * fy, w2 * fz);
+        L.add_force(v.y, w0 * fx, w0 * fy, w0 * fz);
+        L.add_force(v.z, w1 * fx, w1 * fy, w1 * fz);
+        L.add_force(v.w, w2 * fx, w2 * fy, w2 * fz);
     }
 }
 template <class real> __global__ void cell_output_kernel(CellSys<real> C, double* __restrict__ f_out, double* __restrict__ e_out) {

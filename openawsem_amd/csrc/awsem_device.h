@@ -37,6 +37,9 @@ template <class real> struct HelicalItem { int o, n, h; real coef; };
 template <class real> struct DhItem { int i, j; real qq, pad; };
 template <class real> struct MembItem { int atom; real scale; };
 template <class real> struct alignas(16) MassiveItem { int atom; real inv_mass, sqrt_inv_mass, pad; };
+// the virtual sites a massive particle parents (-1 padded) and its weight in each: the step kernel gathers their forces
+#define AWSEM_MAX_GATHER 8
+template <class real> struct alignas(16) GatherItem { int vs[AWSEM_MAX_GATHER]; real w[AWSEM_MAX_GATHER]; };
 struct Int4 { int x, y, z, w; };
 template <class real> struct alignas(2 * sizeof(real)) real2_t { real x, y; };
 struct Int5 { int a[5]; };
@@ -106,7 +109,10 @@ template <class real> struct DevSys {
     const real* inv_mass;                 // natoms (0 for massless)
     const real* sqrt_inv_mass;
     const MassiveItem<real>* massive;     // the nmassive particles the integrator moves
+    const GatherItem<real>* gather;       // per massive particle (same order)
     int nmassive;
+    int nfixed;                           // massless particles that are not virtual sites (they never move)
+    const int* fixed;
     int n_harm, n_chi, n_rama, n_excl, n_contact, n_beta, n_pap, n_helical, n_fm, n_memb, n_dh;
     HarmD<real> harm[AWSEM_MAX_HARM]; ChiD<real> chi[AWSEM_MAX_CHI]; RamaD<real> rama[AWSEM_MAX_RAMA];
     ExclD<real> excl[AWSEM_MAX_EXCL]; ContactD<real> contact[AWSEM_MAX_CONTACT]; BetaD<real> beta[AWSEM_MAX_BETA];

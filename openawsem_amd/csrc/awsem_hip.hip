@@ -353,6 +353,26 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         S.massive = upload(mv);
         S.nmassive = (int)mv.size();
         S.nvs = (int)H.vs_site.size();
+        {   // gather table: which virtual sites hand their force to each massive particle, and with which weight
+            std::vector<GatherItem<real>> gt(mv.size());
+            std::vector<int> slot_of(natoms_, -1), fill(mv.size(), 0), is_vs(natoms_, 0);
+            for (size_t k = 0; k < mv.size(); k++) { slot_of[mv[k].atom] = (int)k; for (int q = 0; q < AWSEM_MAX_GATHER; q++) { gt[k].vs[q] = -1; gt[k].w[q] = (real)0; } }
+            for (int i = 0; i < S.nvs; i++) {
+                is_vs[H.vs_site[i]] = 1;
+                for (int c = 0; c < 3; c++) {
+                    const int par = H.vs_par[3 * i + c];
+                    if (H.mass[par] <= 0) throw std::string("virtual sites: a parent particle must have a mass (sites of sites are not supported)");
+                    const int k = slot_of[par];
+                    if (fill[k] >= AWSEM_MAX_GATHER) throw std::string("virtual sites: more than 8 sites depend on one particle");
+                    gt[k].vs[fill[k]] = H.vs_site[i]; gt[k].w[fill[k]] = (real)H.vs_w[3 * i + c]; fill[k]++;
+                }
+            }
+            S.gather = upload(gt);
+            std::vector<int> fixed;
+            for (int i = 0; i < natoms_; i++) if (H.mass[i] <= 0 && !is_vs[i]) fixed.push_back(i);
+            S.nfixed = (int)fixed.size();
+            S.fixed = upload(fixed);
+        }
         const std::vector<int> perm = spread_order(S.nvs, 3, H.vs_par.data(), natoms_);   // force redistribution adds to the parents
         std::vector<Int4> vs(S.nvs);
         for (int i = 0; i < S.nvs; i++) { int o = perm[i]; vs[i] = Int4{H.vs_site[o], H.vs_par[3 * o], H.vs_par[3 * o + 1], H.vs_par[3 * o + 2]}; }

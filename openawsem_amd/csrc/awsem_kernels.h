@@ -1,14 +1,22 @@
 // awsem_kernels.h -- CDNA4 (gfx950) kernels of the replica-resident AWSEM path.
 //
-// Execution model: ONE WORKGROUP OWNS ONE REPLICA.  The replica's coordinates, velocities and int64 fixed-point
-// force accumulators live in LDS for the whole launch (a 1r69 replica is ~20 KB, so 4-8 replicas are resident per
-// CU); index arrays and parameter tables are shared by every replica and stay L2-resident.  A launch evaluates
-// energies/forces once (awsem_eval_kernel) or advances `nsteps` Langevin steps without touching HBM in between
-// (awsem_step_kernel).  Nothing here is a dense contraction, so no MFMA: the work is distance screens,
-// transcendental switching functions and LDS atomics; wave-uniform "row" operands are LDS broadcasts.
+// Execution model: ONE WORKGROUP OWNS ONE REPLICA.  The replica's coordinates, velocities and fixed-point force
+// accumulators live in LDS for the whole launch (a 1r69 replica is ~36 KB, so 4 replicas are resident per CU); index
+// arrays and parameter tables are shared by every replica and stay L2-resident.  A launch evaluates energies/forces
+// once (awsem_eval_kernel) or advances `nsteps` Langevin steps without touching HBM in between (awsem_step_kernel).
+// Nothing here is a dense contraction, so no MFMA: the work is distance screens, transcendental switching functions
+// and LDS atomics.
 //
-// Determinism: every force, energy and density contribution is converted to 2^-32 fixed point and accumulated
-// with integer LDS atomics (ds_add_u64), so results are bit-identical from run to run regardless of wave order.
+// Every term body is written against a *view* `V` of one replica (positions in, forces out):
+//   Lds<float>   production: float4 positions (one ds_read_b128 per gathered atom) and per-atom 16-byte force
+//                records {xy: two Q19.12 components packed in one 64-bit word, z: Q19.12}, so a force lands with one
+//                ds_add_u64 + one ds_add_u32 per atom (half the LDS bytes of three 64-bit accumulators)
+//   Lds<double>  check mode: SoA doubles and three Q31.32 accumulators per atom
+//   CellView     awsem_cell.h: the same API over global memory for systems that do not fit LDS
+//
+// Determinism: every force, energy and density contribution is converted to fixed point *before* it is added and
+// accumulated with integer atomics (integer adds commute), so results are bit-identical from run to run regardless
+// of wave order; a pair term adds +F to one atom and -F to the other bit for bit (Newton's third law is exact).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "awsem_device.h"
@@ -55,10 +63,9 @@ template <> struct M<double> {
     static __device__ __forceinline__ void sincos2pi(double u, double* s, double* c) { *s = sinpi(2.0 * u); *c = cospi(2.0 * u); }
 };
 
-// value * 2^32 as a two's complement 64-bit integer.  fp32: adding the magic constant 1.5 * 2^52 in f64 leaves the
-// rounded (to nearest even) integer in the low mantissa bits; the constant's low word is zero, so only the high word
-// needs correcting.  to_fixed_scaled takes the value already multiplied by 2^32 (3 VALU ops: cvt, add, sub; callers
-// fold the scale into a factor they multiply by anyway).  Valid for |v| < 2^19 (5.2e5 kJ/mol/nm).
+// value * 2^32 as a two's complement 64-bit integer (energies, densities, fp64 forces).  fp32: adding the magic
+// constant 1.5 * 2^52 in f64 leaves the rounded (to nearest even) integer in the low mantissa bits; the constant's low
+// word is zero, so only the high word needs correcting (cvt, add, sub after the scaling multiply).  |v| < 2^19.
 __device__ __forceinline__ u64 to_fixed_scaled(float v32) {
     const u64 b = (u64)__double_as_longlong((double)v32 + 6755399441055744.0);
     return ((u64)((unsigned)(b >> 32) - 0x43380000u) << 32) | (u64)(unsigned)b;
@@ -67,38 +74,107 @@ __device__ __forceinline__ u64 to_fixed_scaled(double v32) { return (u64)(long l
 __device__ __forceinline__ u64 to_fixed(float v) { return to_fixed_scaled(v * 4294967296.0f); }
 __device__ __forceinline__ u64 to_fixed(double v) { return (u64)(long long)(v * AWSEM_FIXED_SCALE); }
 __device__ __forceinline__ double fixed_to_double(u64 u) { return (double)(long long)u * (1.0 / AWSEM_FIXED_SCALE); }
+// 2^-32 fixed point -> float without the f64 detour: the integer part and the fraction convert separately
+__device__ __forceinline__ float fixed_to_real(u64 u, float) { return (float)(int)(u >> 32) + (float)(unsigned)u * 2.3283064365386963e-10f; }
+__device__ __forceinline__ double fixed_to_real(u64 u, double) { return fixed_to_double(u); }
 
-template <class real> struct Lds {
-    real *px, *py, *pz;      // positions (SoA)
-    u64 *fx, *fy, *fz;       // fixed-point force accumulators
-    real *vx, *vy, *vz;      // velocities (step kernel only)
-    u64 *rho, *drho;         // contact density and dE/drho accumulators (fixed point)
-    real *rhov;              // per-site water switch s_i = sig(-2 eta_s (rho_i - rho0))
+// ds_add / ds_sub (LDS views) or global_atomic_add / _sub (cell view), result unused
+__device__ __forceinline__ void fixed_add(u64* p, u64 v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fixed_sub(u64* p, u64 v) { (void)__hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fixed_add(int* p, int v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fixed_sub(int* p, int v) { (void)__hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <class real> struct R3 { real x, y, z; };
+template <class real> __device__ __forceinline__ R3<real> operator-(const R3<real>& a, const R3<real>& b) { return R3<real>{a.x - b.x, a.y - b.y, a.z - b.z}; }
+// fixed evaluation order, fma in the handle's own precision (v_fma_f32 / v_fma_f64): the pair set is bit-exact
+__device__ __forceinline__ float dist2(float dx, float dy, float dz) { return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)); }
+__device__ __forceinline__ double dist2(double dx, double dy, double dz) { return __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx)); }
+template <class real> __device__ __forceinline__ real dist2(const R3<real>& d) { return dist2(d.x, d.y, d.z); }
+
+// ------------------------------------------------------------------ views of one replica
+// Members every view carries besides coordinates and forces (the contact passes' scratch, energies, pair lists).
+template <class real> struct ViewCommon {
+    u64 *rho, *drho;         // contact density and dE/drho accumulators (2^-32 fixed point)
+    real* rhov;              // per-site water switch s_i = sig(-2 eta_s (rho_i - rho0))
     real *alpha, *dalpha;    // z-dependent membrane switch
-    real *gamma;             // staged gamma tables of the current contact term (env-major)
+    real* gamma;             // gamma tables of the current contact term (env-major)
     u64* eg;                 // per-group energies (fixed point)
-    real *rx, *ry, *rz;      // positions at the last pair-list build (step kernel only)
     int* satom;              // contact site -> atom, [contact term][max_contact_sites]
     unsigned* lcount;        // pair-list entry counts, one per list
-    unsigned* flag;          // [0] = largest squared displacement since the last list build (float bits)
+    unsigned* flag;          // [2]: largest squared displacement since the last list build (float bits), double buffered
     unsigned* lists;         // GLOBAL: this replica's pair-list entries
 };
 
-// ds_sub_u64 / global_atomic_sub_x2 (HIP's atomicSub negates and adds: two more VALU ops per component)
-__device__ __forceinline__ void fixed_sub(u64* p, u64 v) { (void)__hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <class real> __device__ __forceinline__ void add_force(const Lds<real>& L, int a, real x, real y, real z) {
-    atomicAdd(&L.fx[a], to_fixed(x));
-    atomicAdd(&L.fy[a], to_fixed(y));
-    atomicAdd(&L.fz[a], to_fixed(z));
-}
-// force of a pair potential: d = x_i - x_j, s = -dE/dr / r
-template <class real> __device__ __forceinline__ void pair_force(const Lds<real>& L, int i, int j, real dx, real dy, real dz, real s) {
-    // one fixed-point conversion per component: +F on i (ds_add_u64), -F on j (ds_sub_u64)
-    const real t = s * (real)AWSEM_FIXED_SCALE;
-    const u64 X = to_fixed_scaled(t * dx), Y = to_fixed_scaled(t * dy), Z = to_fixed_scaled(t * dz);
-    atomicAdd(&L.fx[i], X); atomicAdd(&L.fy[i], Y); atomicAdd(&L.fz[i], Z);
-    fixed_sub(&L.fx[j], X); fixed_sub(&L.fy[j], Y); fixed_sub(&L.fz[j], Z);
-}
+template <class real> struct Lds;
+
+// fp32 force accumulator: Q19.12 fixed point, x and y packed in one 64-bit word (x * 2^32 + sign-extended y; the
+// packed sums stay exact because integer addition commutes: y = low word, x = (sum - y) >> 32).
+#define AWSEM_F32_FORCE_SCALE 4096.0f
+struct alignas(16) FAcc32 { long long xy; int z; int pad; };
+__device__ __forceinline__ long long pack_xy(int X, int Y) { return ((long long)X << 32) + (long long)Y; }
+
+template <> struct Lds<float> : ViewCommon<float> {
+    typedef float real_t;
+    float4* p;       // positions (w unused)
+    FAcc32* f;       // force accumulators
+    float4* v;       // velocities (step kernel only)
+    float4* ref;     // positions at the last pair-list build (step kernel only)
+    __device__ __forceinline__ R3<float> pos(int a) const { const float4 q = p[a]; return R3<float>{q.x, q.y, q.z}; }
+    __device__ __forceinline__ void set_pos(int a, const R3<float>& r) const { p[a] = make_float4(r.x, r.y, r.z, 0.0f); }
+    __device__ __forceinline__ R3<float> vel(int a) const { const float4 q = v[a]; return R3<float>{q.x, q.y, q.z}; }
+    __device__ __forceinline__ void set_vel(int a, const R3<float>& r) const { v[a] = make_float4(r.x, r.y, r.z, 0.0f); }
+    __device__ __forceinline__ R3<float> refpos(int a) const { const float4 q = ref[a]; return R3<float>{q.x, q.y, q.z}; }
+    __device__ __forceinline__ void set_ref(int a, const R3<float>& r) const { ref[a] = make_float4(r.x, r.y, r.z, 0.0f); }
+    __device__ __forceinline__ void zero_force(int a) const { *(int4*)&f[a] = make_int4(0, 0, 0, 0); }
+    __device__ __forceinline__ R3<float> force(int a) const {
+        const int4 q = *(const int4*)&f[a];   // {xy.lo, xy.hi, z, pad}
+        const int y = q.x, x = q.y + (int)((unsigned)y >> 31);   // undo the borrow of a negative y
+        const float s = 1.0f / AWSEM_F32_FORCE_SCALE;
+        return R3<float>{(float)x * s, (float)y * s, (float)q.z * s};
+    }
+    __device__ __forceinline__ void add_force(int a, float x, float y, float z) const {
+        const float s = AWSEM_F32_FORCE_SCALE;
+        fixed_add((u64*)&f[a].xy, (u64)pack_xy(__float2int_rn(x * s), __float2int_rn(y * s)));
+        fixed_add(&f[a].z, __float2int_rn(z * s));
+    }
+    __device__ __forceinline__ void add_fz(int a, float z) const { fixed_add(&f[a].z, __float2int_rn(z * AWSEM_F32_FORCE_SCALE)); }
+    // force of a pair potential: d = x_i - x_j, s = -dE/dr / r; +F on i, the bit-identical -F on j
+    __device__ __forceinline__ void pair_force(int i, int j, float dx, float dy, float dz, float s) const {
+        const float t = s * AWSEM_F32_FORCE_SCALE;
+        const int Z = __float2int_rn(t * dz);
+        const u64 XY = (u64)pack_xy(__float2int_rn(t * dx), __float2int_rn(t * dy));
+        fixed_add((u64*)&f[i].xy, XY); fixed_add(&f[i].z, Z);
+        fixed_sub((u64*)&f[j].xy, XY); fixed_sub(&f[j].z, Z);
+    }
+};
+
+// SoA coordinates and three Q31.32 accumulators per atom: the fp64 check mode (in LDS) and the cell-list path (in HBM)
+template <class real> struct SoaOps {
+    real *px, *py, *pz;
+    u64 *fx, *fy, *fz;
+    __device__ __forceinline__ R3<real> pos(int a) const { return R3<real>{px[a], py[a], pz[a]}; }
+    __device__ __forceinline__ void set_pos(int a, const R3<real>& r) const { px[a] = r.x; py[a] = r.y; pz[a] = r.z; }
+    __device__ __forceinline__ void zero_force(int a) const { fx[a] = 0; fy[a] = 0; fz[a] = 0; }
+    __device__ __forceinline__ R3<real> force(int a) const { return R3<real>{fixed_to_real(fx[a], (real)0), fixed_to_real(fy[a], (real)0), fixed_to_real(fz[a], (real)0)}; }
+    __device__ __forceinline__ void add_force(int a, real x, real y, real z) const {
+        fixed_add(&fx[a], to_fixed(x)); fixed_add(&fy[a], to_fixed(y)); fixed_add(&fz[a], to_fixed(z));
+    }
+    __device__ __forceinline__ void add_fz(int a, real z) const { fixed_add(&fz[a], to_fixed(z)); }
+    __device__ __forceinline__ void pair_force(int i, int j, real dx, real dy, real dz, real s) const {
+        const real t = s * (real)AWSEM_FIXED_SCALE;
+        const u64 X = to_fixed_scaled(t * dx), Y = to_fixed_scaled(t * dy), Z = to_fixed_scaled(t * dz);
+        fixed_add(&fx[i], X); fixed_add(&fy[i], Y); fixed_add(&fz[i], Z);
+        fixed_sub(&fx[j], X); fixed_sub(&fy[j], Y); fixed_sub(&fz[j], Z);
+    }
+};
+template <> struct Lds<double> : ViewCommon<double>, SoaOps<double> {
+    typedef double real_t;
+    double *vx, *vy, *vz, *rx, *ry, *rz;
+    __device__ __forceinline__ R3<double> vel(int a) const { return R3<double>{vx[a], vy[a], vz[a]}; }
+    __device__ __forceinline__ void set_vel(int a, const R3<double>& r) const { vx[a] = r.x; vy[a] = r.y; vz[a] = r.z; }
+    __device__ __forceinline__ R3<double> refpos(int a) const { return R3<double>{rx[a], ry[a], rz[a]}; }
+    __device__ __forceinline__ void set_ref(int a, const R3<double>& r) const { rx[a] = r.x; ry[a] = r.y; rz[a] = r.z; }
+};
 
 // Energies are summed as 2^-32 fixed point from the first addition on (integer adds commute, so a sum does not
 // depend on the order in which a pair list happens to hold its entries): `Energy` is a per-lane accumulator.
@@ -106,11 +182,11 @@ struct Energy {
     u64 v = 0;
     __device__ __forceinline__ void operator+=(double x) { v += (u64)__double2ll_rn(x * AWSEM_FIXED_SCALE); }   // round to nearest: no bias over 10^4 terms
 };
-template <bool ENERGY, class real> __device__ __forceinline__ void flush_energy(const Lds<real>& L, int group, Energy& e) {
+template <bool ENERGY, class V> __device__ __forceinline__ void flush_energy(const V& L, int group, Energy& e) {
     if (ENERGY) {
         u64 s = e.v;
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-        if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(&L.eg[group], s);
+        if ((threadIdx.x & 63) == 0 && s != 0) fixed_add(&L.eg[group], s);
         e.v = 0;
     }
 }
@@ -135,25 +211,26 @@ struct Rotor {   // hands out starting waves: each job continues where the previ
 };
 
 // ------------------------------------------------------------------ bonded terms
-template <bool ENERGY, class real> __device__ void term_harmonic(const HarmD<real>& d, const Lds<real>& L, int rot = 0) {
+template <bool ENERGY, class V> __device__ void term_harmonic(const HarmD<typename V::real_t>& d, const V& L, int rot = 0) {
+    typedef typename V::real_t real;
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
-        HarmItem<real> it = d.items[b];
-        real dx = L.px[it.i] - L.px[it.j], dy = L.py[it.i] - L.py[it.j], dz = L.pz[it.i] - L.pz[it.j];
-        real r2 = dx * dx + dy * dy + dz * dz, ir = M<real>::rsqrt(r2), r = r2 * ir, dr = r - it.r0;
+        const HarmItem<real> it = d.items[b];
+        const R3<real> dd = L.pos(it.i) - L.pos(it.j);
+        const real r2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z, ir = M<real>::rsqrt(r2), r = r2 * ir, dr = r - it.r0;
         if (ENERGY) e += (double)((real)0.5 * it.k * dr * dr);
-        pair_force(L, it.i, it.j, dx, dy, dz, -it.k * dr * ir);
+        L.pair_force(it.i, it.j, dd.x, dd.y, dd.z, -it.k * dr * ir);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-template <bool ENERGY, class real> __device__ void term_chi(const ChiD<real>& d, const Lds<real>& L, int rot = 0) {
+template <bool ENERGY, class V> __device__ void term_chi(const ChiD<typename V::real_t>& d, const V& L, int rot = 0) {
+    typedef typename V::real_t real;
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
-        Int4 a = d.atoms[b];   // CA, C, N, CB
-        real ux = L.px[a.x] - L.px[a.y], uy = L.py[a.x] - L.py[a.y], uz = L.pz[a.x] - L.pz[a.y];
-        real vx = L.px[a.z] - L.px[a.x], vy = L.py[a.z] - L.py[a.x], vz = L.pz[a.z] - L.pz[a.x];
-        real wx = L.px[a.x] - L.px[a.w], wy = L.py[a.x] - L.py[a.w], wz = L.pz[a.x] - L.pz[a.w];
+        const Int4 a = d.atoms[b];   // CA, C, N, CB
+        const R3<real> pca = L.pos(a.x), u = pca - L.pos(a.y), v = L.pos(a.z) - pca, w = pca - L.pos(a.w);
+        const real ux = u.x, uy = u.y, uz = u.z, vx = v.x, vy = v.y, vz = v.z, wx = w.x, wy = w.y, wz = w.z;
         real uvx = uy * vz - uz * vy, uvy = uz * vx - ux * vz, uvz = ux * vy - uy * vx;
         real vwx = vy * wz - vz * wy, vwy = vz * wx - vx * wz, vwz = vx * wy - vy * wx;
         real wux = wy * uz - wz * uy, wuy = wz * ux - wx * uz, wuz = wx * uy - wy * ux;
@@ -161,33 +238,32 @@ template <bool ENERGY, class real> __device__ void term_chi(const ChiD<real>& d,
         real norm = M<real>::rsqrt(u2 * v2 * w2);
         real chi = (uvx * wx + uvy * wy + uvz * wz) * norm, dchi = chi - d.chi0;
         if (ENERGY) e += (double)(d.k * dchi * dchi);
-        real c = (real)-2 * d.k * dchi, cu = chi / u2, cv = chi / v2, cw = chi / w2;
+        real c = (real)-2 * d.k * dchi, cu = chi * M<real>::rcp(u2), cv = chi * M<real>::rcp(v2), cw = chi * M<real>::rcp(w2);
         real gux = vwx * norm - cu * ux, guy = vwy * norm - cu * uy, guz = vwz * norm - cu * uz;
         real gvx = wux * norm - cv * vx, gvy = wuy * norm - cv * vy, gvz = wuz * norm - cv * vz;
         real gwx = uvx * norm - cw * wx, gwy = uvy * norm - cw * wy, gwz = uvz * norm - cw * wz;
-        add_force(L, a.x, c * (gux - gvx + gwx), c * (guy - gvy + gwy), c * (guz - gvz + gwz));
-        add_force(L, a.y, -c * gux, -c * guy, -c * guz);
-        add_force(L, a.z, c * gvx, c * gvy, c * gvz);
-        add_force(L, a.w, -c * gwx, -c * gwy, -c * gwz);
+        L.add_force(a.x, c * (gux - gvx + gwx), c * (guy - gvy + gwy), c * (guz - gvz + gwz));
+        L.add_force(a.y, -c * gux, -c * guy, -c * guz);
+        L.add_force(a.z, c * gvx, c * gvy, c * gvz);
+        L.add_force(a.w, -c * gwx, -c * gwy, -c * gwz);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
 
 // cos/sin of the IUPAC dihedral p0-p1-p2-p3 and the gradient of the angle (Blondel & Karplus form).
 template <class real> struct Dihedral { real c, s; real g[4][3]; };
-template <class real> __device__ __forceinline__ void dihedral(const Lds<real>& L, int p0, int p1, int p2, int p3, Dihedral<real>& D) {
-    real Fx = L.px[p0] - L.px[p1], Fy = L.py[p0] - L.py[p1], Fz = L.pz[p0] - L.pz[p1];
-    real Gx = L.px[p1] - L.px[p2], Gy = L.py[p1] - L.py[p2], Gz = L.pz[p1] - L.pz[p2];
-    real Hx = L.px[p3] - L.px[p2], Hy = L.py[p3] - L.py[p2], Hz = L.pz[p3] - L.pz[p2];
-    real Ax = Fy * Gz - Fz * Gy, Ay = Fz * Gx - Fx * Gz, Az = Fx * Gy - Fy * Gx;
-    real Bx = Hy * Gz - Hz * Gy, By = Hz * Gx - Hx * Gz, Bz = Hx * Gy - Hy * Gx;
-    real A2 = Ax * Ax + Ay * Ay + Az * Az, B2 = Bx * Bx + By * By + Bz * Bz, G2 = Gx * Gx + Gy * Gy + Gz * Gz;
+template <class real> __device__ __forceinline__ void dihedral(const R3<real>& q0, const R3<real>& q1, const R3<real>& q2, const R3<real>& q3, Dihedral<real>& D) {
+    const R3<real> F = q0 - q1, G = q1 - q2, H = q3 - q2;
+    real Ax = F.y * G.z - F.z * G.y, Ay = F.z * G.x - F.x * G.z, Az = F.x * G.y - F.y * G.x;
+    real Bx = H.y * G.z - H.z * G.y, By = H.z * G.x - H.x * G.z, Bz = H.x * G.y - H.y * G.x;
+    real A2 = Ax * Ax + Ay * Ay + Az * Az, B2 = Bx * Bx + By * By + Bz * Bz, G2 = G.x * G.x + G.y * G.y + G.z * G.z;
     real iAB = M<real>::rsqrt(A2 * B2), iG = M<real>::rsqrt(G2), Gn = G2 * iG;
     D.c = (Ax * Bx + Ay * By + Az * Bz) * iAB;
     real Cx = By * Az - Bz * Ay, Cy = Bz * Ax - Bx * Az, Cz = Bx * Ay - By * Ax;   // B x A
-    D.s = (Cx * Gx + Cy * Gy + Cz * Gz) * iAB * iG;
-    real FG = Fx * Gx + Fy * Gy + Fz * Gz, HG = Hx * Gx + Hy * Gy + Hz * Gz;
-    real a = Gn / A2, b = Gn / B2, ta = FG / (A2 * Gn), tb = HG / (B2 * Gn);
+    D.s = (Cx * G.x + Cy * G.y + Cz * G.z) * iAB * iG;
+    real FG = F.x * G.x + F.y * G.y + F.z * G.z, HG = H.x * G.x + H.y * G.y + H.z * G.z;
+    const real iA2 = M<real>::rcp(A2), iB2 = M<real>::rcp(B2);
+    real a = Gn * iA2, b = Gn * iB2, ta = FG * iA2 * iG, tb = HG * iB2 * iG;
     real A[3] = {Ax, Ay, Az}, B[3] = {Bx, By, Bz};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -196,30 +272,36 @@ template <class real> __device__ __forceinline__ void dihedral(const Lds<real>& 
     }
 }
 
-template <bool ENERGY, class real> __device__ void term_rama(const RamaD<real>& d, const Lds<real>& L, int rot = 0) {
+template <bool ENERGY, class V> __device__ void term_rama(const RamaD<typename V::real_t>& d, const V& L, int rot = 0) {
+    typedef typename V::real_t real;
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
-        Int5 a = d.atoms[b];
+        const Int5 a = d.atoms[b];
+        real W[AWSEM_MAX_WELLS];
+#pragma unroll
+        for (int w = 0; w < AWSEM_MAX_WELLS; w++) W[w] = w < d.nwell ? d.bw[b * d.nwell + w] : (real)0;   // -k * w * weight, folded
+        const R3<real> q0 = L.pos(a.a[0]), q1 = L.pos(a.a[1]), q2 = L.pos(a.a[2]), q3 = L.pos(a.a[3]), q4 = L.pos(a.a[4]);
         Dihedral<real> P, S;
-        dihedral(L, a.a[0], a.a[1], a.a[2], a.a[3], P);
-        dihedral(L, a.a[1], a.a[2], a.a[3], a.a[4], S);
+        dihedral(q0, q1, q2, q3, P);
+        dihedral(q1, q2, q3, q4, S);
         real dEdphi = 0, dEdpsi = 0;
-        for (int w = 0; w < d.nwell; w++) {
-            real W = d.bw[b * d.nwell + w];   // -k * w * weight, folded
+#pragma unroll
+        for (int w = 0; w < AWSEM_MAX_WELLS; w++) {
+            if (w >= d.nwell) break;
             real cp = P.c * d.cphi0[w] + P.s * d.sphi0[w] - (real)1, sp = P.s * d.cphi0[w] - P.c * d.sphi0[w];
             real cs = S.c * d.cpsi0[w] + S.s * d.spsi0[w] - (real)1, ss = S.s * d.cpsi0[w] - S.c * d.spsi0[w];
-            real ex = W * M<real>::exp(-d.sigma[w] * (d.omega_phi[w] * cp * cp + d.omega_psi[w] * cs * cs));
+            real ex = W[w] * M<real>::exp(-d.sigma[w] * (d.omega_phi[w] * cp * cp + d.omega_psi[w] * cs * cs));
             if (ENERGY) e += (double)ex;
             dEdphi += ex * (real)2 * d.sigma[w] * d.omega_phi[w] * cp * sp;
             dEdpsi += ex * (real)2 * d.sigma[w] * d.omega_psi[w] * cs * ss;
         }
         // atoms 1..3 receive both contributions
-        add_force(L, a.a[0], -dEdphi * P.g[0][0], -dEdphi * P.g[0][1], -dEdphi * P.g[0][2]);
+        L.add_force(a.a[0], -dEdphi * P.g[0][0], -dEdphi * P.g[0][1], -dEdphi * P.g[0][2]);
 #pragma unroll
         for (int m = 1; m < 4; m++)
-            add_force(L, a.a[m], -dEdphi * P.g[m][0] - dEdpsi * S.g[m - 1][0], -dEdphi * P.g[m][1] - dEdpsi * S.g[m - 1][1],
-                      -dEdphi * P.g[m][2] - dEdpsi * S.g[m - 1][2]);
-        add_force(L, a.a[4], -dEdpsi * S.g[3][0], -dEdpsi * S.g[3][1], -dEdpsi * S.g[3][2]);
+            L.add_force(a.a[m], -dEdphi * P.g[m][0] - dEdpsi * S.g[m - 1][0], -dEdphi * P.g[m][1] - dEdpsi * S.g[m - 1][1],
+                        -dEdphi * P.g[m][2] - dEdpsi * S.g[m - 1][2]);
+        L.add_force(a.a[4], -dEdpsi * S.g[3][0], -dEdpsi * S.g[3][1], -dEdpsi * S.g[3][2]);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
@@ -232,18 +314,18 @@ template <class real> __device__ __forceinline__ real hb_theta(real r1, real r2,
     return th;
 }
 
-template <bool ENERGY, class real> __device__ void term_helical(const HelicalD<real>& d, const Lds<real>& L, int rot = 0) {
+template <bool ENERGY, class V> __device__ void term_helical(const HelicalD<typename V::real_t>& d, const V& L, int rot = 0) {
+    typedef typename V::real_t real;
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
-        HelicalItem<real> it = d.items[b];
-        real ax = L.px[it.o] - L.px[it.n], ay = L.py[it.o] - L.py[it.n], az = L.pz[it.o] - L.pz[it.n];
-        real bx = L.px[it.o] - L.px[it.h], by = L.py[it.o] - L.py[it.h], bz = L.pz[it.o] - L.pz[it.h];
-        real r1s = ax * ax + ay * ay + az * az, r2s = bx * bx + by * by + bz * bz;
+        const HelicalItem<real> it = d.items[b];
+        const R3<real> po = L.pos(it.o), A = po - L.pos(it.n), B = po - L.pos(it.h);
+        real r1s = A.x * A.x + A.y * A.y + A.z * A.z, r2s = B.x * B.x + B.y * B.y + B.z * B.z;
         real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s), g1, g2;
         real th = hb_theta(r1s * i1, r2s * i2, d.r_ON, d.r_OH, d.inv_sNO2, d.inv_sHO2, g1, g2);
         if (ENERGY) e += (double)(-it.coef * th);
-        pair_force(L, it.o, it.n, ax, ay, az, it.coef * g1 * i1);
-        pair_force(L, it.o, it.h, bx, by, bz, it.coef * g2 * i2);
+        L.pair_force(it.o, it.n, A.x, A.y, A.z, it.coef * g1 * i1);
+        L.pair_force(it.o, it.h, B.x, B.y, B.z, it.coef * g2 * i2);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
@@ -251,7 +333,8 @@ template <bool ENERGY, class real> __device__ void term_helical(const HelicalD<r
 // Fragment memory: per bond two neighbouring floats of an L2-resident table row.  U bonds are kept in flight per
 // thread so that the dependent chain (pair word -> LDS coordinates -> table gather) overlaps across bonds; all index
 // arithmetic is unsigned 32-bit so that the loads use the scalar-base + 32-bit-offset addressing form.
-template <bool ENERGY, int U, bool PACKED, class real> __device__ __forceinline__ void fm_body(const FmD<real>& d, const Lds<real>& L, unsigned b0, unsigned stride, Energy& e) {
+template <bool ENERGY, int U, bool PACKED, class V> __device__ __forceinline__ void fm_body(const FmD<typename V::real_t>& d, const V& L, unsigned b0, unsigned stride, Energy& e) {
+    typedef typename V::real_t real;
     unsigned ai[U], aj[U], i1[U], bb[U];
     real r[U], ir[U];
     real2_t<real> v[U];
@@ -270,8 +353,8 @@ template <bool ENERGY, int U, bool PACKED, class real> __device__ __forceinline_
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const unsigned b = bb[u] < n ? bb[u] : b0;
-        const real dx = L.px[ai[u]] - L.px[aj[u]], dy = L.py[ai[u]] - L.py[aj[u]], dz = L.pz[ai[u]] - L.pz[aj[u]];
-        const real r2 = dx * dx + dy * dy + dz * dz;
+        const R3<real> dd = L.pos(ai[u]) - L.pos(aj[u]);
+        const real r2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z;
         ir[u] = M<real>::rsqrt(r2); r[u] = r2 * ir[u];
         const unsigned bin = (unsigned)(int)(r[u] * d.inv_dr);   // r >= 0: truncation is floor
         i1[u] = bin < nrow - 1u ? bin : nrow - 1u;
@@ -287,13 +370,14 @@ template <bool ENERGY, int U, bool PACKED, class real> __device__ __forceinline_
         const real slope = (v[u].y - v[u].x) * d.inv_dr;
         if (ENERGY) e += (double)(-d.k * (v[u].x + slope * (r[u] - d.dr * (real)i1[u])));
 #ifdef AWSEM_EXP_FM_NOATOMIC
-        if (slope * ir[u] == (real)123.456) L.fx[0] = 1;
+        if (slope * ir[u] == (real)123.456) L.zero_force(0);
 #else
-        pair_force(L, ai[u], aj[u], L.px[ai[u]] - L.px[aj[u]], L.py[ai[u]] - L.py[aj[u]], L.pz[ai[u]] - L.pz[aj[u]], d.k * slope * ir[u]);
+        const R3<real> dd = L.pos(ai[u]) - L.pos(aj[u]);   // read again rather than kept in registers across the gather
+        L.pair_force(ai[u], aj[u], dd.x, dd.y, dd.z, d.k * slope * ir[u]);
 #endif
     }
 }
-template <bool ENERGY, bool PACKED = true, class real> __device__ void term_fm(const FmD<real>& d, const Lds<real>& L, int rot = 0) {
+template <bool ENERGY, bool PACKED = true, class V> __device__ void term_fm(const FmD<typename V::real_t>& d, const V& L, int rot = 0) {
     Energy e;
     constexpr int U = 6;
     const unsigned stride = blockDim.x, n = (unsigned)d.n;
@@ -301,29 +385,31 @@ template <bool ENERGY, bool PACKED = true, class real> __device__ void term_fm(c
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-template <bool ENERGY, class real> __device__ void term_memb(const MembD<real>& d, const Lds<real>& L, int rot = 0) {
+template <bool ENERGY, class V> __device__ void term_memb(const MembD<typename V::real_t>& d, const V& L, int rot = 0) {
+    typedef typename V::real_t real;
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
-        MembItem<real> it = d.items[b];
-        real z = L.pz[it.atom] - d.center;
+        const MembItem<real> it = d.items[b];
+        real z = L.pos(it.atom).z - d.center;
         // 1/2 tanh(u) + 1/2 tanh(v) = sig(2u) + sig(2v) - 1
         real su = sigmoid(d.k_m2 * (z + d.z_m)), sv = sigmoid(d.k_m2 * (d.z_m - z));
         if (ENERGY) e += (double)(d.k * it.scale * (su + sv - (real)1));
         real dEdz = d.k * it.scale * d.k_m2 * (su * ((real)1 - su) - sv * ((real)1 - sv));
-        atomicAdd(&L.fz[it.atom], to_fixed(-dEdz));
+        L.add_fz(it.atom, -dEdz);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-template <bool ENERGY, class real> __device__ void term_dh(const DhD<real>& d, const Lds<real>& L, int rot = 0) {
+template <bool ENERGY, class V> __device__ void term_dh(const DhD<typename V::real_t>& d, const V& L, int rot = 0) {
+    typedef typename V::real_t real;
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
-        DhItem<real> it = d.items[b];
-        real dx = L.px[it.i] - L.px[it.j], dy = L.py[it.i] - L.py[it.j], dz = L.pz[it.i] - L.pz[it.j];
-        real r2 = dx * dx + dy * dy + dz * dz, ir = M<real>::rsqrt(r2), r = r2 * ir;
+        const DhItem<real> it = d.items[b];
+        const R3<real> dd = L.pos(it.i) - L.pos(it.j);
+        real r2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z, ir = M<real>::rsqrt(r2), r = r2 * ir;
         real E = d.k * it.qq * ir * M<real>::exp(-r * d.inv_lam);
         if (ENERGY) e += (double)E;
-        pair_force(L, it.i, it.j, dx, dy, dz, E * (ir + d.inv_lam) * ir);
+        L.pair_force(it.i, it.j, dd.x, dd.y, dd.z, E * (ir + d.inv_lam) * ir);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
@@ -337,9 +423,6 @@ template <bool ENERGY, class real> __device__ void term_dh(const DhD<real>& d, c
 // coalesced store.  EVALUATE reads the list 64 entries per wave iteration with every lane busy, and books both
 // sides of the pair with fixed-point LDS atomics (conflict-light thanks to the diagonal order).  The evaluators
 // re-apply the exact cutoff of the reference, so the result does not depend on when a list was built.
-// fixed evaluation order, fma in the handle's own precision (v_fma_f32 / v_fma_f64): the pair set is bit-exact
-__device__ __forceinline__ float dist2(float dx, float dy, float dz) { return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)); }
-__device__ __forceinline__ double dist2(double dx, double dy, double dz) { return __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx)); }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ void list_append(unsigned* __restrict__ e, unsigned* cnt, int cap, int* status, bool pass, unsigned entry) {
@@ -361,14 +444,15 @@ __device__ __forceinline__ void list_append(unsigned* __restrict__ e, unsigned* 
 // that short lists do not all land on wave 0
 #define AWSEM_LIST_CHUNKS(c0, count, rot) for (int c0 = ((wave + nw - ((rot) % nw)) % nw) * 64; c0 < (count); c0 += nw * 64)
 
-template <class real> struct ListView { const unsigned* e; int count; };
-template <class real> __device__ __forceinline__ ListView<real> list_view(const Lds<real>& L, const ListSlot& ls) {
+struct ListView { const unsigned* e; int count; };
+template <class V> __device__ __forceinline__ ListView list_view(const V& L, const ListSlot& ls) {
     const int n = (int)L.lcount[ls.list_id];
-    return ListView<real>{L.lists + ls.list_off, n < ls.list_cap ? n : ls.list_cap};
+    return ListView{L.lists + ls.list_off, n < ls.list_cap ? n : ls.list_cap};
 }
 
 // ---- excluded volume: same-class site pairs that are not bonded partners
-template <class real> __device__ void build_excl(const ExclD<real>& d, const Lds<real>& L, int* status) {
+template <class V> __device__ void build_excl(const ExclD<typename V::real_t>& d, const V& L, int* status) {
+    typedef typename V::real_t real;
     AWSEM_WAVE_VARS;
     unsigned* e = L.lists + d.ls.list_off;
     unsigned* cnt = &L.lcount[d.ls.list_id];
@@ -380,7 +464,7 @@ template <class real> __device__ void build_excl(const ExclD<real>& d, const Lds
                 const bool v = j < n;
                 const int si = base + (v ? i : 0), sj = base + (v ? j : 0);
                 const int a = d.atom[si], b = d.atom[sj];
-                const real r2 = dist2(L.px[a] - L.px[b], L.py[a] - L.py[b], L.pz[a] - L.pz[b]);
+                const real r2 = dist2(L.pos(a) - L.pos(b));
                 bool pass = v && r2 < d.list_rc2;
                 if (pass) {
                     const Int4 p = d.partners[si];
@@ -392,19 +476,20 @@ template <class real> __device__ void build_excl(const ExclD<real>& d, const Lds
     }
 }
 // one candidate pair per lane (v = lane holds a pair); shared by the replica-resident and the cell-list path
-template <bool ENERGY, class real> __device__ __forceinline__ void excl_body(const ExclD<real>& d, const Lds<real>& L, int a, int b, bool v, Energy& e) {
-    const real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
-    const real r2 = dist2(dx, dy, dz);
+template <bool ENERGY, class V> __device__ __forceinline__ void excl_body(const ExclD<typename V::real_t>& d, const V& L, int a, int b, bool v, Energy& e) {
+    typedef typename V::real_t real;
+    const R3<real> dd = L.pos(a) - L.pos(b);
+    const real r2 = dist2(dd);
     if (v && r2 < d.r0 * d.r0) {   // clashes are rare: divergent body
         const real ir = M<real>::rsqrt(r2), dr = r2 * ir - d.r0;
         if (ENERGY) e += (double)(d.k * dr * dr);
-        pair_force(L, a, b, dx, dy, dz, (real)-2 * d.k * dr * ir);
+        L.pair_force(a, b, dd.x, dd.y, dd.z, (real)-2 * d.k * dr * ir);
     }
 }
-template <bool ENERGY, class real> __device__ void eval_excl(const ExclD<real>& d, const Lds<real>& L) {
+template <bool ENERGY, class V> __device__ void eval_excl(const ExclD<typename V::real_t>& d, const V& L) {
     AWSEM_WAVE_VARS;
     Energy e;
-    const ListView<real> lv = list_view(L, d.ls);
+    const ListView lv = list_view(L, d.ls);
     AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id) {
         const int idx = c0 + lane;
         const bool v = idx < lv.count;
@@ -415,7 +500,8 @@ template <bool ENERGY, class real> __device__ void eval_excl(const ExclD<real>& 
 }
 
 // ---- contact: site pairs with |resid_i - resid_j| >= 2 (the density's own exclusion; the pair energy needs more)
-template <class real> __device__ void build_contact(const ContactD<real>& d, const Lds<real>& L, const int* satom, int* status) {
+template <class V> __device__ void build_contact(const ContactD<typename V::real_t>& d, const V& L, const int* satom, int* status) {
+    typedef typename V::real_t real;
     AWSEM_WAVE_VARS;
     unsigned* e = L.lists + d.ls.list_off;
     unsigned* cnt = &L.lcount[d.ls.list_id];
@@ -427,7 +513,7 @@ template <class real> __device__ void build_contact(const ContactD<real>& d, con
             const int si = v ? i : 0, sj = v ? j : 0;
             const int info_i = d.info[si], info_j = d.info[sj], a = satom[si], b = satom[sj];
             const int dres = (info_j & 0xffff) - (info_i & 0xffff);
-            const real r2 = dist2(L.px[a] - L.px[b], L.py[a] - L.py[b], L.pz[a] - L.pz[b]);
+            const real r2 = dist2(L.pos(a) - L.pos(b));
             // the density counts |resid_i - resid_j| >= 2 whatever the chains (contactTerms.py:255); the pair energy
             // counts different chains or |resid_i - resid_j| >= min_seq_sep (res_table, contactTerms.py:200-210)
             const bool in_rho = dres >= 2 || dres <= -2;
@@ -440,21 +526,22 @@ template <class real> __device__ void build_contact(const ContactD<real>& d, con
     }
 }
 // pass 1: density rho_i = sum_j theta_I(r_ij) inside the cutoff
-template <class real> __device__ __forceinline__ void density_body(const ContactD<real>& d, const Lds<real>& L, int i, int j, int a, int b, bool v) {
-    const real r2 = dist2(L.px[a] - L.px[b], L.py[a] - L.py[b], L.pz[a] - L.pz[b]);
+template <class V> __device__ __forceinline__ void density_body(const ContactD<typename V::real_t>& d, const V& L, int i, int j, int a, int b, bool v) {
+    typedef typename V::real_t real;
+    const real r2 = dist2(L.pos(a) - L.pos(b));
     const bool pass = v && r2 < d.cutoff2;
     if (__ballot(pass) == 0) return;
     const real r = M<real>::sqrt(r2);
     const real th = sigmoid(d.eta2 * (r - d.rmin)) * sigmoid(d.eta2 * (d.rmax - r));
     if (pass) {
         const u64 t = to_fixed(th);
-        atomicAdd(&L.rho[i], t);
-        atomicAdd(&L.rho[j], t);
+        fixed_add(&L.rho[i], t);
+        fixed_add(&L.rho[j], t);
     }
 }
-template <class real> __device__ void contact_density(const ContactD<real>& d, const Lds<real>& L, const int* satom) {
+template <class V> __device__ void contact_density(const ContactD<typename V::real_t>& d, const V& L, const int* satom) {
     AWSEM_WAVE_VARS;
-    const ListView<real> lv = list_view(L, d.ls);
+    const ListView lv = list_view(L, d.ls);
     AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id) {
         const int idx = c0 + lane;
         const bool v = idx < lv.count;
@@ -465,8 +552,9 @@ template <class real> __device__ void contact_density(const ContactD<real>& d, c
 }
 // Between pass 1 and 2: evaluate the burial wells (single-particle energy), seed dE/drho, and precompute the
 // per-site water switch s_i = sig(-2 eta_s (rho_i - rho0)) (sigma_water_ij = s_i s_j) into L.rhov.
-template <bool ENERGY, class real> __device__ __forceinline__ void single_body(const ContactD<real>& d, const Lds<real>& L, int i, int atom, Energy& e) {
-    real rho = (real)fixed_to_double(L.rho[i]);
+template <bool ENERGY, class V> __device__ __forceinline__ void single_body(const ContactD<typename V::real_t>& d, const V& L, int i, int atom, Energy& e) {
+    typedef typename V::real_t real;
+    real rho = fixed_to_real(L.rho[i], (real)0);
     L.rhov[i] = sigmoid(-d.eta_s2 * (rho - d.rho0));
     real dE = 0;
     if (d.has_burial) {
@@ -482,25 +570,26 @@ template <bool ENERGY, class real> __device__ __forceinline__ void single_body(c
     }
     L.drho[i] = to_fixed(dE);
     if (d.flags & 1) {
-        real z = L.pz[atom] - d.zc;
+        real z = L.pos(atom).z - d.zc;
         real su = sigmoid(d.eta_sw2 * (z + d.z_m)), sv = sigmoid(d.eta_sw2 * (d.z_m - z));
         L.alpha[i] = su + sv - (real)1;
         L.dalpha[i] = d.eta_sw2 * (su * ((real)1 - su) - sv * ((real)1 - sv));
     }
 }
-template <bool ENERGY, class real> __device__ void contact_single(const ContactD<real>& d, const Lds<real>& L, const int* satom, int rot = 0) {
+template <bool ENERGY, class V> __device__ void contact_single(const ContactD<typename V::real_t>& d, const V& L, const int* satom, int rot = 0) {
     Energy e;
     for (int i = rot_tid(rot); i < d.nsites; i += blockDim.x) single_body<ENERGY>(d, L, i, satom[i], e);
     flush_energy<ENERGY>(L, d.group, e);
 }
 // pass 2: pair energy (direct + mediated), its explicit radial force, and dE/drho through sigma_water
-template <bool ENERGY, class real> __device__ __forceinline__ void pairs_body(const ContactD<real>& d, const Lds<real>& L, int i, int j, int ty, int a, int b, bool v, Energy& e) {
+template <bool ENERGY, class V> __device__ __forceinline__ void pairs_body(const ContactD<typename V::real_t>& d, const V& L, int i, int j, int ty, int a, int b, bool v, Energy& e) {
+    typedef typename V::real_t real;
     const bool zdep = d.flags & 1;
     const real* g0 = L.gamma;
     const real* g1 = L.gamma + 1200;
     const real one = (real)1;
-    const real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
-    const real r2 = dist2(dx, dy, dz);
+    const R3<real> dd = L.pos(a) - L.pos(b);
+    const real r2 = dist2(dd);
     const bool pass = v && r2 < d.cutoff2;
     if (__ballot(pass) == 0) return;
     const real ir = M<real>::rsqrt(pass ? r2 : one), r = r2 * ir;
@@ -530,19 +619,19 @@ template <bool ENERGY, class real> __device__ __forceinline__ void pairs_body(co
     }
     if (pass) {
         if (ENERGY) e += (double)E;
-        pair_force(L, a, b, dx, dy, dz, -dEdr * ir);
-        atomicAdd(&L.drho[i], to_fixed(dEdsw * sj * (-d.eta_s2 * si * (one - si))));
-        atomicAdd(&L.drho[j], to_fixed(dEdsw * si * (-d.eta_s2 * sj * (one - sj))));
+        L.pair_force(a, b, dd.x, dd.y, dd.z, -dEdr * ir);
+        fixed_add(&L.drho[i], to_fixed(dEdsw * sj * (-d.eta_s2 * si * (one - si))));
+        fixed_add(&L.drho[j], to_fixed(dEdsw * si * (-d.eta_s2 * sj * (one - sj))));
         if (zdep) {
-            atomicAdd(&L.fz[a], to_fixed(fzi));
-            atomicAdd(&L.fz[b], to_fixed(fzj));
+            L.add_fz(a, fzi);
+            L.add_fz(b, fzj);
         }
     }
 }
-template <bool ENERGY, class real> __device__ void contact_pairs(const ContactD<real>& d, const Lds<real>& L, const int* satom) {
+template <bool ENERGY, class V> __device__ void contact_pairs(const ContactD<typename V::real_t>& d, const V& L, const int* satom) {
     AWSEM_WAVE_VARS;
     Energy e;
-    const ListView<real> lv = list_view(L, d.ls);
+    const ListView lv = list_view(L, d.ls);
     AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id + 1) {
         const int idx = c0 + lane;
         const bool v = idx < lv.count;
@@ -553,19 +642,20 @@ template <bool ENERGY, class real> __device__ void contact_pairs(const ContactD<
     flush_energy<ENERGY>(L, d.group, e);
 }
 // pass 3: chain rule through the densities: F_j += (dE/drho_i + dE/drho_j) theta_I'(r) (x_i - x_j)/r
-template <class real> __device__ __forceinline__ void chain_body(const ContactD<real>& d, const Lds<real>& L, int i, int j, int a, int b, bool v) {
-    const real dx = L.px[a] - L.px[b], dy = L.py[a] - L.py[b], dz = L.pz[a] - L.pz[b];
-    const real r2 = dist2(dx, dy, dz);
+template <class V> __device__ __forceinline__ void chain_body(const ContactD<typename V::real_t>& d, const V& L, int i, int j, int a, int b, bool v) {
+    typedef typename V::real_t real;
+    const R3<real> dd = L.pos(a) - L.pos(b);
+    const real r2 = dist2(dd);
     const bool pass = v && r2 < d.cutoff2;
     if (__ballot(pass) == 0) return;
     const real ir = M<real>::rsqrt(pass ? r2 : (real)1), r = r2 * ir;
     const real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
-    const real g = (real)(fixed_to_double(L.drho[i]) + fixed_to_double(L.drho[j]));
-    if (pass) pair_force(L, a, b, dx, dy, dz, -g * d.eta2 * s1 * s2 * (s2 - s1) * ir);
+    const real g = fixed_to_real(L.drho[i] + L.drho[j], (real)0);
+    if (pass) L.pair_force(a, b, dd.x, dd.y, dd.z, -g * d.eta2 * s1 * s2 * (s2 - s1) * ir);
 }
-template <class real> __device__ void contact_chain_rule(const ContactD<real>& d, const Lds<real>& L, const int* satom) {
+template <class V> __device__ void contact_chain_rule(const ContactD<typename V::real_t>& d, const V& L, const int* satom) {
     AWSEM_WAVE_VARS;
-    const ListView<real> lv = list_view(L, d.ls);
+    const ListView lv = list_view(L, d.ls);
     AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id + 2) {
         const int idx = c0 + lane;
         const bool v = idx < lv.count;
@@ -578,7 +668,8 @@ template <class real> __device__ void contact_chain_rule(const ContactD<real>& d
 // ---- acceptor x donor terms (CustomHbondForce shape)
 // In fp32 the lists use a conservative pre-screen (Gaussian factors below e^-30 of their maximum are skipped, far
 // under fp32 resolution); the fp64 check mode applies only the reference's cutoff.
-template <class real, class Desc> __device__ void build_hbond(const Desc& d, const real* __restrict__ table, const Lds<real>& L, int* status) {
+template <class V, class Desc> __device__ void build_hbond(const Desc& d, const typename V::real_t* __restrict__ table, const V& L, int* status) {
+    typedef typename V::real_t real;
     AWSEM_WAVE_VARS;
     unsigned* e = L.lists + d.ls.list_off;
     unsigned* cnt = &L.lcount[d.ls.list_id];
@@ -587,7 +678,7 @@ template <class real, class Desc> __device__ void build_hbond(const Desc& d, con
         const int ia = a0 + lane;
         const bool va = ia < d.nacc;
         const Int4 A = d.acc[va ? ia : 0];
-        const real ax = L.px[A.x], ay = L.py[A.x], az = L.pz[A.x];
+        const R3<real> pa = L.pos(A.x);
         const int ares = resw == 3 ? A.w : A.z;
         const int q0 = (va ? ia : 0) % d.ndon;
         for (int dd = wave; dd < d.ndon; dd += nw) {
@@ -595,7 +686,7 @@ template <class real, class Desc> __device__ void build_hbond(const Desc& d, con
             q = q >= d.ndon ? q - d.ndon : q;
             const Int4 D = d.don[q];
             const int dres = resw == 3 ? D.w : D.z, dq = dres - ares;
-            const real r2 = dist2(ax - L.px[D.x], ay - L.py[D.x], az - L.pz[D.x]);
+            const real r2 = dist2(pa - L.pos(D.x));
             bool pass = va && r2 < d.list_rc2 && (dq <= d.band_lo || dq >= d.band_hi);
             if (pass) pass = table[(size_t)dres * d.nres + ares] != (real)0;
             list_append(e, cnt, d.ls.list_cap, status, pass, ((unsigned)ia << 16) | (unsigned)q);
@@ -603,21 +694,21 @@ template <class real, class Desc> __device__ void build_hbond(const Desc& d, con
     }
 }
 
-template <bool ENERGY, class real> __device__ void eval_beta(const BetaD<real>& d, const Lds<real>& L) {
+template <bool ENERGY, class V> __device__ void eval_beta(const BetaD<typename V::real_t>& d, const V& L) {
+    typedef typename V::real_t real;
     AWSEM_WAVE_VARS;
     Energy e;
-    const ListView<real> lv = list_view(L, d.ls);
+    const ListView lv = list_view(L, d.ls);
     AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id) {
         const int idx = c0 + lane;
         if (idx >= lv.count) continue;
         const unsigned ent = lv.e[idx];
         const Int4 A = d.acc[ent >> 16], D = d.don[ent & 0xffff];
-        const real ox = L.px[A.x], oy = L.py[A.x], oz = L.pz[A.x];
-        const real ax = ox - L.px[D.x], ay = oy - L.py[D.x], az = oz - L.pz[D.x];
-        const real r1s = dist2(ax, ay, az);
+        const R3<real> po = L.pos(A.x), a = po - L.pos(D.x);
+        const real r1s = dist2(a);
         if (!(r1s < d.screen2)) continue;
-        const real bx = ox - L.px[D.y], by = oy - L.py[D.y], bz = oz - L.pz[D.y];
-        const real r2s = dist2(bx, by, bz);
+        const R3<real> b = po - L.pos(D.y);
+        const real r2s = dist2(b);
         const real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
         const real da = r1s * i1 - d.r_ON, db = r2s * i2 - d.r_OH;
         const real ex1 = (real)0.5 * (da * da * d.inv_sNO2 + db * db * d.inv_sHO2);
@@ -626,112 +717,113 @@ template <bool ENERGY, class real> __device__ void eval_beta(const BetaD<real>& 
         const real th1 = M<real>::exp(-ex1), g1 = -th1 * da * d.inv_sNO2, g2 = -th1 * db * d.inv_sHO2;
         if (!d.two_theta) {
             if (ENERGY) e += (double)(c * th1);
-            pair_force(L, A.x, D.x, ax, ay, az, -c * g1 * i1);
-            pair_force(L, A.x, D.y, bx, by, bz, -c * g2 * i2);
+            L.pair_force(A.x, D.x, a.x, a.y, a.z, -c * g1 * i1);
+            L.pair_force(A.x, D.y, b.x, b.y, b.z, -c * g2 * i2);
         } else {
-            const real px = L.px[D.z], py = L.py[D.z], pz = L.pz[D.z];
-            const real cx = px - L.px[A.y], cy = py - L.py[A.y], cz = pz - L.pz[A.y];
-            const real ex = px - L.px[A.z], ey = py - L.py[A.z], ez = pz - L.pz[A.z];
-            const real r3s = dist2(cx, cy, cz), r4s = dist2(ex, ey, ez);
+            const R3<real> pp = L.pos(D.z), cc = pp - L.pos(A.y), ee = pp - L.pos(A.z);
+            const real r3s = dist2(cc), r4s = dist2(ee);
             const real i3 = M<real>::rsqrt(r3s), i4 = M<real>::rsqrt(r4s);
             real h1, h2;
             const real th2 = hb_theta(r3s * i3, r4s * i4, d.r_ON, d.r_OH, d.inv_sNO2, d.inv_sHO2, h1, h2);
             if (ENERGY) e += (double)(c * th1 * th2);
-            pair_force(L, A.x, D.x, ax, ay, az, -c * g1 * th2 * i1);
-            pair_force(L, A.x, D.y, bx, by, bz, -c * g2 * th2 * i2);
-            pair_force(L, D.z, A.y, cx, cy, cz, -c * th1 * h1 * i3);
-            pair_force(L, D.z, A.z, ex, ey, ez, -c * th1 * h2 * i4);
+            L.pair_force(A.x, D.x, a.x, a.y, a.z, -c * g1 * th2 * i1);
+            L.pair_force(A.x, D.y, b.x, b.y, b.z, -c * g2 * th2 * i2);
+            L.pair_force(D.z, A.y, cc.x, cc.y, cc.z, -c * th1 * h1 * i3);
+            L.pair_force(D.z, A.z, ee.x, ee.y, ee.z, -c * th1 * h2 * i4);
         }
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-template <bool ENERGY, class real> __device__ void eval_pap(const PapD<real>& d, const Lds<real>& L) {
+template <bool ENERGY, class V> __device__ void eval_pap(const PapD<typename V::real_t>& d, const V& L) {
+    typedef typename V::real_t real;
     AWSEM_WAVE_VARS;
     Energy e;
     const real one = (real)1;
-    const ListView<real> lv = list_view(L, d.ls);
+    const ListView lv = list_view(L, d.ls);
     AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id) {
         const int idx = c0 + lane;
         if (idx >= lv.count) continue;
         const unsigned ent = lv.e[idx];
         const Int4 A = d.acc[ent >> 16], D = d.don[ent & 0xffff];
-        const real a1x = L.px[A.x], a1y = L.py[A.x], a1z = L.pz[A.x];
-        const real ax = a1x - L.px[D.x], ay = a1y - L.py[D.x], az = a1z - L.pz[D.x];
-        const real r1s = dist2(ax, ay, az);
+        const R3<real> a1 = L.pos(A.x), a = a1 - L.pos(D.x);
+        const real r1s = dist2(a);
         if (!(r1s < d.cutoff2)) continue;
-        const real a2x = L.px[A.y], a2y = L.py[A.y], a2z = L.pz[A.y];
-        const real ex = a1x - a2x, ey = a1y - a2y, ez = a1z - a2z;
-        const real r3s = dist2(ex, ey, ez), i3 = M<real>::rsqrt(r3s);
+        const R3<real> a2 = L.pos(A.y), ee = a1 - a2;
+        const real r3s = dist2(ee), i3 = M<real>::rsqrt(r3s);
         const real arg3 = d.eta2 * (r3s * i3 - d.d_i4);
         if (arg3 < d.min_arg) continue;
-        const real bx = a2x - L.px[D.y], by = a2y - L.py[D.y], bz = a2z - L.pz[D.y];
-        const real r2s = dist2(bx, by, bz);
+        const R3<real> b = a2 - L.pos(D.y);
+        const real r2s = dist2(b);
         const real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
         const real arg2 = d.eta2 * (d.r0 - r2s * i2);
         if (arg2 < d.min_arg) continue;
         const real c = d.gamma[(size_t)D.z * d.nres + A.z];   // -k * gamma[don_res][acc_res]
         const real s1 = sigmoid(d.eta2 * (d.r0 - r1s * i1)), s2 = sigmoid(arg2), s3 = sigmoid(arg3);
         if (ENERGY) e += (double)(c * s1 * s2 * s3);
-        pair_force(L, A.x, D.x, ax, ay, az, c * d.eta2 * s1 * (one - s1) * s2 * s3 * i1);
-        pair_force(L, A.y, D.y, bx, by, bz, c * s1 * d.eta2 * s2 * (one - s2) * s3 * i2);
-        pair_force(L, A.x, A.y, ex, ey, ez, -c * s1 * s2 * d.eta2 * s3 * (one - s3) * i3);
+        L.pair_force(A.x, D.x, a.x, a.y, a.z, c * d.eta2 * s1 * (one - s1) * s2 * s3 * i1);
+        L.pair_force(A.y, D.y, b.x, b.y, b.z, c * s1 * d.eta2 * s2 * (one - s2) * s3 * i2);
+        L.pair_force(A.x, A.y, ee.x, ee.y, ee.z, -c * s1 * s2 * d.eta2 * s3 * (one - s3) * i3);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
 
 // ------------------------------------------------------------------ virtual sites, whole-system evaluation
-template <class real> __device__ void compute_virtual_sites(const DevSys<real>& S, const Lds<real>& L) {
+template <class V> __device__ void compute_virtual_sites(const DevSys<typename V::real_t>& S, const V& L) {
+    typedef typename V::real_t real;
     for (int i = threadIdx.x; i < S.nvs; i += blockDim.x) {
-        Int4 v = S.vs[i];
-        real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
-        L.px[v.x] = w0 * L.px[v.y] + w1 * L.px[v.z] + w2 * L.px[v.w];
-        L.py[v.x] = w0 * L.py[v.y] + w1 * L.py[v.z] + w2 * L.py[v.w];
-        L.pz[v.x] = w0 * L.pz[v.y] + w1 * L.pz[v.z] + w2 * L.pz[v.w];
+        const Int4 v = S.vs[i];
+        const real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
+        const R3<real> a = L.pos(v.y), b = L.pos(v.z), c = L.pos(v.w);
+        L.set_pos(v.x, R3<real>{w0 * a.x + w1 * b.x + w2 * c.x, w0 * a.y + w1 * b.y + w2 * c.y, w0 * a.z + w1 * b.z + w2 * c.z});
     }
 }
-// fold the force on each virtual site onto its three parents (ThreeParticleAverageSite chain rule)
-template <class real> __device__ void redistribute_forces(const DevSys<real>& S, const Lds<real>& L) {
+// fold the force on each virtual site onto its three parents (ThreeParticleAverageSite chain rule); evaluation API
+// only -- the step kernel gathers instead (every massive atom collects from the sites it parents, no atomics)
+template <class V> __device__ void redistribute_forces(const DevSys<typename V::real_t>& S, const V& L) {
+    typedef typename V::real_t real;
     for (int i = threadIdx.x; i < S.nvs; i += blockDim.x) {
-        Int4 v = S.vs[i];
-        real fx = (real)fixed_to_double(L.fx[v.x]), fy = (real)fixed_to_double(L.fy[v.x]), fz = (real)fixed_to_double(L.fz[v.x]);
-        L.fx[v.x] = 0; L.fy[v.x] = 0; L.fz[v.x] = 0;
-        real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
-        add_force(L, v.y, w0 * fx, w0 * fy, w0 * fz);
-        add_force(L, v.z, w1 * fx, w1 * fy, w1 * fz);
-        add_force(L, v.w, w2 * fx, w2 * fy, w2 * fz);
+        const Int4 v = S.vs[i];
+        const R3<real> f = L.force(v.x);
+        L.zero_force(v.x);
+        const real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
+        L.add_force(v.y, w0 * f.x, w0 * f.y, w0 * f.z);
+        L.add_force(v.z, w1 * f.x, w1 * f.y, w1 * f.z);
+        L.add_force(v.w, w2 * f.x, w2 * f.y, w2 * f.z);
     }
 }
 
 // Once per launch: contact site -> atom tables and (when the system has a single contact term) its gamma tables.
-template <class real> __device__ void stage_contact_gamma(const ContactD<real>& d, const Lds<real>& L) {
+template <class V> __device__ void stage_contact_gamma(const ContactD<typename V::real_t>& d, const V& L) {
+    typedef typename V::real_t real;
     if (d.flags & 2) return;
     const int ng = (d.flags & 1) ? 2400 : 1200;
     const real* src = d.gamma + ((d.flags & 1) ? 0 : d.env * 1200);
     for (int i = threadIdx.x; i < ng; i += blockDim.x) L.gamma[i] = src[i];
 }
-template <class real> __device__ void stage_tables(const DevSys<real>& S, const Lds<real>& L) {
+template <class V> __device__ void stage_tables(const DevSys<typename V::real_t>& S, const V& L) {
     for (int t = 0; t < S.n_contact; t++)
         for (int i = threadIdx.x; i < S.contact[t].nsites; i += blockDim.x) L.satom[t * S.max_contact_sites + i] = S.contact[t].atom[i];
     if (S.n_contact == 1) stage_contact_gamma(S.contact[0], L);
 }
 
 #define AWSEM_ON(d) ((mask >> (d).group) & 1u)
-// (Re)build the pair list of every pair term in `mask` from the current LDS positions.  The caller zeroes
-// L.lcount before (and synchronises), and synchronises after.
-template <class real> __device__ void build_lists(const DevSys<real>& S, const Lds<real>& L, unsigned mask) {
+// (Re)build the pair list of every pair term in `mask` from the current positions.  The caller zeroes L.lcount
+// before (and synchronises), and synchronises after.
+template <class V> __device__ void build_lists(const DevSys<typename V::real_t>& S, const V& L, unsigned mask) {
     for (int t = 0; t < S.n_contact; t++) if (AWSEM_ON(S.contact[t])) build_contact(S.contact[t], L, L.satom + t * S.max_contact_sites, S.status);
     for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) build_excl(S.excl[t], L, S.status);
     for (int t = 0; t < S.n_beta; t++) if (AWSEM_ON(S.beta[t])) build_hbond(S.beta[t], S.beta[t].lambda, L, S.status);
     for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) build_hbond(S.pap[t], S.pap[t].gamma, L, S.status);
 }
 
-// Evaluate every term whose group is in `mask` from the current pair lists.  Forces accumulate into L.f* and the
+// Evaluate every term whose group is in `mask` from the current pair lists.  Forces accumulate into the view and the
 // density of the first contact term into L.rho: both zeroed by the caller and visible (call after a __syncthreads());
 // ends with all contributions visible to the workgroup.
 // The contact passes need workgroup barriers between them, which cuts the evaluation into four phases; every other
 // term is issued in one of the phases so that each phase keeps all waves busy.
-template <bool ENERGY, class real> __device__ void evaluate_terms(const DevSys<real>& S, const Lds<real>& L, unsigned mask AWSEM_STAMP_ARG) {
+template <bool ENERGY, class V> __device__ void evaluate_terms(const DevSys<typename V::real_t>& S, const V& L, unsigned mask AWSEM_STAMP_ARG) {
+    typedef typename V::real_t real;
     int first = -1;   // the contact term whose passes define the phases
     for (int t = S.n_contact - 1; t >= 0; t--) if (AWSEM_ON(S.contact[t])) first = t;
     const ContactD<real>* c0 = first >= 0 ? &S.contact[first] : nullptr;
@@ -786,45 +878,62 @@ template <bool ENERGY, class real> __device__ void evaluate_terms(const DevSys<r
 }
 
 // ------------------------------------------------------------------ LDS carve-up
+template <class real> struct LdsLayout;
+template <> struct LdsLayout<float> { static constexpr int pos = 16, force = 16, vel = 16, ref = 16; };      // float4, FAcc32, float4, float4
+template <> struct LdsLayout<double> { static constexpr int pos = 24, force = 24, vel = 24, ref = 24; };     // three 8-byte planes each
 template <class real> __host__ __device__ inline size_t lds_bytes(int natoms, int nsites, int ncontact, bool with_vel) {
+    typedef LdsLayout<real> Y;
     size_t b = 0;
-    b += (size_t)3 * natoms * sizeof(u64);            // forces
+    b += (size_t)natoms * (Y::pos + Y::force + (with_vel ? Y::vel + Y::ref : 0));
     b += (size_t)2 * nsites * sizeof(u64);            // rho, drho
     b += AWSEM_NGROUPS * sizeof(u64);                 // group energies
-    b += (size_t)3 * natoms * sizeof(real);           // positions
-    if (with_vel) b += (size_t)6 * natoms * sizeof(real);   // velocities, pair-list reference positions
     b += (size_t)3 * nsites * sizeof(real);           // rhov, alpha, dalpha
     b += (size_t)2400 * sizeof(real);                 // gamma staging
     b += (size_t)(ncontact > 0 ? ncontact : 1) * nsites * sizeof(int);   // contact site -> atom
     b += (AWSEM_MAX_LISTS + 4) * sizeof(unsigned);    // list counters, flags
     return (b + 15) & ~(size_t)15;
 }
-template <class real> __device__ inline Lds<real> carve_lds(unsigned char* base, int natoms, int nsites, int ncontact, bool with_vel) {
-    Lds<real> L;
-    u64* q = (u64*)base;
-    L.fx = q; q += natoms; L.fy = q; q += natoms; L.fz = q; q += natoms;
-    L.rho = q; q += nsites; L.drho = q; q += nsites;
-    L.eg = q; q += AWSEM_NGROUPS;
-    real* r = (real*)q;
-    L.px = r; r += natoms; L.py = r; r += natoms; L.pz = r; r += natoms;
-    if (with_vel) {
-        L.vx = r; r += natoms; L.vy = r; r += natoms; L.vz = r; r += natoms;
-        L.rx = r; r += natoms; L.ry = r; r += natoms; L.rz = r; r += natoms;
-    } else {
-        L.vx = L.vy = L.vz = L.rx = L.ry = L.rz = nullptr;
-    }
+template <class real> __device__ inline void carve_common(ViewCommon<real>& L, unsigned char* q, int nsites, int ncontact) {
+    u64* w = (u64*)q;
+    L.rho = w; w += nsites; L.drho = w; w += nsites;
+    L.eg = w; w += AWSEM_NGROUPS;
+    real* r = (real*)w;
     L.rhov = r; r += nsites; L.alpha = r; r += nsites; L.dalpha = r; r += nsites;
     L.gamma = r; r += 2400;
     L.satom = (int*)r;
     L.lcount = (unsigned*)(L.satom + (ncontact > 0 ? ncontact : 1) * nsites);
     L.flag = L.lcount + AWSEM_MAX_LISTS;
     L.lists = nullptr;
+}
+__device__ inline Lds<float> carve_lds(float, unsigned char* base, int natoms, int nsites, int ncontact, bool with_vel) {
+    Lds<float> L;
+    unsigned char* q = base;
+    L.p = (float4*)q; q += (size_t)16 * natoms;
+    L.f = (FAcc32*)q; q += (size_t)16 * natoms;
+    L.v = nullptr; L.ref = nullptr;
+    if (with_vel) { L.v = (float4*)q; q += (size_t)16 * natoms; L.ref = (float4*)q; q += (size_t)16 * natoms; }
+    carve_common<float>(L, q, nsites, ncontact);
+    return L;
+}
+__device__ inline Lds<double> carve_lds(double, unsigned char* base, int natoms, int nsites, int ncontact, bool with_vel) {
+    Lds<double> L;
+    u64* w = (u64*)base;
+    L.fx = w; w += natoms; L.fy = w; w += natoms; L.fz = w; w += natoms;
+    double* r = (double*)w;
+    L.px = r; r += natoms; L.py = r; r += natoms; L.pz = r; r += natoms;
+    L.vx = L.vy = L.vz = L.rx = L.ry = L.rz = nullptr;
+    if (with_vel) {
+        L.vx = r; r += natoms; L.vy = r; r += natoms; L.vz = r; r += natoms;
+        L.rx = r; r += natoms; L.ry = r; r += natoms; L.rz = r; r += natoms;
+    }
+    carve_common<double>(L, (unsigned char*)r, nsites, ncontact);
     return L;
 }
 
 // replica state in global memory: SoA per replica, [replica][xyz][natoms]
-template <class real> __device__ inline void load_positions(const real* g, const Lds<real>& L, int natoms) {
-    for (int i = threadIdx.x; i < natoms; i += blockDim.x) { L.px[i] = g[i]; L.py[i] = g[natoms + i]; L.pz[i] = g[2 * natoms + i]; }
+template <class V> __device__ inline void load_positions(const typename V::real_t* g, const V& L, int natoms) {
+    typedef typename V::real_t real;
+    for (int i = threadIdx.x; i < natoms; i += blockDim.x) { L.set_pos(i, R3<real>{g[i], g[natoms + i], g[2 * natoms + i]}); L.zero_force(i); }
 }
 
 // ------------------------------------------------------------------ evaluation kernel (energies and/or forces)
@@ -833,10 +942,9 @@ __global__ void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__
                                   double* __restrict__ e_out /* [R][32] or null */, double* __restrict__ f_out /* [R][natoms][3] or null */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = blockIdx.x;
-    Lds<real> L = carve_lds<real>(smem, natoms, S.max_contact_sites, S.n_contact, false);
+    Lds<real> L = carve_lds((real)0, smem, natoms, S.max_contact_sites, S.n_contact, false);
     L.lists = S.lists + (size_t)rep * S.list_stride;
     load_positions(pos + (size_t)rep * 3 * natoms, L, natoms);
-    for (int i = threadIdx.x; i < natoms; i += blockDim.x) { L.fx[i] = 0; L.fy[i] = 0; L.fz[i] = 0; }
     for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
     if (threadIdx.x < AWSEM_NGROUPS) L.eg[threadIdx.x] = 0;
     if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
@@ -850,7 +958,8 @@ __global__ void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__
         if (redistribute) { redistribute_forces(S, L); __syncthreads(); }
         double* f = f_out + (size_t)rep * 3 * natoms;
         for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
-            f[3 * i] = fixed_to_double(L.fx[i]); f[3 * i + 1] = fixed_to_double(L.fy[i]); f[3 * i + 2] = fixed_to_double(L.fz[i]);
+            const R3<real> F = L.force(i);
+            f[3 * i] = (double)F.x; f[3 * i + 1] = (double)F.y; f[3 * i + 2] = (double)F.z;
         }
     }
     if (ENERGY && e_out && threadIdx.x < AWSEM_NGROUPS) e_out[(size_t)rep * AWSEM_NGROUPS + threadIdx.x] = fixed_to_double(L.eg[threadIdx.x]);
@@ -861,7 +970,7 @@ template <class real>
 __global__ void awsem_list_kernel(const DevSys<real> S, const real* __restrict__ pos, unsigned mask, unsigned* __restrict__ counts /* [R][AWSEM_MAX_LISTS] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = blockIdx.x;
-    Lds<real> L = carve_lds<real>(smem, natoms, S.max_contact_sites, S.n_contact, false);
+    Lds<real> L = carve_lds((real)0, smem, natoms, S.max_contact_sites, S.n_contact, false);
     L.lists = S.lists + (size_t)rep * S.list_stride;
     load_positions(pos + (size_t)rep * 3 * natoms, L, natoms);
     if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
@@ -935,80 +1044,101 @@ __global__ void awsem_vsite_kernel(const DevSys<real> S, real* __restrict__ pos)
 }
 
 // ------------------------------------------------------------------ fused multi-step Langevin kernel
-// OpenMM LangevinIntegrator update (see oracle/awsem_oracle.c: awsem_oracle_step) with the state LDS-resident:
-// per step: virtual sites -> [pair lists, if an atom moved more than skin/2] -> forces (all groups) -> virtual-site
-// force redistribution -> v, x update.
+// OpenMM LangevinIntegrator update (see oracle/awsem_oracle.c: awsem_oracle_step) with the state LDS-resident.
+// Per step:  [pair lists, if an atom moved more than skin/2]  ->  forces (all groups, four barrier-separated phases)
+//   ->  INTEGRATE: every massive particle gathers the forces of the virtual sites it parents (owner computes: no
+//       atomics), clears its accumulator, takes the Langevin step and books its displacement since the last list build
+//   ->  VIRTUAL SITES: positions from the new parents, accumulators cleared, displacement booked.
+// The displacement maximum is double buffered (L.flag[s & 1] is read while L.flag[~s & 1] is being written).
+__device__ __forceinline__ void book_displacement(unsigned* flag, float m) {
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(flag, __float_as_uint(m));   // non-negative floats order like their bits
+}
 template <class real>
 __global__ void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, real* __restrict__ vel,
                                   const double* __restrict__ T, int nsteps, double dt, double friction, unsigned long long seed,
                                   long long step0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = blockIdx.x;
-    Lds<real> L = carve_lds<real>(smem, natoms, S.max_contact_sites, S.n_contact, true);
+    Lds<real> L = carve_lds((real)0, smem, natoms, S.max_contact_sites, S.n_contact, true);
     L.lists = S.lists + (size_t)rep * S.list_stride;
     real* gp = pos + (size_t)rep * 3 * natoms;
     real* gv = vel + (size_t)rep * 3 * natoms;
     load_positions(gp, L, natoms);
-    for (int i = threadIdx.x; i < natoms; i += blockDim.x) { L.vx[i] = gv[i]; L.vy[i] = gv[natoms + i]; L.vz[i] = gv[2 * natoms + i]; }
+    for (int i = threadIdx.x; i < natoms; i += blockDim.x) L.set_vel(i, R3<real>{gv[i], gv[natoms + i], gv[2 * natoms + i]});
+    for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
     const double a_d = ::exp(-friction * dt);
     const real a = (real)a_d, fs = (real)(friction == 0.0 ? dt : (1.0 - a_d) / friction);
     const real ns = (real)::sqrt(AWSEM_KB * T[rep] * (1.0 - a_d * a_d)), dtr = (real)dt;
     stage_tables(S, L);
-    if (threadIdx.x == 0) L.flag[0] = 0;
+    if (threadIdx.x < 2) L.flag[threadIdx.x] = 0;
+    __syncthreads();
+    compute_virtual_sites(S, L);
     __syncthreads();
     AWSEM_STAMP_INIT;
     for (int s = 0; s < nsteps; s++) {
-        compute_virtual_sites(S, L);
-        __syncthreads();
-        AWSEM_STAMP(S, 0);
-        {   // zero the accumulators; how far has any atom (virtual sites included) moved since the lists were built?
-            real m = 0;
-            for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
-            for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
-                L.fx[i] = 0; L.fy[i] = 0; L.fz[i] = 0;
-                if (s > 0) m = fmax(m, dist2(L.px[i] - L.rx[i], L.py[i] - L.ry[i], L.pz[i] - L.rz[i]));
-            }
-            if (s > 0) {
-                for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off));
-                if ((threadIdx.x & 63) == 0) atomicMax(&L.flag[0], __float_as_uint((float)m));   // non-negative floats order like their bits
-            }
-        }
-        __syncthreads();
-        AWSEM_STAMP(S, 1);
-        if (s == 0 || __uint_as_float(L.flag[0]) > (float)S.skin_half2) {   // uniform across the workgroup
+        const int cur = s & 1;
+        if (s == 0 || __uint_as_float(L.flag[cur]) > (float)S.skin_half2) {   // uniform across the workgroup
             if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
-            for (int i = threadIdx.x; i < natoms; i += blockDim.x) { L.rx[i] = L.px[i]; L.ry[i] = L.py[i]; L.rz[i] = L.pz[i]; }
+            for (int i = threadIdx.x; i < natoms; i += blockDim.x) L.set_ref(i, L.pos(i));
             __syncthreads();
             build_lists(S, L, 0xffffffffu);
             __syncthreads();
             AWSEM_STAMP(S, 2);
         }
         evaluate_terms<false>(S, L, 0xffffffffu AWSEM_STAMP_PASS);
-        redistribute_forces(S, L);
-        if (threadIdx.x == 0) L.flag[0] = 0;   // every thread has read it; the next atomicMax comes after two more barriers
-        __syncthreads();
-        AWSEM_STAMP(S, 8);
-        for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {   // compact list: no lane idles on a virtual site
-            const MassiveItem<real> mi = S.massive[k];
-            const int i = mi.atom;
-            const real im = mi.inv_mass, sq = mi.sqrt_inv_mass;
-            real g[3];
-            gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, i, g);
-            real fx = (real)fixed_to_double(L.fx[i]), fy = (real)fixed_to_double(L.fy[i]), fz = (real)fixed_to_double(L.fz[i]);
-            real vx = a * L.vx[i] + fs * im * fx + ns * sq * g[0];
-            real vy = a * L.vy[i] + fs * im * fy + ns * sq * g[1];
-            real vz = a * L.vz[i] + fs * im * fz + ns * sq * g[2];
-            L.vx[i] = vx; L.vy[i] = vy; L.vz[i] = vz;
-            L.px[i] += dtr * vx; L.py[i] += dtr * vy; L.pz[i] += dtr * vz;
+        if (threadIdx.x == 0) L.flag[cur] = 0;   // read by everyone before the barriers of the evaluation; written again next step
+        {
+            float m = 0;
+            for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {   // compact list: no lane idles on a virtual site
+                const MassiveItem<real> mi = S.massive[k];
+                const GatherItem<real> gi = S.gather[k];
+                const int i = mi.atom;
+                R3<real> F = L.force(i);
+                L.zero_force(i);
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    if (gi.vs[q] < 0) continue;
+                    const R3<real> fv = L.force(gi.vs[q]);
+                    F.x += gi.w[q] * fv.x; F.y += gi.w[q] * fv.y; F.z += gi.w[q] * fv.z;
+                }
+                real g[3];
+                gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, i, g);
+                const real im = fs * mi.inv_mass, sq = ns * mi.sqrt_inv_mass;
+                R3<real> v = L.vel(i), x = L.pos(i);
+                v.x = a * v.x + im * F.x + sq * g[0];
+                v.y = a * v.y + im * F.y + sq * g[1];
+                v.z = a * v.z + im * F.z + sq * g[2];
+                x.x += dtr * v.x; x.y += dtr * v.y; x.z += dtr * v.z;
+                L.set_vel(i, v); L.set_pos(i, x);
+                m = fmaxf(m, (float)dist2(x - L.refpos(i)));
+            }
+            book_displacement(&L.flag[cur ^ 1], m);
         }
         __syncthreads();
         AWSEM_STAMP(S, 9);
+        {
+            float m = 0;
+            for (int i = threadIdx.x; i < S.nvs; i += blockDim.x) {
+                const Int4 v = S.vs[i];
+                const real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
+                const R3<real> pa = L.pos(v.y), pb = L.pos(v.z), pc = L.pos(v.w);
+                const R3<real> x = R3<real>{w0 * pa.x + w1 * pb.x + w2 * pc.x, w0 * pa.y + w1 * pb.y + w2 * pc.y, w0 * pa.z + w1 * pb.z + w2 * pc.z};
+                L.set_pos(v.x, x);
+                L.zero_force(v.x);
+                m = fmaxf(m, (float)dist2(x - L.refpos(v.x)));
+            }
+            for (int i = threadIdx.x; i < S.nfixed; i += blockDim.x) L.zero_force(S.fixed[i]);   // massless particles that are no virtual sites
+            for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
+            book_displacement(&L.flag[cur ^ 1], m);
+        }
+        __syncthreads();
+        AWSEM_STAMP(S, 0);
     }
     AWSEM_STAMP_FLUSH(S);
-    compute_virtual_sites(S, L);
-    __syncthreads();
     for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
-        gp[i] = L.px[i]; gp[natoms + i] = L.py[i]; gp[2 * natoms + i] = L.pz[i];
-        gv[i] = L.vx[i]; gv[natoms + i] = L.vy[i]; gv[2 * natoms + i] = L.vz[i];
+        const R3<real> x = L.pos(i), v = L.vel(i);
+        gp[i] = x.x; gp[natoms + i] = x.y; gp[2 * natoms + i] = x.z;
+        gv[i] = v.x; gv[natoms + i] = v.y; gv[2 * natoms + i] = v.z;
     }
 }

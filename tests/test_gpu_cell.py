@@ -58,7 +58,10 @@ def test_cell_path_equals_resident_path(protein, precision, monkeypatch):
     assert np.abs(ea).sum() > 0 and np.abs(ea - eb).max() <= atol, np.abs(ea - eb).max()
     for redistribute in (False, True):
         fa, fb = a.forces(redistribute=redistribute), b.forces(redistribute=redistribute)
-        assert np.abs(fa - fb).max() <= atol, np.abs(fa - fb).max()
+        # fp32: the resident path books forces as Q19.12 (2.4e-4 kJ/mol/nm per bit, x/y packed in one LDS word), the cell
+        # path as Q31.32 -> agreement to a few bits of the coarser format, i.e. ~1e-5 of the largest force
+        ftol = atol if precision == 1 else 1e-5 * np.abs(fb).max() + 1e-3
+        assert np.abs(fa - fb).max() <= ftol, np.abs(fa - fb).max()
     # single group masks take the same route
     assert np.abs(a.energy(1 << 22) - b.energy(1 << 22)).max() <= atol
     # the cell path itself is deterministic although its list order is not
