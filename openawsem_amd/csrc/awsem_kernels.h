@@ -1054,8 +1054,11 @@ __device__ __forceinline__ void book_displacement(unsigned* flag, float m) {
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
     if ((threadIdx.x & 63) == 0) atomicMax(flag, __float_as_uint(m));   // non-negative floats order like their bits
 }
+#ifndef AWSEM_STEP_ATTR
+#define AWSEM_STEP_ATTR
+#endif
 template <class real>
-__global__ void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, real* __restrict__ vel,
+__global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, real* __restrict__ vel,
                                   const double* __restrict__ T, int nsteps, double dt, double friction, unsigned long long seed,
                                   long long step0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
