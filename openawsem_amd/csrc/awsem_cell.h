@@ -1,51 +1,63 @@
 // awsem_cell.h -- cell-list path: systems whose replica does not fit the LDS of one CU (tens of thousands of residues).
 //
-// State lives in HBM (SoA positions / velocities, int64 fixed-point force accumulators); one evaluation is a short
-// sequence of grid-wide kernels:
-//   [when an atom has moved more than skin/2 since the last build]
-//     bounding box -> cell grid (edge >= cutoff + skin) -> counting sort of the atoms into cells ->
-//     neighbour lists of the contact and the excluded-volume term (27-cell scan per atom, wave-compacted appends)
-//   zero accumulators -> bonded terms (one lane per item) -> contact density -> per-site pass -> pair pass ->
-//   chain-rule pass -> excluded volume -> [virtual-site force redistribution -> Langevin update]
-// The per-pair arithmetic is the same code as on the replica-resident path (the *_body functions of awsem_kernels.h
-// work on an `Lds` view, here filled with global pointers), so both paths compute the same contributions;
-// all sums are fixed point, so the result does not depend on the (non-deterministic) order of the list entries.
+// State lives in HBM (SoA positions / velocities, int64 fixed-point force accumulators).  The pair terms are
+// evaluated OWNER-COMPUTES from FULL neighbour lists: every contact site (excluded-volume atom) owns one row of a
+// fixed-stride list holding all its partners, a group of 16 lanes (one DPP row of the wavefront) walks that row,
+// reduces its partial sums across the 16 lanes and the row leader adds the result to the owner's accumulator with a
+// plain read-modify-write -- no atomics in any pair pass, at the price of meeting every pair from both sides.
+// One MD step is a short fixed sequence of grid-wide kernels on the handle's stream:
+//   pre (virtual sites, displacement test, bounding box, packed site records)
+//   [grid -> count -> scan -> fill -> neighbour rows: all exit at once unless an atom moved more than skin/2]
+//   bonded terms -> density + per-site pass + excluded volume -> pair pass -> chain-rule pass ->
+//   integrate (gathers the virtual-site forces of each massive particle, Langevin update)
+// The per-pair arithmetic is the same code as on the replica-resident path (awsem_kernels.h); all sums are fixed
+// point, so the result does not depend on the (non-deterministic) order of the list entries.
 #pragma once
 #include "awsem_kernels.h"
 
 #define AWSEM_CELL_MAXDIM 64
 #define AWSEM_CELL_MAXCELLS (AWSEM_CELL_MAXDIM * AWSEM_CELL_MAXDIM * AWSEM_CELL_MAXDIM)
+#define AWSEM_ROW 16   // lanes that share one list row
+#define AWSEM_WIN 512        // atoms per window of the bonded-term kernel
+#define AWSEM_WIN_SPAN 768   // atoms a window's LDS holds: its own and the next half window (items reach forward along the chain)
 
-template <class real> struct CellSys {
-    int natoms, nrep, nsites;   // nsites: sites of the contact term (0 if none)
-    // static roles of the atoms
-    const int* c_site;          // [natoms] site index in contact term 0, or -1
-    const int* x_slot;          // [natoms] slot in the class-sorted table of excl term 0 (ExclD::atom / partners), or -1
-    const int* x_cls;           // [natoms] excluded-volume class, or -1
-    // cell grid, per replica
-    int* bbox;                  // [R][8]  order-preserving int images of min xyz (0..2) and max xyz (4..6)
+// One binning = the members of one listed term (bin 0: contact sites, bin 1: excluded-volume atoms) sorted into a
+// uniform grid whose cell edge is at least that term's cutoff + skin.
+template <class real> struct CellBin {
+    int n;                      // members
+    const int* atom;            // [n] member -> atom
+    real edge_min;              // cutoff + skin
+    real rc2;                   // (cutoff + skin)^2 of the list
+    int stride;                 // list row length (multiple of AWSEM_ROW)
+    // per replica
     real* grid;                 // [R][4]  origin xyz, 1/edge
     int* dims;                  // [R][4]  nx, ny, nz, ncells
     int* cell_count;            // [R][MAXCELLS]
     int* cell_start;            // [R][MAXCELLS + 1]
-    int* cell_of;               // [R][natoms]
-    int* cell_atoms;            // [R][natoms] atom ids sorted by cell
-    // neighbour lists, per replica
-    u64* clist;                 // contact: site_i | site_j << 24 | type pair << 48 | in_density << 57 | has_pair_energy << 58
-    u64* xlist;                 // excl: atom_a | atom_b << 32
-    unsigned* counts;           // [R][2] entries in clist, xlist
-    long long ccap, xcap;
+    int* tile_sum;              // [R][MAXCELLS / 1024] members per tile of 1024 cells
+    int* cell_of;               // [R][n]
+    int* sorted;                // [R][n] member ids in cell order
+    real* rec;                  // [R][n][4] packed member records: x, y, z, tag (bits)
+    unsigned* rows;             // [R][n][stride] neighbour rows (member ids, flags in the top bits)
+    int* row_count;             // [R][n]
+};
+
+template <class real> struct CellSys {
+    int natoms, nrep, nsites;   // nsites: sites of the contact term (0 if none)
+    CellBin<real> bin[2];
+    const Int4* x_partners;     // [bin[1].n] excluded partner atoms of each excluded-volume member
+    const int* x_class;         // [bin[1].n] excluded-volume class of each member
+    int* bbox;                  // [R][nblk_pre][8] per-workgroup bounding boxes of the pre kernel: order-preserving int images of min xyz (0..2), max xyz (4..6)
+    int nblk_pre;
+    unsigned* flag;             // [R][2]   != 0 -> a member moved further than skin/2 since the last build, double buffered
     // accumulators, per replica
     u64* f;                     // [R][3][natoms]
     u64* eg;                    // [R][32]
     u64 *rho, *drho;            // [R][nsites]
     real *rhov, *alpha, *dalpha;
-    // list validity
     real* ref;                  // [R][3][natoms] positions at the last build
-    unsigned* flag;             // [R][2]: [0] != 0 -> an atom moved further than skin/2, [1] != 0 -> rebuild in progress
-    real rc_cell;               // minimum cell edge = largest (cutoff + skin)
     real skin_half2;
-    int* status;                // bit 1: neighbour list overflow
+    int* status;                // bit 1: neighbour row overflow
 };
 
 __device__ __forceinline__ int ordered_int(float f) { int o = __float_as_int(f); return o >= 0 ? o : o ^ 0x7fffffff; }
@@ -73,272 +85,419 @@ template <class real> __device__ inline CellView<real> cell_view(const DevSys<re
     return L;
 }
 
-// ------------------------------------------------------------------ list validity and cell grid
-// grid (blocks, R).  Largest squared displacement since the last build; `force` marks the lists stale regardless.
-template <class real> __global__ void cell_displacement_kernel(CellSys<real> C, const real* __restrict__ pos, int force) {
+template <class real> struct alignas(4 * sizeof(real)) Rec { real x, y, z, tag; };
+__device__ __forceinline__ int tag_bits(float t) { return __float_as_int(t); }
+__device__ __forceinline__ int tag_bits(double t) { return (int)__double_as_longlong(t); }
+__device__ __forceinline__ float make_tag(int b, float) { return __int_as_float(b); }
+__device__ __forceinline__ double make_tag(int b, double) { return __longlong_as_double((long long)(unsigned)b); }
+
+// sum over the 16 lanes of a row; every lane of the row receives the total
+__device__ __forceinline__ u64 row_sum(u64 v) {
+#pragma unroll
+    for (int off = 1; off < AWSEM_ROW; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ------------------------------------------------------------------ pre kernel (every step / evaluation)
+// grid (blocks, R), one pass.  (1) STEP only: virtual sites placed, their accumulators cleared for the coming
+// evaluation, as are those of massless particles that are no sites; (2) for the list members: has one moved further than skin/2
+// since the last build, and the bounding box; (3) packed member records.  `cur` selects the flag this step
+// writes and the rebuild kernels read; the other one is reset for the next step.
+// List members are massive particles (checked at finalize), so (1) and (2) touch different atoms.
+template <bool STEP, class real> __global__ void cell_pre_kernel(DevSys<real> S, CellSys<real> C, real* __restrict__ pos, int cur) {
     const int rep = blockIdx.y, n = C.natoms;
-    const real* p = pos + (size_t)rep * 3 * n;
+    real* p = pos + (size_t)rep * 3 * n;
     const real* q = C.ref + (size_t)rep * 3 * n;
-    bool moved = force != 0;
-    if (!force)
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-            moved |= (float)dist2(p[i] - q[i], p[n + i] - q[n + i], p[2 * n + i] - q[2 * n + i]) > (float)C.skin_half2;
-    if (__ballot(moved) && (threadIdx.x & 63) == 0) C.flag[2 * rep] = 1u;   // same value from every writer: no atomic needed
-}
-// one thread per replica: decide, and reset what a rebuild accumulates into
-template <class real> __global__ void cell_decide_kernel(CellSys<real> C) {
-    const int rep = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rep >= C.nrep) return;
-    const bool rebuild = C.flag[2 * rep] != 0;
-    C.flag[2 * rep + 1] = rebuild ? 1u : 0u;
-    C.flag[2 * rep] = 0;
-    if (rebuild) {
-        for (int k = 0; k < 3; k++) { C.bbox[8 * rep + k] = 0x7fffffff; C.bbox[8 * rep + 4 + k] = (int)0x80000000; }
-        C.counts[2 * rep] = 0; C.counts[2 * rep + 1] = 0;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (STEP) {   // the evaluation API uses the stored site coordinates as given (as OpenMM does after setPositions)
+        u64* f = C.f + (size_t)rep * 3 * n;
+        if (t < S.nvs) {
+            const Int4 v = S.vs[t];
+            const real w0 = S.vs_w[3 * t], w1 = S.vs_w[3 * t + 1], w2 = S.vs_w[3 * t + 2];
+            for (int k = 0; k < 3; k++) p[(size_t)k * n + v.x] = w0 * p[(size_t)k * n + v.y] + w1 * p[(size_t)k * n + v.z] + w2 * p[(size_t)k * n + v.w];
+            f[v.x] = 0; f[n + v.x] = 0; f[2 * (size_t)n + v.x] = 0;
+        }
+        if (t < S.nfixed) { const int a = S.fixed[t]; f[a] = 0; f[n + a] = 0; f[2 * (size_t)n + a] = 0; }
     }
-}
-template <class real> __global__ void cell_bbox_kernel(CellSys<real> C, const real* __restrict__ pos) {
-    const int rep = blockIdx.y, n = C.natoms;
-    if (!C.flag[2 * rep + 1]) return;
-    const real* p = pos + (size_t)rep * 3 * n;
-    real* q = C.ref + (size_t)rep * 3 * n;
     __shared__ int slo[3], shi[3];
     if (threadIdx.x < 3) { slo[threadIdx.x] = 0x7fffffff; shi[threadIdx.x] = (int)0x80000000; }
     __syncthreads();
+    const int n0 = C.bin[0].n, n1 = C.bin[1].n;
+    const bool member = t < n0 + n1;
+    bool moved = false;
     float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    if (member) {
+        const int b = t < n0 ? 0 : 1, m = t - (b ? n0 : 0);
+        const int a = C.bin[b].atom[m];
+        const real x = p[a], y = p[n + a], z = p[2 * (size_t)n + a];
+        moved = (float)dist2(x - q[a], y - q[n + a], z - q[2 * (size_t)n + a]) > (float)C.skin_half2;
+        lo[0] = hi[0] = (float)x; lo[1] = hi[1] = (float)y; lo[2] = hi[2] = (float)z;
+        const int tag = b == 0 ? S.contact[0].info[m] : a;   // excluded volume: the atom index (partners are listed by atom)
+        Rec<real>* rec = (Rec<real>*)C.bin[b].rec + (size_t)rep * C.bin[b].n;
+        rec[m] = Rec<real>{x, y, z, make_tag(tag, (real)0)};
+    }
+    if (__ballot(moved) && (threadIdx.x & 63) == 0) C.flag[2 * rep + cur] = 1u;   // same value from every writer: no atomic needed
+    if (__ballot(member)) {
         for (int k = 0; k < 3; k++) {
-            const real x = p[k * n + i];
-            q[k * n + i] = x;   // new reference positions
-            lo[k] = fminf(lo[k], (float)x); hi[k] = fmaxf(hi[k], (float)x);
+            for (int off = 32; off > 0; off >>= 1) { lo[k] = fminf(lo[k], __shfl_down(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_down(hi[k], off)); }
+            if ((threadIdx.x & 63) == 0) { atomicMin(&slo[k], ordered_int(lo[k])); atomicMax(&shi[k], ordered_int(hi[k])); }
         }
-    for (int k = 0; k < 3; k++) {
-        for (int off = 32; off > 0; off >>= 1) { lo[k] = fminf(lo[k], __shfl_down(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_down(hi[k], off)); }
-        if ((threadIdx.x & 63) == 0) { atomicMin(&slo[k], ordered_int(lo[k])); atomicMax(&shi[k], ordered_int(hi[k])); }
     }
     __syncthreads();
-    if (threadIdx.x < 3) { atomicMin(&C.bbox[8 * rep + threadIdx.x], slo[threadIdx.x]); atomicMax(&C.bbox[8 * rep + 4 + threadIdx.x], shi[threadIdx.x]); }
+    int* bb = C.bbox + ((size_t)rep * C.nblk_pre + blockIdx.x) * 8;   // read by cell_geom_kernel of this step only
+    if (threadIdx.x < 3) { bb[threadIdx.x] = slo[threadIdx.x]; bb[4 + threadIdx.x] = shi[threadIdx.x]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) C.flag[2 * rep + (cur ^ 1)] = 0;   // nobody reads or writes the other flag during this step
 }
-// grid (ceil(MAXCELLS / block), R): grid geometry (every thread derives the same numbers) and zeroed cell counts
-template <class real> __global__ void cell_grid_kernel(CellSys<real> C) {
-    const int rep = blockIdx.y;
-    if (!C.flag[2 * rep + 1]) return;
+
+// ------------------------------------------------------------------ rebuild (all kernels exit at once unless flagged)
+// blockIdx.y = 2 * rep + bin
+template <class real> __device__ __forceinline__ bool cell_rebuild(const CellSys<real>& C, int rep, int cur, int force) { return force || C.flag[2 * rep + cur] != 0; }
+
+// one 1024-thread workgroup per (replica, bin): bounding box from the pre kernel's per-workgroup boxes, grid geometry,
+// zeroed cell and tile counts
+template <class real> __global__ void cell_geom_kernel(CellSys<real> C, int cur, int force) {
+    const int rep = blockIdx.x >> 1, b = blockIdx.x & 1;
+    const CellBin<real>& B = C.bin[b];
+    if (B.n == 0 || !cell_rebuild(C, rep, cur, force)) return;
+    __shared__ int slo[3], shi[3];
+    if (threadIdx.x < 3) { slo[threadIdx.x] = 0x7fffffff; shi[threadIdx.x] = (int)0x80000000; }
+    __syncthreads();
+    for (int k = 0; k < 3; k++) {
+        int lo = 0x7fffffff, hi = (int)0x80000000;
+        for (int w = threadIdx.x; w < C.nblk_pre; w += blockDim.x) {
+            const int* bb = C.bbox + ((size_t)rep * C.nblk_pre + w) * 8;
+            lo = min(lo, bb[k]); hi = max(hi, bb[4 + k]);
+        }
+        for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off)); hi = max(hi, __shfl_down(hi, off)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&slo[k], lo); atomicMax(&shi[k], hi); }
+    }
+    __syncthreads();
     float lo[3], ext = 0;
     for (int k = 0; k < 3; k++) {
-        lo[k] = ordered_float(C.bbox[8 * rep + k]) - 1e-3f;
-        ext = fmaxf(ext, ordered_float(C.bbox[8 * rep + 4 + k]) + 1e-3f - lo[k]);
+        lo[k] = ordered_float(slo[k]) - 1e-3f;
+        ext = fmaxf(ext, ordered_float(shi[k]) + 1e-3f - lo[k]);
     }
-    const float edge = fmaxf((float)C.rc_cell, ext / (float)AWSEM_CELL_MAXDIM * 1.0001f);
+    const float edge = fmaxf((float)B.edge_min, ext / (float)AWSEM_CELL_MAXDIM * 1.0001f);
     int nd[3];
     for (int k = 0; k < 3; k++) {
-        nd[k] = (int)floorf((ordered_float(C.bbox[8 * rep + 4 + k]) + 1e-3f - lo[k]) / edge) + 1;
+        nd[k] = (int)floorf((ordered_float(shi[k]) + 1e-3f - lo[k]) / edge) + 1;
         nd[k] = nd[k] > AWSEM_CELL_MAXDIM ? AWSEM_CELL_MAXDIM : nd[k];
     }
-    const int ncell = nd[0] * nd[1] * nd[2], c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0) {
-        for (int k = 0; k < 3; k++) { C.grid[4 * rep + k] = (real)lo[k]; C.dims[4 * rep + k] = nd[k]; }
-        C.grid[4 * rep + 3] = (real)(1.0f / edge);
-        C.dims[4 * rep + 3] = ncell;
+    const int ncell = nd[0] * nd[1] * nd[2];
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 3; k++) { B.grid[4 * rep + k] = (real)lo[k]; B.dims[4 * rep + k] = nd[k]; }
+        B.grid[4 * rep + 3] = (real)(1.0f / edge);
+        B.dims[4 * rep + 3] = ncell;
     }
-    if (c < ncell) C.cell_count[(size_t)rep * AWSEM_CELL_MAXCELLS + c] = 0;
+    for (int c = threadIdx.x; c < ncell; c += blockDim.x) B.cell_count[(size_t)rep * AWSEM_CELL_MAXCELLS + c] = 0;
+    for (int c = threadIdx.x; c < AWSEM_CELL_MAXCELLS / 1024; c += blockDim.x) B.tile_sum[(size_t)rep * (AWSEM_CELL_MAXCELLS / 1024) + c] = 0;
 }
-template <class real> __device__ __forceinline__ void cell_coords(const CellSys<real>& C, int rep, real x, real y, real z, int c[3]) {
-    const real inv = C.grid[4 * rep + 3];
+// cell coordinates from the grid geometry stored by cell_geom_kernel
+template <class real> __device__ __forceinline__ void cell_coords(const CellBin<real>& B, int rep, real x, real y, real z, int c[3]) {
+    const real inv = B.grid[4 * rep + 3];
     const real v[3] = {x, y, z};
     for (int k = 0; k < 3; k++) {
-        int t = (int)M<real>::floor((v[k] - C.grid[4 * rep + k]) * inv);
-        const int nk = C.dims[4 * rep + k];
+        int t = (int)M<real>::floor((v[k] - B.grid[4 * rep + k]) * inv);
+        const int nk = B.dims[4 * rep + k];
         c[k] = t < 0 ? 0 : (t >= nk ? nk - 1 : t);
     }
 }
-template <class real> __global__ void cell_count_kernel(CellSys<real> C, const real* __restrict__ pos) {
-    const int rep = blockIdx.y, n = C.natoms;
-    if (!C.flag[2 * rep + 1]) return;
+// grid (blocks, 2R): cell of every member, cell populations, new reference positions
+template <class real> __global__ void cell_count_kernel(CellSys<real> C, const real* __restrict__ pos, int cur, int force) {
+    const int rep = blockIdx.y >> 1, b = blockIdx.y & 1, n = C.natoms;
+    const CellBin<real>& B = C.bin[b];
+    if (!cell_rebuild(C, rep, cur, force)) return;
     const real* p = pos + (size_t)rep * 3 * n;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (C.c_site[i] < 0 && C.x_cls[i] < 0) { C.cell_of[(size_t)rep * n + i] = -1; continue; }   // only atoms that are a site of a listed term
-        int c[3];
-        cell_coords(C, rep, p[i], p[n + i], p[2 * n + i], c);
-        const int cell = (c[2] * C.dims[4 * rep + 1] + c[1]) * C.dims[4 * rep] + c[0];
-        C.cell_of[(size_t)rep * n + i] = cell;
-        atomicAdd(&C.cell_count[(size_t)rep * AWSEM_CELL_MAXCELLS + cell], 1);
-    }
-}
-// one 1024-thread workgroup per replica: exclusive scan of the cell counts; the counts are zeroed for the fill pass
-template <class real> __global__ void cell_scan_kernel(CellSys<real> C) {
-    const int rep = blockIdx.x;
-    if (!C.flag[2 * rep + 1]) return;
-    __shared__ int part[1024];
-    const int ncell = C.dims[4 * rep + 3], per = (ncell + 1023) / 1024;
-    int* cnt = C.cell_count + (size_t)rep * AWSEM_CELL_MAXCELLS;
-    int* start = C.cell_start + (size_t)rep * (AWSEM_CELL_MAXCELLS + 1);
-    const int b = threadIdx.x * per, e = min(b + per, ncell);
-    int s = 0;
-    for (int c = b; c < e; c++) s += cnt[c];
-    part[threadIdx.x] = s;
+    real* q = C.ref + (size_t)rep * 3 * n;
+    // tile populations: same-address global atomics from many workgroups serialise (~0.1 us each), so each workgroup
+    // first histograms its members' tiles in LDS and then books every tile it met once
+    __shared__ int hist[AWSEM_CELL_MAXCELLS / 1024];
+    for (int t = threadIdx.x; t < AWSEM_CELL_MAXCELLS / 1024; t += blockDim.x) hist[t] = 0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partial sums
-        int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < B.n; m += gridDim.x * blockDim.x) {
+        const int a = B.atom[m];
+        const real x = p[a], y = p[n + a], z = p[2 * (size_t)n + a];
+        q[a] = x; q[n + a] = y; q[2 * (size_t)n + a] = z;
+        int c[3];
+        cell_coords(B, rep, x, y, z, c);
+        const int cell = (c[2] * B.dims[4 * rep + 1] + c[1]) * B.dims[4 * rep] + c[0];
+        B.cell_of[(size_t)rep * B.n + m] = cell;
+        atomicAdd(&B.cell_count[(size_t)rep * AWSEM_CELL_MAXCELLS + cell], 1);
+        atomicAdd(&hist[cell >> 10], 1);
     }
-    int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-    for (int c = b; c < e; c++) { start[c] = run; run += cnt[c]; cnt[c] = 0; }
-    if (threadIdx.x == 1023) start[ncell] = part[1023];
+    __syncthreads();
+    for (int t = threadIdx.x; t < AWSEM_CELL_MAXCELLS / 1024; t += blockDim.x)
+        if (hist[t]) atomicAdd(&B.tile_sum[(size_t)rep * (AWSEM_CELL_MAXCELLS / 1024) + t], hist[t]);
 }
-template <class real> __global__ void cell_fill_kernel(CellSys<real> C) {
-    const int rep = blockIdx.y, n = C.natoms;
-    if (!C.flag[2 * rep + 1]) return;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int cell = C.cell_of[(size_t)rep * n + i];
-        if (cell < 0) continue;
-        const int slot = C.cell_start[(size_t)rep * (AWSEM_CELL_MAXCELLS + 1) + cell] + atomicAdd(&C.cell_count[(size_t)rep * AWSEM_CELL_MAXCELLS + cell], 1);
-        C.cell_atoms[(size_t)rep * n + slot] = i;
+// grid (MAXCELLS / 1024, 2R), 1024 threads: exclusive scan of the cell counts, one tile of 1024 cells per workgroup (its
+// offset is the sum of the tile populations before it, booked by cell_count_kernel); the counts are zeroed for the fill pass
+template <class real> __global__ void cell_scan_kernel(CellSys<real> C, int cur, int force) {
+    const int rep = blockIdx.y >> 1, b = blockIdx.y & 1;
+    const CellBin<real>& B = C.bin[b];
+    if (B.n == 0 || !cell_rebuild(C, rep, cur, force)) return;
+    const int ncell = B.dims[4 * rep + 3], tile = blockIdx.x, c = tile * 1024 + threadIdx.x;
+    if (tile * 1024 >= ncell) return;
+    __shared__ int wsum[16], base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    const int* ts = B.tile_sum + (size_t)rep * (AWSEM_CELL_MAXCELLS / 1024);
+    int before = threadIdx.x < tile ? ts[threadIdx.x] : 0;   // at most 256 tiles
+    if (threadIdx.x < 256) {
+        for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+        if ((threadIdx.x & 63) == 0 && before) atomicAdd(&base, before);
+    }
+    int* cnt = B.cell_count + (size_t)rep * AWSEM_CELL_MAXCELLS;
+    int* start = B.cell_start + (size_t)rep * (AWSEM_CELL_MAXCELLS + 1);
+    const int mine = c < ncell ? cnt[c] : 0;
+    int incl = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; w++) woff += wsum[w];
+    const int excl = base + woff + incl - mine;
+    if (c < ncell) { start[c] = excl; cnt[c] = 0; }
+    if (c == ncell - 1) start[ncell] = excl + mine;
+}
+template <class real> __global__ void cell_fill_kernel(CellSys<real> C, int cur, int force) {
+    const int rep = blockIdx.y >> 1, b = blockIdx.y & 1;
+    const CellBin<real>& B = C.bin[b];
+    if (!cell_rebuild(C, rep, cur, force)) return;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < B.n; m += gridDim.x * blockDim.x) {
+        const int cell = B.cell_of[(size_t)rep * B.n + m];
+        const int slot = B.cell_start[(size_t)rep * (AWSEM_CELL_MAXCELLS + 1) + cell] + atomicAdd(&B.cell_count[(size_t)rep * AWSEM_CELL_MAXCELLS + cell], 1);
+        B.sorted[(size_t)rep * B.n + slot] = m;
     }
 }
 
-// wave-compacted append to a global list
-__device__ __forceinline__ void cell_append(u64* __restrict__ e, unsigned* cnt, long long cap, int* status, bool pass, u64 entry) {
-    const u64 m = __ballot(pass);
-    if (m == 0) return;
-    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-    unsigned base = 0;
-    if (lane == leader) base = atomicAdd(cnt, (unsigned)__popcll(m));
-    base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
-    const unsigned off = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-    if (pass) {
-        if ((long long)base + off < cap) e[base + off] = entry;
-        else atomicOr(status, 2);
-    }
-}
-
-// One lane per binned atom, in cell order: scan the HALF shell of cells around it (the rest of its own cell and of
-// the x-row behind it, then the 4 rows of 3 cells "above"), so that every pair is met exactly once.  Both lists in
-// one sweep.  rc2c / rc2x: (cutoff + skin)^2 of the contact / excluded-volume term (<= 0 disables that list).
-template <class real> __global__ void cell_list_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos, real rc2c, real rc2x) {
-    const int rep = blockIdx.y, n = C.natoms;
-    if (!C.flag[2 * rep + 1]) return;
-    const real* p = pos + (size_t)rep * 3 * n;
-    const int* catoms = C.cell_atoms + (size_t)rep * n;
-    const int* cstart = C.cell_start + (size_t)rep * (AWSEM_CELL_MAXCELLS + 1);
-    u64* cl = C.clist + (size_t)rep * C.ccap;
-    u64* xl = C.xlist + (size_t)rep * C.xcap;
-    const int nx = C.dims[4 * rep], ny = C.dims[4 * rep + 1], nz = C.dims[4 * rep + 2];
-    const int nb = cstart[C.dims[4 * rep + 3]];   // binned atoms
-    const int ntot = (nb + 63) & ~63;             // whole waves: the appends are wave collectives
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < ntot; k += gridDim.x * blockDim.x) {
-        const bool vi = k < nb;
-        const int i = vi ? catoms[k] : 0;
-        const real xi = p[i], yi = p[n + i], zi = p[2 * n + i];
-        const int si = vi && rc2c > (real)0 ? C.c_site[i] : -1;
-        const int xi_cls = vi && rc2x > (real)0 ? C.x_cls[i] : -1;
+// Neighbour rows.  16 lanes per member (members taken in cell order, so a wave works on four neighbours in space):
+// the 27 cells around the member are 9 runs of 3 consecutive cells in the sorted member array; the 16 lanes test 16
+// candidates at a time and the passing ones are compacted into the member's row with a ballot -- the row count is a
+// register of the row, no atomics.  blockIdx.y = 2 * rep + bin.
+//   bin 0 (contact): entry = site_j | in_density << 30 | has_pair_energy << 31
+//   bin 1 (excl):    entry = member_j   (same class, not an excluded partner)
+template <class real> __global__ void cell_rows_kernel(DevSys<real> S, CellSys<real> C, int cur, int force) {
+    const int rep = blockIdx.y >> 1, b = blockIdx.y & 1;
+    const CellBin<real>& B = C.bin[b];
+    if (!cell_rebuild(C, rep, cur, force)) return;
+    const Rec<real>* rec = (const Rec<real>*)B.rec + (size_t)rep * B.n;
+    const int* sorted = B.sorted + (size_t)rep * B.n;
+    const int* cstart = B.cell_start + (size_t)rep * (AWSEM_CELL_MAXCELLS + 1);
+    unsigned* rows = B.rows + (size_t)rep * B.n * B.stride;
+    const int nx = B.dims[4 * rep], ny = B.dims[4 * rep + 1], nz = B.dims[4 * rep + 2];
+    const int sub = threadIdx.x & (AWSEM_ROW - 1), row_in_wave = (threadIdx.x & 63) / AWSEM_ROW;
+    const int nrows_total = (B.n + 3) & ~3;   // whole waves: the ballots are wave collectives
+    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows_total; k += gridDim.x * blockDim.x / AWSEM_ROW) {
+        const bool vi = k < B.n;
+        const int i = vi ? sorted[k] : 0;
+        const Rec<real> ri = rec[i];
+        const int tag_i = tag_bits(ri.tag);
         int c[3] = {0, 0, 0};
-        if (vi) cell_coords(C, rep, xi, yi, zi, c);
-        int info_i = 0;
+        if (vi) cell_coords(B, rep, ri.x, ri.y, ri.z, c);
         Int4 part = {-1, -1, -1, -1};
-        if (si >= 0) info_i = S.contact[0].info[si];
-        if (xi_cls >= 0) part = S.excl[0].partners[C.x_slot[i]];
-        for (int row = 0; row < 5; row++) {
-            // row 0: own row, from the entry after this atom to the end of cell x+1; rows 1..4: (dy,dz) = (1,0), (-1,1), (0,1), (1,1)
-            const int dy = row == 0 ? 0 : (row == 1 ? 1 : row - 3), dz = row < 2 ? 0 : 1;
-            const int cz = c[2] + dz, cy = c[1] + dy;
-            const bool vrow = vi && (si >= 0 || xi_cls >= 0) && cz < nz && cy >= 0 && cy < ny;
+        int cls_i = 0;
+        if (b == 1 && vi) { part = C.x_partners[i]; cls_i = C.x_class[i]; }
+        int cnt = 0;
+        for (int cell_row = 0; cell_row < 9; cell_row++) {
+            const int cy = c[1] + cell_row % 3 - 1, cz = c[2] + cell_row / 3 - 1;
+            const bool vrow = vi && cy >= 0 && cy < ny && cz >= 0 && cz < nz;
             const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, nx - 1);
             const int base = (cz * ny + cy) * nx;
-            int q = vrow ? (row == 0 ? k + 1 : cstart[base + x0]) : 0;
+            int q = vrow ? cstart[base + x0] + sub : 0;
             const int qe = vrow ? cstart[base + x1 + 1] : 0;
             while (__ballot(q < qe)) {
                 const bool vq = q < qe;
-                const int j = vq ? catoms[q] : i;
-                q++;
-                const real r2 = dist2(xi - p[j], yi - p[n + j], zi - p[2 * n + j]);
-                bool pc = false;
-                u64 ec = 0;
-                if (vq && si >= 0 && r2 < rc2c) {
-                    const int sj = C.c_site[j];
-                    if (sj >= 0) {
-                        const ContactD<real>& d = S.contact[0];
-                        const int info_j = d.info[sj], dres = (info_j & 0xffff) - (info_i & 0xffff);
-                        const bool in_rho = dres >= 2 || dres <= -2;
-                        const bool pair_e = !(d.flags & 2) && ((((info_i ^ info_j) >> 16) & 0x7ff) != 0 || dres >= d.min_seq_sep || -dres >= d.min_seq_sep);
-                        pc = in_rho || pair_e;
-                        const u64 ty = (u64)(((info_i >> 27) & 31) * 20 + ((info_j >> 27) & 31));
-                        ec = (u64)si | ((u64)sj << 24) | (ty << 48) | ((u64)in_rho << 57) | ((u64)pair_e << 58);
-                    }
+                const int j = vq ? sorted[q] : i;
+                q += AWSEM_ROW;
+                const Rec<real> rj = rec[j];
+                const real r2 = dist2(ri.x - rj.x, ri.y - rj.y, ri.z - rj.z);
+                bool pass = vq && j != i && r2 < B.rc2;
+                unsigned ent = (unsigned)j;
+                if (b == 0) {
+                    const ContactD<real>& d = S.contact[0];
+                    const int tag_j = tag_bits(rj.tag), dres = (tag_j & 0xffff) - (tag_i & 0xffff);
+                    const bool in_rho = dres >= 2 || dres <= -2;
+                    const bool pair_e = !(d.flags & 2) && ((((tag_i ^ tag_j) >> 16) & 0x7ff) != 0 || dres >= d.min_seq_sep || -dres >= d.min_seq_sep);
+                    pass = pass && (in_rho || pair_e);
+                    ent |= (in_rho ? 0x40000000u : 0u) | (pair_e ? 0x80000000u : 0u);
+                } else if (pass) {
+                    const int aj = tag_bits(rj.tag);
+                    pass = C.x_class[j] == cls_i && part.x != aj && part.y != aj && part.z != aj && part.w != aj;
                 }
-                cell_append(cl, &C.counts[2 * rep], C.ccap, C.status, pc, ec);
-                const bool px = vq && xi_cls >= 0 && r2 < rc2x && C.x_cls[j] == xi_cls &&
-                                part.x != j && part.y != j && part.z != j && part.w != j;
-                cell_append(xl, &C.counts[2 * rep + 1], C.xcap, C.status, px, (u64)(unsigned)i | ((u64)(unsigned)j << 32));
+                const unsigned rowmask = (unsigned)(__ballot(pass) >> (row_in_wave * AWSEM_ROW)) & 0xffffu;
+                if (pass) {
+                    const int slot = cnt + __popc(rowmask & ((1u << sub) - 1u));
+                    if (slot < B.stride) rows[(size_t)i * B.stride + slot] = ent;
+                    else atomicOr(C.status, 2);
+                }
+                cnt += __popc(rowmask);
             }
         }
+        if (vi && sub == 0) B.row_count[(size_t)rep * B.n + i] = min(cnt, B.stride);
     }
 }
 
-// ------------------------------------------------------------------ evaluation from the lists (grid (blocks, R))
-template <class real> __global__ void cell_density_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos) {
+// ------------------------------------------------------------------ evaluation from the rows (grid (blocks, R))
+// The leader of a row adds the row's force to the owner's accumulator: a plain read-modify-write, because within one
+// of these kernels nobody else touches that atom (kernels on the stream run one after the other).
+template <class real> __device__ __forceinline__ void owner_add_force(const CellView<real>& L, int atom, u64 X, u64 Y, u64 Z) {
+    L.fx[atom] += X; L.fy[atom] += Y; L.fz[atom] += Z;
+}
+#define AWSEM_ROW_LOOP(B, k)                                                                                              \
+    const int sub = threadIdx.x & (AWSEM_ROW - 1);                                                                        \
+    const int nrows_ = ((B).n + 3) & ~3;                                                                                  \
+    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows_; k += gridDim.x * blockDim.x / AWSEM_ROW)
+
+// pass 1: rho_i, then the per-site pass (burial wells, water switch, dE/drho seed) by the row leader;
+// blocks from `nb_contact` on evaluate the excluded volume (its rows live in bin 1).
+template <bool ENERGY, class real> __global__ void cell_density_excl_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos, int nb_contact, unsigned mask) {
     const int rep = blockIdx.y;
     const CellView<real> L = cell_view(S, C, pos, rep);
-    const ContactD<real>& d = S.contact[0];
-    const u64* e = C.clist + (size_t)rep * C.ccap;
-    const int count = (int)min((long long)C.counts[2 * rep], C.ccap), ntot = (count + 63) & ~63;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < ntot; k += gridDim.x * blockDim.x) {
-        const bool v = k < count;
-        const u64 ent = v ? e[k] : 0;
-        const int i = (int)(ent & 0xffffff), j = (int)((ent >> 24) & 0xffffff);
-        density_body(d, L, i, j, L.satom[i], L.satom[j], v && ((ent >> 57) & 1));
+    Energy en;
+    if ((int)blockIdx.x < nb_contact) {
+        const ContactD<real>& d = S.contact[0];
+        const CellBin<real>& B = C.bin[0];
+        const Rec<real>* rec = (const Rec<real>*)B.rec + (size_t)rep * B.n;
+        const int* sorted = B.sorted + (size_t)rep * B.n;
+        const unsigned* rows = B.rows + (size_t)rep * B.n * B.stride;
+        const int sub = threadIdx.x & (AWSEM_ROW - 1), nrows = (B.n + 3) & ~3;
+        for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows; k += nb_contact * blockDim.x / AWSEM_ROW) {
+            const bool vi = k < B.n;
+            const int i = vi ? sorted[k] : 0;
+            const Rec<real> ri = rec[i];
+            const int cnt = vi ? B.row_count[(size_t)rep * B.n + i] : 0;
+            u64 acc = 0;
+            for (int s = sub; s < cnt; s += AWSEM_ROW) {
+                const unsigned ent = rows[(size_t)i * B.stride + s];
+                if (!(ent & 0x40000000u)) continue;
+                const Rec<real> rj = rec[ent & 0xffffffu];
+                const real r2 = dist2(ri.x - rj.x, ri.y - rj.y, ri.z - rj.z);
+                if (!(r2 < d.cutoff2)) continue;
+                const real r = M<real>::sqrt(r2);
+                acc += to_fixed(sigmoid(d.eta2 * (r - d.rmin)) * sigmoid(d.eta2 * (d.rmax - r)));
+            }
+            acc = row_sum(acc);
+            if (vi && sub == 0) {
+                L.rho[i] = acc;
+                single_body<ENERGY>(d, L, i, L.satom[i], en);
+            }
+        }
+        flush_energy<ENERGY>(L, d.group, en);
+    } else {
+        const ExclD<real>& d = S.excl[0];
+        if (!AWSEM_ON(d)) return;
+        const CellBin<real>& B = C.bin[1];
+        const Rec<real>* rec = (const Rec<real>*)B.rec + (size_t)rep * B.n;
+        const int* sorted = B.sorted + (size_t)rep * B.n;
+        const unsigned* rows = B.rows + (size_t)rep * B.n * B.stride;
+        const int sub = threadIdx.x & (AWSEM_ROW - 1), nrows = (B.n + 3) & ~3, nb = gridDim.x - nb_contact;
+        const real r02 = d.r0 * d.r0;
+        for (int k = ((blockIdx.x - nb_contact) * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows; k += nb * blockDim.x / AWSEM_ROW) {
+            const bool vi = k < B.n;
+            const int i = vi ? sorted[k] : 0;
+            const Rec<real> ri = rec[i];
+            const int cnt = vi ? B.row_count[(size_t)rep * B.n + i] : 0;
+            u64 X = 0, Y = 0, Z = 0;
+            for (int s = sub; s < cnt; s += AWSEM_ROW) {
+                const Rec<real> rj = rec[rows[(size_t)i * B.stride + s]];
+                const real dx = ri.x - rj.x, dy = ri.y - rj.y, dz = ri.z - rj.z;
+                const real r2 = dist2(dx, dy, dz);
+                if (!(r2 < r02)) continue;
+                const real ir = M<real>::rsqrt(r2), dr = r2 * ir - d.r0;
+                if (ENERGY) en += (double)((real)0.5 * d.k * dr * dr);   // the pair is met from both sides
+                const real t = (real)-2 * d.k * dr * ir * (real)AWSEM_FIXED_SCALE;
+                X += to_fixed_scaled(t * dx); Y += to_fixed_scaled(t * dy); Z += to_fixed_scaled(t * dz);
+            }
+            if (__ballot((X | Y | Z) != 0) == 0) continue;   // clashes are rare
+            X = row_sum(X); Y = row_sum(Y); Z = row_sum(Z);
+            if (vi && sub == 0 && (X | Y | Z) != 0) owner_add_force(L, tag_bits(ri.tag), X, Y, Z);
+        }
+        flush_energy<ENERGY>(L, d.group, en);
     }
 }
-template <bool ENERGY, class real> __global__ void cell_single_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos) {
-    const int rep = blockIdx.y;
-    const CellView<real> L = cell_view(S, C, pos, rep);
-    const ContactD<real>& d = S.contact[0];
-    Energy e;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.nsites; i += gridDim.x * blockDim.x) single_body<ENERGY>(d, L, i, L.satom[i], e);
-    flush_energy<ENERGY>(L, d.group, e);
-}
+// pass 2: pair energy, its radial force on the owner, the owner's dE/drho through sigma_water
 template <bool ENERGY, class real> __global__ void cell_pairs_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos) {
     const int rep = blockIdx.y;
     const CellView<real> L = cell_view(S, C, pos, rep);
     const ContactD<real>& d = S.contact[0];
-    const u64* e = C.clist + (size_t)rep * C.ccap;
-    const int count = (int)min((long long)C.counts[2 * rep], C.ccap), ntot = (count + 63) & ~63;
+    const CellBin<real>& B = C.bin[0];
+    const Rec<real>* rec = (const Rec<real>*)B.rec + (size_t)rep * B.n;
+    const int* sorted = B.sorted + (size_t)rep * B.n;
+    const unsigned* rows = B.rows + (size_t)rep * B.n * B.stride;
+    const bool zdep = d.flags & 1;
+    const real one = (real)1;
     Energy en;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < ntot; k += gridDim.x * blockDim.x) {
-        const bool v = k < count;
-        const u64 ent = v ? e[k] : 0;
-        const int i = (int)(ent & 0xffffff), j = (int)((ent >> 24) & 0xffffff), ty = (int)((ent >> 48) & 0x1ff);
-        pairs_body<ENERGY>(d, L, i, j, ty, L.satom[i], L.satom[j], v && ((ent >> 58) & 1), en);
+    AWSEM_ROW_LOOP(B, k) {
+        const bool vi = k < B.n;
+        const int i = vi ? sorted[k] : 0;
+        const Rec<real> ri = rec[i];
+        const int cnt = vi ? B.row_count[(size_t)rep * B.n + i] : 0;
+        const int ti = (tag_bits(ri.tag) >> 27) & 31;
+        const real si = L.rhov[i], ai = zdep ? L.alpha[i] : (real)0;
+        u64 X = 0, Y = 0, Z = 0, D = 0, FZ = 0;
+        for (int s = sub; s < cnt; s += AWSEM_ROW) {
+            const unsigned ent = rows[(size_t)i * B.stride + s];
+            if (!(ent >> 31)) continue;
+            const int j = ent & 0xffffffu;
+            const Rec<real> rj = rec[j];
+            const real dx = ri.x - rj.x, dy = ri.y - rj.y, dz = ri.z - rj.z;
+            const real r2 = dist2(dx, dy, dz);
+            if (!(r2 < d.cutoff2)) continue;
+            const real ir = M<real>::rsqrt(r2), r = r2 * ir;
+            const int tj = (tag_bits(rj.tag) >> 27) & 31;
+            const real sj = L.rhov[j], aj = zdep ? L.alpha[j] : (real)0;
+            // the type pair as the lower site sees it (what the half lists of the resident path hold)
+            const int ty = i < j ? ti * 20 + tj : tj * 20 + ti;
+            const PairTerms<real> t = contact_pair_math(d, L.gamma, ty, r, si * sj, ai * aj);
+            if (ENERGY) en += (double)((real)0.5 * t.E);
+            const real c = -t.dEdr * ir * (real)AWSEM_FIXED_SCALE;
+            X += to_fixed_scaled(c * dx); Y += to_fixed_scaled(c * dy); Z += to_fixed_scaled(c * dz);
+            D += to_fixed(t.dEdsw * sj * (-d.eta_s2 * si * (one - si)));
+            if (zdep) FZ += to_fixed(-t.MW * aj * L.dalpha[i]);
+        }
+        X = row_sum(X); Y = row_sum(Y); Z = row_sum(Z); D = row_sum(D);
+        if (zdep) FZ = row_sum(FZ);
+        if (vi && sub == 0) {
+            owner_add_force(L, L.satom[i], X, Y, Z + FZ);
+            L.drho[i] += D;
+        }
     }
     flush_energy<ENERGY>(L, d.group, en);
 }
+// pass 3: chain rule through the densities: F_i -= (dE/drho_i + dE/drho_j) theta_I'(r) (x_i - x_j)/r
 template <class real> __global__ void cell_chain_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos) {
     const int rep = blockIdx.y;
     const CellView<real> L = cell_view(S, C, pos, rep);
     const ContactD<real>& d = S.contact[0];
-    const u64* e = C.clist + (size_t)rep * C.ccap;
-    const int count = (int)min((long long)C.counts[2 * rep], C.ccap), ntot = (count + 63) & ~63;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < ntot; k += gridDim.x * blockDim.x) {
-        const bool v = k < count;
-        const u64 ent = v ? e[k] : 0;
-        const int i = (int)(ent & 0xffffff), j = (int)((ent >> 24) & 0xffffff);
-        chain_body(d, L, i, j, L.satom[i], L.satom[j], v && ((ent >> 57) & 1));
+    const CellBin<real>& B = C.bin[0];
+    const Rec<real>* rec = (const Rec<real>*)B.rec + (size_t)rep * B.n;
+    const int* sorted = B.sorted + (size_t)rep * B.n;
+    const unsigned* rows = B.rows + (size_t)rep * B.n * B.stride;
+    AWSEM_ROW_LOOP(B, k) {
+        const bool vi = k < B.n;
+        const int i = vi ? sorted[k] : 0;
+        const Rec<real> ri = rec[i];
+        const int cnt = vi ? B.row_count[(size_t)rep * B.n + i] : 0;
+        const u64 di = L.drho[i];
+        u64 X = 0, Y = 0, Z = 0;
+        for (int s = sub; s < cnt; s += AWSEM_ROW) {
+            const unsigned ent = rows[(size_t)i * B.stride + s];
+            if (!(ent & 0x40000000u)) continue;
+            const int j = ent & 0xffffffu;
+            const Rec<real> rj = rec[j];
+            const real dx = ri.x - rj.x, dy = ri.y - rj.y, dz = ri.z - rj.z;
+            const real r2 = dist2(dx, dy, dz);
+            if (!(r2 < d.cutoff2)) continue;
+            const real ir = M<real>::rsqrt(r2), r = r2 * ir;
+            const real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
+            const real g = fixed_to_real(di + L.drho[j], (real)0);
+            const real c = -g * d.eta2 * s1 * s2 * (s2 - s1) * ir * (real)AWSEM_FIXED_SCALE;
+            X += to_fixed_scaled(c * dx); Y += to_fixed_scaled(c * dy); Z += to_fixed_scaled(c * dz);
+        }
+        X = row_sum(X); Y = row_sum(Y); Z = row_sum(Z);
+        if (vi && sub == 0) owner_add_force(L, L.satom[i], X, Y, Z);
     }
-}
-template <bool ENERGY, class real> __global__ void cell_excl_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos) {
-    const int rep = blockIdx.y;
-    const CellView<real> L = cell_view(S, C, pos, rep);
-    const ExclD<real>& d = S.excl[0];
-    const u64* e = C.xlist + (size_t)rep * C.xcap;
-    const int count = (int)min((long long)C.counts[2 * rep + 1], C.xcap), ntot = (count + 63) & ~63;
-    Energy en;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < ntot; k += gridDim.x * blockDim.x) {
-        const bool v = k < count;
-        const u64 ent = v ? e[k] : 0;
-        excl_body<ENERGY>(d, L, (int)(ent & 0xffffffffu), (int)(ent >> 32), v, en);
-    }
-    flush_energy<ENERGY>(L, d.group, en);
 }
 
 // Bonded terms: one workgroup per 256 items of one term (job table built at finalize).
@@ -360,6 +519,43 @@ template <bool ENERGY, class real> __global__ void cell_bonded_kernel(DevSys<rea
     }
 }
 
+// Bonded terms, window by window: a workgroup stages the positions of AWSEM_WIN_SPAN consecutive atoms in LDS, runs
+// every item whose lowest atom lies in its window (the item lists are sorted by window at finalize) with LDS
+// accumulators, and flushes the touched atoms with one global atomic per component -- a fifth of the global atomics of
+// the item-by-item kernel above, which keeps the items that do not fit a window.
+// wstart[slot][w]: first item of window w in the slot's term; slots run over harm, chi, rama, helical, fm, memb.
+template <class real> struct WinView : ViewCommon<real>, SoaOps<real> { typedef real real_t; };
+template <bool ENERGY, class real> __global__ void cell_window_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos, const int* __restrict__ wstart, int nwin, unsigned mask) {
+    __shared__ real sp[3][AWSEM_WIN_SPAN];
+    __shared__ u64 sf[3][AWSEM_WIN_SPAN];
+    const int rep = blockIdx.y, w = blockIdx.x, n = C.natoms;
+    const int a0 = w * AWSEM_WIN, na = min(AWSEM_WIN_SPAN, n - a0);
+    const real* p = pos + (size_t)rep * 3 * n;
+    for (int i = threadIdx.x; i < na; i += blockDim.x)
+        for (int k = 0; k < 3; k++) { sp[k][i] = p[(size_t)k * n + a0 + i]; sf[k][i] = 0; }
+    WinView<real> L;
+    L.px = &sp[0][0] - a0; L.py = &sp[1][0] - a0; L.pz = &sp[2][0] - a0;
+    L.fx = &sf[0][0] - a0; L.fy = &sf[1][0] - a0; L.fz = &sf[2][0] - a0;
+    L.rho = L.drho = nullptr; L.rhov = L.alpha = L.dalpha = L.gamma = nullptr; L.satom = nullptr;
+    L.lcount = nullptr; L.flag = nullptr; L.lists = nullptr;
+    L.eg = C.eg + (size_t)rep * AWSEM_NGROUPS;
+    __syncthreads();
+    const int* ws = wstart + w;
+    const int stride = nwin + 1;
+    for (int t = 0; t < S.n_harm; t++, ws += stride) { HarmD<real> d = S.harm[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.items += ws[0]; d.n = ws[1] - ws[0]; term_harmonic<ENERGY>(d, L); }
+    for (int t = 0; t < S.n_chi; t++, ws += stride) { ChiD<real> d = S.chi[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.atoms += ws[0]; d.n = ws[1] - ws[0]; term_chi<ENERGY>(d, L); }
+    for (int t = 0; t < S.n_rama; t++, ws += stride) { RamaD<real> d = S.rama[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.atoms += ws[0]; d.bw += (size_t)ws[0] * d.nwell; d.n = ws[1] - ws[0]; term_rama<ENERGY>(d, L); }
+    for (int t = 0; t < S.n_helical; t++, ws += stride) { HelicalD<real> d = S.helical[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.items += ws[0]; d.n = ws[1] - ws[0]; term_helical<ENERGY>(d, L); }
+    for (int t = 0; t < S.n_fm; t++, ws += stride) { FmD<real> d = S.fm[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.pairs2 += 2 * (size_t)ws[0]; d.table2 += (size_t)ws[0] * (d.ntab - 1); d.n = ws[1] - ws[0]; term_fm<ENERGY, false>(d, L); }
+    for (int t = 0; t < S.n_memb; t++, ws += stride) { MembD<real> d = S.memb[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.items += ws[0]; d.n = ws[1] - ws[0]; term_memb<ENERGY>(d, L); }
+    __syncthreads();
+    u64* f = C.f + (size_t)rep * 3 * n;
+    for (int i = threadIdx.x; i < na; i += blockDim.x)
+        for (int k = 0; k < 3; k++) { const u64 v = sf[k][i]; if (v) fixed_add(&f[(size_t)k * n + a0 + i], v); }
+}
+
+template <class T> __global__ void cell_set_word_kernel(T* p, T v) { *p = v; }
+
 // ------------------------------------------------------------------ outputs, virtual sites, integrator
 template <class real> __global__ void cell_vsite_kernel(DevSys<real> S, real* __restrict__ pos) {
     const int n = S.natoms;
@@ -367,21 +563,21 @@ template <class real> __global__ void cell_vsite_kernel(DevSys<real> S, real* __
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S.nvs; i += gridDim.x * blockDim.x) {
         const Int4 v = S.vs[i];
         const real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
-        for (int k = 0; k < 3; k++) p[k * n + v.x] = w0 * p[k * n + v.y] + w1 * p[k * n + v.z] + w2 * p[k * n + v.w];
+        for (int k = 0; k < 3; k++) p[(size_t)k * n + v.x] = w0 * p[(size_t)k * n + v.y] + w1 * p[(size_t)k * n + v.z] + w2 * p[(size_t)k * n + v.w];
     }
 }
+// evaluation API only (getState(getForces=True) reports the forces folded onto the parents)
 template <class real> __global__ void cell_redistribute_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos) {
     const int rep = blockIdx.y;
     const CellView<real> L = cell_view(S, C, pos, rep);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S.nvs; i += gridDim.x * blockDim.x) {
         const Int4 v = S.vs[i];
         const R3<real> F = L.force(v.x);
-        const real fx = F.x, fy = F.y, fz = F.z;
         L.zero_force(v.x);   // only this lane touches the accumulators of its virtual site here
         const real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
-        L.add_force(v.y, w0 * fx, w0 * fy, w0 * fz);
-        L.add_force(v.z, w1 * fx, w1 * fy, w1 * fz);
-        L.add_force(v.w, w2 * fx, w2 * fy, w2 * fz);
+        L.add_force(v.y, w0 * F.x, w0 * F.y, w0 * F.z);
+        L.add_force(v.z, w1 * F.x, w1 * F.y, w1 * F.z);
+        L.add_force(v.w, w2 * F.x, w2 * F.y, w2 * F.z);
     }
 }
 template <class real> __global__ void cell_output_kernel(CellSys<real> C, double* __restrict__ f_out, double* __restrict__ e_out) {
@@ -392,25 +588,37 @@ template <class real> __global__ void cell_output_kernel(CellSys<real> C, double
             for (int k = 0; k < 3; k++) f_out[((size_t)rep * n + i) * 3 + k] = fixed_to_double(f[(size_t)k * n + i]);
     if (e_out && blockIdx.x == 0 && threadIdx.x < AWSEM_NGROUPS) e_out[(size_t)rep * AWSEM_NGROUPS + threadIdx.x] = fixed_to_double(C.eg[(size_t)rep * AWSEM_NGROUPS + threadIdx.x]);
 }
+// Langevin update; every massive particle gathers the forces of the virtual sites it parents (no atomics) and clears
+// its own accumulator (those of the sites are cleared by the next step's pre kernel, once every parent has read them).
 template <class real>
 __global__ void cell_integrate_kernel(DevSys<real> S, CellSys<real> C, real* __restrict__ pos, real* __restrict__ vel, const double* __restrict__ T,
-                                      double dt, double friction, unsigned long long seed, long long step) {
+                                      double dt, double friction, unsigned long long seed, const long long* __restrict__ step_base, int step_offset) {
+    const long long step = *step_base + step_offset;   // the base lives in device memory so that a captured graph of several steps can be replayed
     const int rep = blockIdx.y, n = C.natoms;
-    real* p = pos + (size_t)rep * 3 * n;
+    const CellView<real> L = cell_view(S, C, pos, rep);
     real* v = vel + (size_t)rep * 3 * n;
-    const u64* f = C.f + (size_t)rep * 3 * n;
     const double a_d = ::exp(-friction * dt);
     const real a = (real)a_d, fs = (real)(friction == 0.0 ? dt : (1.0 - a_d) / friction);
     const real ns = (real)::sqrt(AWSEM_KB * T[rep] * (1.0 - a_d * a_d)), dtr = (real)dt;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S.nmassive; k += gridDim.x * blockDim.x) {
         const MassiveItem<real> mi = S.massive[k];
+        const GatherItem<real> gi = S.gather[k];
         const int i = mi.atom;
+        R3<real> F = L.force(i);
+        L.zero_force(i);
+#pragma unroll
+        for (int q = 0; q < AWSEM_MAX_GATHER; q++) {
+            if (gi.vs[q] < 0) continue;
+            const R3<real> fv = L.force(gi.vs[q]);
+            F.x += gi.w[q] * fv.x; F.y += gi.w[q] * fv.y; F.z += gi.w[q] * fv.z;
+        }
         real g[3];
         gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step, i, g);
-        for (int c = 0; c < 3; c++) {
-            const real vn = a * v[c * n + i] + fs * mi.inv_mass * (real)fixed_to_double(f[(size_t)c * n + i]) + ns * mi.sqrt_inv_mass * g[c];
-            v[c * n + i] = vn;
-            p[c * n + i] += dtr * vn;
-        }
+        const real im = fs * mi.inv_mass, sq = ns * mi.sqrt_inv_mass;
+        const real vx = a * v[i] + im * F.x + sq * g[0];
+        const real vy = a * v[n + i] + im * F.y + sq * g[1];
+        const real vz = a * v[2 * (size_t)n + i] + im * F.z + sq * g[2];
+        v[i] = vx; v[n + i] = vy; v[2 * (size_t)n + i] = vz;
+        L.px[i] += dtr * vx; L.py[i] += dtr * vy; L.pz[i] += dtr * vz;
     }
 }

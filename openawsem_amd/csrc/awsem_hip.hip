@@ -107,6 +107,7 @@ public:
                 if (tot > 0) for (int k = 0; k < 10; k++) fprintf(stderr, "[awsem prof] %-24s %14lld cycles  %5.1f %%\n", names[k], p[k], 100.0 * p[k] / tot);
             }
         }
+        for (auto& G : cell_graph_) if (G.exec) (void)hipGraphExecDestroy(G.exec);
         for (void* p : allocs_) (void)hipFree(p);
         if (ev0_) (void)hipEventDestroy(ev0_);
         if (ev1_) (void)hipEventDestroy(ev1_);
@@ -218,7 +219,7 @@ private:
             HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
             if (st & 2) {
                 cell_stale_ = true;
-                throw std::string("neighbour list overflow on the cell-list path during dynamics: raise AWSEM_CELL_NEIGHBORS (pairs reserved per site, default 128)");
+                throw std::string("neighbour list overflow on the cell-list path during dynamics: raise AWSEM_CELL_NEIGHBORS (partners reserved per contact site, default 64)");
             }
             throw std::string("pair list overflow on the device (internal error: list capacity below the candidate pair count)");
         }
@@ -267,18 +268,26 @@ private:
     // ---- cell-list path (awsem_cell.h): systems that do not fit one CU's LDS
     void cell_setup(DevSys<real>& S, const HostSystem& H);
     void cell_alloc_lists();
-    void cell_refresh(const CellSys<real>& C, real rc2c, real rc2x);
+    void cell_pre(bool step);
+    void cell_refresh(const CellSys<real>& C);
     void cell_forces_pass(bool energy, unsigned mask);
     void cell_evaluate(bool energy, unsigned mask, int redistribute, double* e, double* f);
     void cell_step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0);
+    void cell_one_step(double dt, double friction, uint64_t seed, int offset);
+    struct CellGraph { hipGraphExec_t exec = nullptr; double dt = 0, friction = 0; uint64_t seed = 0; const void *rows0 = nullptr, *rows1 = nullptr; };
+    CellGraph cell_graph_[2];
+    long long* cell_step_base_ = nullptr;
     int cell_neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity);
     dim3 cell_grid(long long n) const { long long b = (n + 255) / 256; return dim3((unsigned)std::max(1LL, std::min(b, 2048LL)), nrep_); }
     bool cell_mode_ = false, cell_stale_ = true;
     CellSys<real> cell_;
     const CellJob* cell_jobs_ = nullptr;
-    int cell_njobs_ = 0, cell_per_site_ = 128;
+    int cell_njobs_ = 0, cell_per_site_ = 64, cell_cur_ = 0;
     double cell_rc_contact_ = 0, cell_rc_excl_ = 0;
     std::vector<int> excl_sorted_atom_, excl_sorted_cls_;   // class-sorted site table of excl term 0
+    std::vector<int> cell_wstart_, cell_nlocal_;            // per local bonded term (harm, chi, rama, helical, fm, memb order): window starts, local item count
+    const int* cell_wstart_dev_ = nullptr;
+    int cell_nwin_ = 0, cell_nslots_ = 0;
 };
 
 // Order static items (bonds, dihedrals, virtual sites ...) so that the 64 items one wave handles in one
@@ -339,6 +348,40 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
     DevSys<real> S;
     memset(&S, 0, sizeof S);
     S.natoms = natoms_;
+    {   // which path: replica-resident (one replica fits the LDS of a CU) or cell lists
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device_));
+        size_t lds_max = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
+        if (prop.maxSharedMemoryPerMultiProcessor > lds_max) lds_max = prop.maxSharedMemoryPerMultiProcessor;
+        lds_max_ = lds_max;
+        int max_sites = 0;
+        for (auto& h : H.contact) max_sites = std::max(max_sites, (int)h.atom.size());
+        const char* force = getenv("AWSEM_FORCE_CELL");
+        cell_mode_ = lds_bytes<real>(natoms_, max_sites, (int)H.contact.size(), false) > lds_max || (force && atoi(force) != 0);
+    }
+    // Item order of the static lists.  Replica-resident path: conflict-aware (spread_order).  Cell-list path: by window of
+    // AWSEM_WIN atoms (the window kernel accumulates a window's items in LDS); items spanning more than a window's LDS
+    // span go last and take the direct path.
+    auto item_order = [&](int n, int width, const int* atoms) {
+        if (!cell_mode_) return spread_order(n, width, atoms, natoms_);
+        const int nwin = (natoms_ + AWSEM_WIN - 1) / AWSEM_WIN;
+        std::vector<int> win(n), perm(n);
+        for (int i = 0; i < n; i++) {
+            int lo = natoms_, hi = -1;
+            for (int k = 0; k < width; k++) { const int a = atoms[(size_t)i * width + k]; if (a >= 0) { lo = std::min(lo, a); hi = std::max(hi, a); } }
+            const int w = lo / AWSEM_WIN;
+            win[i] = (hi >= 0 && hi < w * AWSEM_WIN + AWSEM_WIN_SPAN) ? w : nwin;   // nwin = not local
+            perm[i] = i;
+        }
+        std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return win[x] < win[y]; });
+        std::vector<int> start(nwin + 2, 0);
+        for (int i = 0; i < n; i++) start[win[i] + 1]++;
+        for (int w = 0; w <= nwin; w++) start[w + 1] += start[w];
+        cell_wstart_.insert(cell_wstart_.end(), start.begin(), start.begin() + nwin + 1);   // start[nwin] = number of local items
+        cell_nlocal_.push_back(start[nwin]);
+        return perm;
+    };
+    cell_wstart_.clear(); cell_nlocal_.clear();
     // particles
     {
         std::vector<real> im(natoms_), sim(natoms_);
@@ -383,7 +426,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         std::vector<HarmD<real>> D;
         for (auto& h : H.harm) {
             std::vector<HarmItem<real>> it(h.r0.size());
-            const std::vector<int> perm = spread_order((int)it.size(), 2, h.pairs.data(), natoms_);
+            const std::vector<int> perm = item_order((int)it.size(), 2, h.pairs.data());
             for (size_t b = 0; b < it.size(); b++) { int o = perm[b]; it[b] = HarmItem<real>{h.pairs[2 * o], h.pairs[2 * o + 1], (real)h.r0[o], (real)h.k[o]}; }
             D.push_back(HarmD<real>{h.group, (int)it.size(), upload(it)});
         }
@@ -394,7 +437,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         std::vector<ChiD<real>> D;
         for (auto& h : H.chi) {
             std::vector<Int4> a(h.atoms.size() / 4);
-            const std::vector<int> perm = spread_order((int)a.size(), 4, h.atoms.data(), natoms_);
+            const std::vector<int> perm = item_order((int)a.size(), 4, h.atoms.data());
             for (size_t b = 0; b < a.size(); b++) { int o = perm[b]; a[b] = Int4{h.atoms[4 * o], h.atoms[4 * o + 1], h.atoms[4 * o + 2], h.atoms[4 * o + 3]}; }
             D.push_back(ChiD<real>{h.group, (int)a.size(), upload(a), (real)h.k, (real)h.chi0});
         }
@@ -408,7 +451,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             memset(&d, 0, sizeof d);
             d.group = h.group; d.n = (int)(h.atoms.size() / 5); d.nwell = h.nwell;
             std::vector<Int5> a(d.n);
-            const std::vector<int> perm = spread_order(d.n, 5, h.atoms.data(), natoms_);
+            const std::vector<int> perm = item_order(d.n, 5, h.atoms.data());
             for (int b = 0; b < d.n; b++) for (int k = 0; k < 5; k++) a[b].a[k] = h.atoms[5 * perm[b] + k];
             d.atoms = upload(a);
             std::vector<real> bw((size_t)d.n * h.nwell);
@@ -549,7 +592,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         std::vector<HelicalD<real>> D;
         for (auto& h : H.helical) {
             std::vector<HelicalItem<real>> it(h.coef.size());
-            const std::vector<int> perm = spread_order((int)it.size(), 3, h.atoms.data(), natoms_);
+            const std::vector<int> perm = item_order((int)it.size(), 3, h.atoms.data());
             for (size_t b = 0; b < it.size(); b++) { int o = perm[b]; it[b] = HelicalItem<real>{h.atoms[3 * o], h.atoms[3 * o + 1], h.atoms[3 * o + 2], (real)h.coef[o]}; }
             D.push_back(HelicalD<real>{h.group, (int)it.size(), upload(it), (real)h.r_ON, (real)h.r_OH, (real)(1.0 / (h.s_NO * h.s_NO)), (real)(1.0 / (h.s_HO * h.s_HO))});
         }
@@ -560,7 +603,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         std::vector<FmD<real>> D;
         for (auto& h : H.fm) {
             const int nb = (int)(h.pairs.size() / 2);
-            const std::vector<int> perm = spread_order(nb, 2, h.pairs.data(), natoms_);
+            const std::vector<int> perm = item_order(nb, 2, h.pairs.data());
             std::vector<real2_t<real>> t2((size_t)nb * (h.ntab - 1));
             for (int b = 0; b < nb; b++) for (int i = 0; i + 1 < h.ntab; i++)
                 t2[(size_t)b * (h.ntab - 1) + i] = real2_t<real>{(real)h.table[(size_t)perm[b] * h.ntab + i], (real)h.table[(size_t)perm[b] * h.ntab + i + 1]};
@@ -577,7 +620,10 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         std::vector<MembD<real>> D;
         for (auto& h : H.memb) {
             std::vector<MembItem<real>> it(h.atoms.size());
-            for (size_t b = 0; b < it.size(); b++) it[b] = MembItem<real>{h.atoms[b], (real)h.scale[b]};
+            std::vector<int> perm(it.size());
+            for (size_t b = 0; b < it.size(); b++) perm[b] = (int)b;
+            if (cell_mode_) perm = item_order((int)it.size(), 1, h.atoms.data());
+            for (size_t b = 0; b < it.size(); b++) it[b] = MembItem<real>{h.atoms[perm[b]], (real)h.scale[perm[b]]};
             D.push_back(MembD<real>{h.group, (int)it.size(), upload(it), (real)h.k, (real)(2 * h.k_m), (real)h.z_m, (real)h.center});
         }
         if (D.size() > AWSEM_MAX_MEMB) throw std::string("too many memb terms: at most " + std::to_string(AWSEM_MAX_MEMB) + " per system");
@@ -604,17 +650,9 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
     S.status = dstatus_;
     S.prof = dalloc<long long>(16);
     HIP_TRY(hipMemset(S.prof, 0, 16 * sizeof(long long)));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device_));
-    size_t lds_max = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
-    if (prop.maxSharedMemoryPerMultiProcessor > lds_max) lds_max = prop.maxSharedMemoryPerMultiProcessor;
-    lds_max_ = lds_max;
+    const size_t lds_max = lds_max_;
     lds_eval_ = lds_bytes<real>(natoms_, S.max_contact_sites, S.n_contact, false);
     lds_step_ = lds_bytes<real>(natoms_, S.max_contact_sites, S.n_contact, true);
-    {
-        const char* force = getenv("AWSEM_FORCE_CELL");
-        cell_mode_ = lds_eval_ > lds_max || (force && atoi(force) != 0);
-    }
     if (cell_mode_) {
         cell_setup(S, H);
     } else {
@@ -744,104 +782,144 @@ template <class real> void Engine<real>::cell_setup(DevSys<real>& S, const HostS
     if (S.n_contact > 1 || S.n_excl > 1) throw std::string("cell-list path: at most one contact and one excluded-volume term");
     if (S.n_contact && (H.contact[0].flags & AWSEM_CONTACT_NOCUTOFF)) throw std::string("cell-list path: the contact term needs a cutoff");
     if (S.n_contact && S.contact[0].nsites >= (1 << 24)) throw std::string("cell-list path: at most 2^24 contact sites");
-    if (const char* env = getenv("AWSEM_CELL_NEIGHBORS")) { int v = atoi(env); if (v >= 8 && v <= 4096) cell_per_site_ = v; }
+    if (const char* env = getenv("AWSEM_CELL_NEIGHBORS")) { int v = atoi(env); if (v >= 16 && v <= 4096) cell_per_site_ = v; }
     CellSys<real>& C = cell_;
     memset(&C, 0, sizeof C);
     C.natoms = natoms_; C.nrep = nrep_; C.nsites = S.n_contact ? S.contact[0].nsites : 0;
-    std::vector<int> c_site(natoms_, -1), x_slot(natoms_, -1), x_cls(natoms_, -1);
-    if (S.n_contact) for (int i = 0; i < C.nsites; i++) c_site[H.contact[0].atom[i]] = i;
-    if (S.n_excl) for (size_t q = 0; q < excl_sorted_atom_.size(); q++) { x_slot[excl_sorted_atom_[q]] = (int)q; x_cls[excl_sorted_atom_[q]] = excl_sorted_cls_[q]; }
-    C.c_site = upload(c_site); C.x_slot = upload(x_slot); C.x_cls = upload(x_cls);
     cell_rc_contact_ = S.n_contact ? H.contact[0].p[AWSEM_CP_CUTOFF] : 0.0;
     cell_rc_excl_ = S.n_excl ? H.excl[0].r0 : 0.0;
-    C.rc_cell = (real)(std::max(cell_rc_contact_, cell_rc_excl_) + skin_);
     C.skin_half2 = (real)(0.25 * skin_ * skin_ * 0.999);
     C.status = dstatus_;
     const size_t R = nrep_;
-    C.bbox = dalloc<int>(R * 8); C.grid = dalloc<real>(R * 4); C.dims = dalloc<int>(R * 4);
-    C.cell_count = dalloc<int>(R * AWSEM_CELL_MAXCELLS); C.cell_start = dalloc<int>(R * (AWSEM_CELL_MAXCELLS + 1));
-    C.cell_of = dalloc<int>(R * natoms_); C.cell_atoms = dalloc<int>(R * natoms_);
-    C.counts = dalloc<unsigned>(R * 2);
-    HIP_TRY(hipMemset(C.counts, 0, R * 2 * sizeof(unsigned)));
+    // bin 0: the contact sites; bin 1: the excluded-volume atoms (class-sorted table of the term)
+    CellBin<real>& B0 = C.bin[0];
+    CellBin<real>& B1 = C.bin[1];
+    B0.n = C.nsites; B0.atom = S.n_contact ? S.contact[0].atom : nullptr;
+    B1.n = S.n_excl ? (int)excl_sorted_atom_.size() : 0; B1.atom = S.n_excl ? S.excl[0].atom : nullptr;
+    if (S.n_excl) { C.x_partners = S.excl[0].partners; C.x_class = upload(excl_sorted_cls_); }
+    for (int i = 0; i < B0.n; i++) if (H.mass[H.contact[0].atom[i]] <= 0) throw std::string("cell-list path: contact sites must be massive particles");
+    for (int a : excl_sorted_atom_) if (S.n_excl && H.mass[a] <= 0) throw std::string("cell-list path: excluded-volume sites must be massive particles");
+    for (int b = 0; b < 2; b++) {
+        CellBin<real>& B = C.bin[b];
+        const double rc = (b == 0 ? cell_rc_contact_ : cell_rc_excl_) + skin_;
+        B.edge_min = (real)rc; B.rc2 = (real)(rc * rc);
+        const size_t n = std::max(1, B.n);
+        B.grid = dalloc<real>(R * 4); B.dims = dalloc<int>(R * 4);
+        B.cell_count = dalloc<int>(R * AWSEM_CELL_MAXCELLS); B.cell_start = dalloc<int>(R * (AWSEM_CELL_MAXCELLS + 1));
+        B.tile_sum = dalloc<int>(R * (AWSEM_CELL_MAXCELLS / 1024));
+        B.cell_of = dalloc<int>(R * n); B.sorted = dalloc<int>(R * n);
+        B.rec = dalloc<real>(R * n * 4);
+        B.row_count = dalloc<int>(R * n);
+        HIP_TRY(hipMemset(B.row_count, 0, R * n * sizeof(int)));
+        HIP_TRY(hipMemset(B.dims, 0, R * 4 * sizeof(int)));
+    }
+    {
+        const long long n = std::max<long long>(std::max(S.nvs, S.nfixed), (long long)B0.n + B1.n);
+        C.nblk_pre = (int)std::max(1LL, (n + 255) / 256);
+        C.bbox = dalloc<int>(R * C.nblk_pre * 8);
+    }
+    C.flag = dalloc<unsigned>(R * 2);
+    HIP_TRY(hipMemset(C.flag, 0, R * 2 * sizeof(unsigned)));
     C.eg = dalloc<u64>(R * AWSEM_NGROUPS);
     const size_t ns = std::max(1, C.nsites);
     C.rho = dalloc<u64>(R * ns); C.drho = dalloc<u64>(R * ns);
     C.rhov = dalloc<real>(R * ns); C.alpha = dalloc<real>(R * ns); C.dalpha = dalloc<real>(R * ns);
-    C.flag = dalloc<unsigned>(R * 2);
-    HIP_TRY(hipMemset(C.flag, 0, R * 2 * sizeof(unsigned)));
     cell_alloc_lists();
-    // bonded terms: one job per 256 items
+    // bonded terms: the items local to a window go through cell_window_kernel (LDS accumulation); the others (and
+    // Debye-Hueckel, whose pairs span the whole system) one job per 256 items with global atomics
     std::vector<CellJob> jobs;
-    auto add = [&](int kind, int term, int n) { for (int f = 0; f < n; f += 256) jobs.push_back(CellJob{kind, term, f}); };
-    for (int t = 0; t < S.n_harm; t++) add(CJ_HARM, t, S.harm[t].n);
-    for (int t = 0; t < S.n_chi; t++) add(CJ_CHI, t, S.chi[t].n);
-    for (int t = 0; t < S.n_rama; t++) add(CJ_RAMA, t, S.rama[t].n);
-    for (int t = 0; t < S.n_helical; t++) add(CJ_HELICAL, t, S.helical[t].n);
-    for (int t = 0; t < S.n_fm; t++) add(CJ_FM, t, S.fm[t].n);
-    for (int t = 0; t < S.n_memb; t++) add(CJ_MEMB, t, S.memb[t].n);
-    for (int t = 0; t < S.n_dh; t++) add(CJ_DH, t, S.dh[t].n);
+    int slot = 0;
+    auto add = [&](int kind, int term, int n, bool local_kind) {
+        const int first = local_kind ? cell_nlocal_[slot++] : 0;
+        for (int f = first; f < n; f += 256) jobs.push_back(CellJob{kind, term, f});
+    };
+    for (int t = 0; t < S.n_harm; t++) add(CJ_HARM, t, S.harm[t].n, true);
+    for (int t = 0; t < S.n_chi; t++) add(CJ_CHI, t, S.chi[t].n, true);
+    for (int t = 0; t < S.n_rama; t++) add(CJ_RAMA, t, S.rama[t].n, true);
+    for (int t = 0; t < S.n_helical; t++) add(CJ_HELICAL, t, S.helical[t].n, true);
+    for (int t = 0; t < S.n_fm; t++) add(CJ_FM, t, S.fm[t].n, true);
+    for (int t = 0; t < S.n_memb; t++) add(CJ_MEMB, t, S.memb[t].n, true);
+    for (int t = 0; t < S.n_dh; t++) add(CJ_DH, t, S.dh[t].n, false);
+    cell_nslots_ = slot;
+    cell_nwin_ = (natoms_ + AWSEM_WIN - 1) / AWSEM_WIN;
+    if ((size_t)cell_nslots_ * (cell_nwin_ + 1) != cell_wstart_.size()) throw std::string("internal error: window tables out of step with the bonded terms");
+    cell_wstart_dev_ = upload(cell_wstart_);
     cell_njobs_ = (int)jobs.size();
     cell_jobs_ = upload(jobs);
     S.lists = nullptr; S.list_stride = 0; S.n_lists = 0; S.skin_half2 = C.skin_half2;
 }
+// neighbour rows: `cell_per_site_` entries per contact site, a quarter of that (at least 16) per excluded-volume atom
 template <class real> void Engine<real>::cell_alloc_lists() {
     CellSys<real>& C = cell_;
-    C.ccap = std::max<long long>(1024, (long long)C.nsites * cell_per_site_);
-    C.xcap = std::max<long long>(1024, (long long)excl_sorted_atom_.size() * std::max(16, cell_per_site_ / 2));
-    if (C.ccap > 0x7fffffffLL || C.xcap > 0x7fffffffLL) throw std::string("cell-list path: neighbour list capacity exceeds 2^31 entries per replica");
-    C.clist = dalloc<u64>((size_t)C.ccap * nrep_);
-    C.xlist = dalloc<u64>((size_t)C.xcap * nrep_);
+    C.bin[0].stride = (cell_per_site_ + AWSEM_ROW - 1) / AWSEM_ROW * AWSEM_ROW;
+    C.bin[1].stride = std::max(AWSEM_ROW, (cell_per_site_ / 4 + AWSEM_ROW - 1) / AWSEM_ROW * AWSEM_ROW);
+    for (int b = 0; b < 2; b++) {
+        const size_t n = (size_t)std::max(1, C.bin[b].n) * C.bin[b].stride;
+        if (n > 0x7fffffffULL) throw std::string("cell-list path: neighbour rows exceed 2^31 entries per replica");
+        C.bin[b].rows = dalloc<unsigned>(n * nrep_);
+    }
     cell_stale_ = true;
 }
-// displacement test and, for the replicas that need it, the whole list build (kernels of other replicas exit at once)
-template <class real> void Engine<real>::cell_refresh(const CellSys<real>& C, real rc2c, real rc2x) {
-    const dim3 ga = cell_grid(natoms_), b(256);
-    hipLaunchKernelGGL(cell_displacement_kernel<real>, ga, b, 0, stream_, C, pos_, cell_stale_ ? 1 : 0);
-    hipLaunchKernelGGL(cell_decide_kernel<real>, dim3((nrep_ + 63) / 64), dim3(64), 0, stream_, C);
-    hipLaunchKernelGGL(cell_bbox_kernel<real>, ga, b, 0, stream_, C, pos_);
-    hipLaunchKernelGGL(cell_grid_kernel<real>, dim3(AWSEM_CELL_MAXCELLS / 256, nrep_), b, 0, stream_, C);
-    hipLaunchKernelGGL(cell_count_kernel<real>, ga, b, 0, stream_, C, pos_);
-    hipLaunchKernelGGL(cell_scan_kernel<real>, dim3(nrep_), dim3(1024), 0, stream_, C);
-    hipLaunchKernelGGL(cell_fill_kernel<real>, ga, b, 0, stream_, C);
-    hipLaunchKernelGGL(cell_list_kernel<real>, ga, b, 0, stream_, dsys_, C, pos_, rc2c, rc2x);
+// member records, displacement test, bounding box (and, when asked, the virtual sites)
+template <class real> void Engine<real>::cell_pre(bool step) {
+    const CellSys<real>& C = cell_;
+    const dim3 g(C.nblk_pre, nrep_), b(256);
+    cell_cur_ ^= 1;
+    if (step) hipLaunchKernelGGL((cell_pre_kernel<true, real>), g, b, 0, stream_, dsys_, C, pos_, cell_cur_);
+    else hipLaunchKernelGGL((cell_pre_kernel<false, real>), g, b, 0, stream_, dsys_, C, pos_, cell_cur_);
+}
+// the list build for the replicas that need it (kernels of other replicas exit at once)
+template <class real> void Engine<real>::cell_refresh(const CellSys<real>& C) {
+    const int force = cell_stale_ ? 1 : 0, cur = cell_cur_;
+    const long long nm = std::max(C.bin[0].n, C.bin[1].n);
+    const dim3 gm((unsigned)std::max(1LL, std::min((nm + 255) / 256, 4096LL)), 2 * nrep_), b(256);
+    const dim3 gr((unsigned)std::max(1LL, std::min((nm * AWSEM_ROW + 255) / 256, 16384LL)), 2 * nrep_);
+    hipLaunchKernelGGL(cell_geom_kernel<real>, dim3(2 * nrep_), dim3(1024), 0, stream_, C, cur, force);
+    hipLaunchKernelGGL(cell_count_kernel<real>, dim3(std::min(gm.x, 64u), gm.y), b, 0, stream_, C, pos_, cur, force);   // few workgroups: see the tile histogram
+    hipLaunchKernelGGL(cell_scan_kernel<real>, dim3(AWSEM_CELL_MAXCELLS / 1024, 2 * nrep_), dim3(1024), 0, stream_, C, cur, force);
+    hipLaunchKernelGGL(cell_fill_kernel<real>, gm, b, 0, stream_, C, cur, force);
+    hipLaunchKernelGGL(cell_rows_kernel<real>, gr, b, 0, stream_, dsys_, C, cur, force);
     HIP_TRY(hipGetLastError());
     cell_stale_ = false;
 }
 template <class real> void Engine<real>::cell_forces_pass(bool energy, unsigned mask) {
     const CellSys<real>& C = cell_;
     const DevSys<real>& S = dsys_;
-    const size_t R = nrep_;
     const dim3 b(256);
-    HIP_TRY(hipMemsetAsync(C.f, 0, R * 3 * natoms_ * sizeof(u64), stream_));
-    if (energy) HIP_TRY(hipMemsetAsync(C.eg, 0, R * AWSEM_NGROUPS * sizeof(u64), stream_));
+    if (cell_nslots_) {
+        if (energy) hipLaunchKernelGGL((cell_window_kernel<true, real>), dim3(cell_nwin_, nrep_), b, 0, stream_, S, C, pos_, cell_wstart_dev_, cell_nwin_, mask);
+        else hipLaunchKernelGGL((cell_window_kernel<false, real>), dim3(cell_nwin_, nrep_), b, 0, stream_, S, C, pos_, cell_wstart_dev_, cell_nwin_, mask);
+    }
     if (cell_njobs_) {
         if (energy) hipLaunchKernelGGL((cell_bonded_kernel<true, real>), dim3(cell_njobs_, nrep_), b, 0, stream_, S, C, pos_, cell_jobs_, mask);
         else hipLaunchKernelGGL((cell_bonded_kernel<false, real>), dim3(cell_njobs_, nrep_), b, 0, stream_, S, C, pos_, cell_jobs_, mask);
     }
-    if (S.n_contact && ((mask >> S.contact[0].group) & 1u)) {
-        HIP_TRY(hipMemsetAsync(C.rho, 0, R * C.nsites * sizeof(u64), stream_));
-        const dim3 gl = cell_grid(C.ccap / 4), gs = cell_grid(C.nsites);
-        hipLaunchKernelGGL(cell_density_kernel<real>, gl, b, 0, stream_, S, C, pos_);
-        if (energy) hipLaunchKernelGGL((cell_single_kernel<true, real>), gs, b, 0, stream_, S, C, pos_);
-        else hipLaunchKernelGGL((cell_single_kernel<false, real>), gs, b, 0, stream_, S, C, pos_);
-        if (!(S.contact[0].flags & 2)) {
-            if (energy) hipLaunchKernelGGL((cell_pairs_kernel<true, real>), gl, b, 0, stream_, S, C, pos_);
-            else hipLaunchKernelGGL((cell_pairs_kernel<false, real>), gl, b, 0, stream_, S, C, pos_);
-        }
-        hipLaunchKernelGGL(cell_chain_kernel<real>, gl, b, 0, stream_, S, C, pos_);
+    auto row_blocks = [](int n) { return (int)std::max(1LL, std::min(((long long)n * AWSEM_ROW + 255) / 256, 16384LL)); };
+    const bool contact_on = S.n_contact && ((mask >> S.contact[0].group) & 1u);
+    const bool excl_on = S.n_excl && ((mask >> S.excl[0].group) & 1u);
+    if (contact_on || excl_on) {
+        const int nbc = contact_on ? row_blocks(C.bin[0].n) : 0, nbx = excl_on ? row_blocks(C.bin[1].n) : 0;
+        if (energy) hipLaunchKernelGGL((cell_density_excl_kernel<true, real>), dim3(nbc + nbx, nrep_), b, 0, stream_, S, C, pos_, nbc, mask);
+        else hipLaunchKernelGGL((cell_density_excl_kernel<false, real>), dim3(nbc + nbx, nrep_), b, 0, stream_, S, C, pos_, nbc, mask);
     }
-    if (S.n_excl && ((mask >> S.excl[0].group) & 1u)) {
-        const dim3 gx = cell_grid(C.xcap / 4);
-        if (energy) hipLaunchKernelGGL((cell_excl_kernel<true, real>), gx, b, 0, stream_, S, C, pos_);
-        else hipLaunchKernelGGL((cell_excl_kernel<false, real>), gx, b, 0, stream_, S, C, pos_);
+    if (contact_on) {
+        const dim3 g(row_blocks(C.bin[0].n), nrep_);
+        if (!(S.contact[0].flags & 2)) {
+            if (energy) hipLaunchKernelGGL((cell_pairs_kernel<true, real>), g, b, 0, stream_, S, C, pos_);
+            else hipLaunchKernelGGL((cell_pairs_kernel<false, real>), g, b, 0, stream_, S, C, pos_);
+        }
+        hipLaunchKernelGGL(cell_chain_kernel<real>, g, b, 0, stream_, S, C, pos_);
     }
     HIP_TRY(hipGetLastError());
 }
 template <class real> void Engine<real>::cell_evaluate(bool energy, unsigned mask, int redistribute, double* e, double* f) {
-    auto rc2 = [&](double cutoff) { double r = cutoff + skin_; return cutoff > 0 ? (real)(r * r) : (real)-1; };
+    const size_t R = nrep_;
     for (int attempt = 0;; attempt++) {
         HIP_TRY(hipEventRecord(ev0_, stream_));
-        cell_refresh(cell_, rc2(cell_rc_contact_), rc2(cell_rc_excl_));
+        HIP_TRY(hipMemsetAsync(cell_.f, 0, R * 3 * natoms_ * sizeof(u64), stream_));
+        if (energy) HIP_TRY(hipMemsetAsync(cell_.eg, 0, R * AWSEM_NGROUPS * sizeof(u64), stream_));
+        cell_pre(false);
+        cell_refresh(cell_);
         cell_forces_pass(energy, mask);
         if (f && redistribute) hipLaunchKernelGGL(cell_redistribute_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, cell_, pos_);
         hipLaunchKernelGGL(cell_output_kernel<real>, cell_grid(natoms_), dim3(256), 0, stream_, cell_, f ? dF_ : (double*)nullptr, e ? dE_ : (double*)nullptr);
@@ -853,26 +931,57 @@ template <class real> void Engine<real>::cell_evaluate(bool energy, unsigned mas
         HIP_TRY(hipMemcpy(&st, dstatus_, sizeof st, hipMemcpyDeviceToHost));
         if (!(st & 2)) break;
         HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
-        if (attempt >= 4) throw std::string("cell-list path: neighbour lists keep overflowing (more than 2048 pairs per site)");
+        if (attempt >= 5) throw std::string("cell-list path: neighbour rows keep overflowing (more than 2048 partners per site)");
         cell_per_site_ *= 2;   // denser than expected: reserve more and rebuild
         cell_alloc_lists();
     }
     if (e) HIP_TRY(hipMemcpy(e, dE_, sizeof(double) * nrep_ * AWSEM_NGROUPS, hipMemcpyDeviceToHost));
     if (f) HIP_TRY(hipMemcpy(f, dF_, sizeof(double) * 3 * natoms_ * nrep_, hipMemcpyDeviceToHost));
 }
+// one MD step on the stream; `offset` is added to the device-resident step base by the integrator
+template <class real> void Engine<real>::cell_one_step(double dt, double friction, uint64_t seed, int offset) {
+    cell_pre(true);
+    cell_refresh(cell_);
+    cell_forces_pass(false, 0xffffffffu);
+    hipLaunchKernelGGL(cell_integrate_kernel<real>, cell_grid(dsys_.nmassive), dim3(256), 0, stream_, dsys_, cell_, pos_, vel_, dT_, dt, friction,
+                       (unsigned long long)seed, (const long long*)cell_step_base_, offset);
+}
+// A launch of `nsteps` is played as captured HIP graphs of AWSEM_CELL_CHUNK steps (the ~11 kernels of a step cost more
+// to enqueue from the host than to run) plus single steps for the remainder; AWSEM_CELL_GRAPH=0 disables the graphs.
+#define AWSEM_CELL_CHUNK 10
 template <class real> void Engine<real>::cell_step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) {
     HIP_TRY(hipSetDevice(device_));
     upload_T(T);
-    auto rc2 = [&](double cutoff) { double r = cutoff + skin_; return cutoff > 0 ? (real)(r * r) : (real)-1; };
-    const real rc2c = rc2(cell_rc_contact_), rc2x = rc2(cell_rc_excl_);
+    if (!cell_step_base_) cell_step_base_ = dalloc<long long>(1);
+    static const bool use_graph = !(getenv("AWSEM_CELL_GRAPH") && atoi(getenv("AWSEM_CELL_GRAPH")) == 0);
     HIP_TRY(hipEventRecord(ev0_, stream_));
-    for (int s = 0; s < nsteps; s++) {
-        hipLaunchKernelGGL(cell_vsite_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, pos_);
-        cell_refresh(cell_, rc2c, rc2x);
-        cell_forces_pass(false, 0xffffffffu);
-        hipLaunchKernelGGL(cell_redistribute_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, cell_, pos_);
-        hipLaunchKernelGGL(cell_integrate_kernel<real>, cell_grid(dsys_.nmassive), dim3(256), 0, stream_, dsys_, cell_, pos_, vel_, dT_, dt, friction,
-                           (unsigned long long)seed, (long long)(step0 + s));
+    HIP_TRY(hipMemsetAsync(cell_.f, 0, (size_t)nrep_ * 3 * natoms_ * sizeof(u64), stream_));
+    int s = 0;
+    auto set_base = [&](long long v) { hipLaunchKernelGGL(cell_set_word_kernel<long long>, dim3(1), dim3(1), 0, stream_, cell_step_base_, v); };
+    while (s < nsteps) {
+        // the rows are rebuilt unconditionally (a host-side decision baked into the launch) right after the coordinates were set
+        if (use_graph && !cell_stale_ && nsteps - s >= AWSEM_CELL_CHUNK) {
+            CellGraph& G = cell_graph_[cell_cur_];   // the flag parity is baked into the captured launches
+            if (!G.exec || G.dt != dt || G.friction != friction || G.seed != seed || G.rows0 != cell_.bin[0].rows || G.rows1 != cell_.bin[1].rows) {
+                if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+                const int cur0 = cell_cur_;
+                hipGraph_t graph = nullptr;
+                HIP_TRY(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+                for (int k = 0; k < AWSEM_CELL_CHUNK; k++) cell_one_step(dt, friction, seed, k);
+                HIP_TRY(hipStreamEndCapture(stream_, &graph));
+                HIP_TRY(hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0));
+                HIP_TRY(hipGraphDestroy(graph));
+                cell_cur_ = cur0;   // capturing ran nothing; AWSEM_CELL_CHUNK is even, so a replay ends on the parity it started on
+                G.dt = dt; G.friction = friction; G.seed = seed; G.rows0 = cell_.bin[0].rows; G.rows1 = cell_.bin[1].rows;
+            }
+            set_base((long long)(step0 + s));
+            HIP_TRY(hipGraphLaunch(G.exec, stream_));
+            s += AWSEM_CELL_CHUNK;
+        } else {
+            set_base((long long)(step0 + s));
+            cell_one_step(dt, friction, seed, 0);
+            s++;
+        }
     }
     hipLaunchKernelGGL(cell_vsite_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, pos_);
     HIP_TRY(hipGetLastError());
@@ -882,38 +991,43 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
 template <class real> int Engine<real>::cell_neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) {
     if (index != 0 || (kind != AWSEM_LIST_EXCL && kind != AWSEM_LIST_CONTACT)) throw std::string("neighbors (cell-list path): kind must be AWSEM_LIST_EXCL or AWSEM_LIST_CONTACT, index 0");
     if ((kind == AWSEM_LIST_EXCL && !dsys_.n_excl) || (kind == AWSEM_LIST_CONTACT && !dsys_.n_contact)) throw std::string("neighbors: no such term");
-    const double cutoff = kind == AWSEM_LIST_EXCL ? cell_rc_excl_ : cell_rc_contact_, r = cutoff + skin;
-    std::vector<u64> ent;
+    const int b = kind == AWSEM_LIST_EXCL ? 1 : 0;
+    const double cutoff = b ? cell_rc_excl_ : cell_rc_contact_, r = cutoff + skin;
     for (int attempt = 0;; attempt++) {
         CellSys<real> C = cell_;
-        C.rc_cell = (real)std::max((double)C.rc_cell, r);
+        C.bin[b].edge_min = (real)std::max((double)C.bin[b].edge_min, r);
+        C.bin[b].rc2 = (real)(r * r);
+        cell_pre(false);
         cell_stale_ = true;
-        cell_refresh(C, kind == AWSEM_LIST_CONTACT ? (real)(r * r) : (real)-1, kind == AWSEM_LIST_EXCL ? (real)(r * r) : (real)-1);
-        cell_stale_ = true;   // the lists now hold a non-standard cutoff: rebuild before the next evaluation
+        cell_refresh(C);
+        cell_stale_ = true;   // the rows now hold a non-standard cutoff: rebuild before the next evaluation
         HIP_TRY(hipStreamSynchronize(stream_));
         int st = 0;
         HIP_TRY(hipMemcpy(&st, dstatus_, sizeof st, hipMemcpyDeviceToHost));
         if (!(st & 2)) break;
         HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
-        if (attempt >= 4) throw std::string("cell-list path: neighbour lists keep overflowing");
+        if (attempt >= 5) throw std::string("cell-list path: neighbour rows keep overflowing");
         cell_per_site_ *= 2;
         cell_alloc_lists();
     }
-    unsigned counts[2];
-    HIP_TRY(hipMemcpy(counts, cell_.counts + 2 * (size_t)rep, sizeof counts, hipMemcpyDeviceToHost));
-    const unsigned n = counts[kind == AWSEM_LIST_EXCL ? 1 : 0];
-    ent.resize(n);
-    const u64* src = kind == AWSEM_LIST_EXCL ? cell_.xlist + (size_t)rep * cell_.xcap : cell_.clist + (size_t)rep * cell_.ccap;
-    if (n) HIP_TRY(hipMemcpy(ent.data(), src, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
-    std::vector<std::pair<int, int>> out(n);
-    for (unsigned k = 0; k < n; k++) {
-        if (kind == AWSEM_LIST_CONTACT) out[k] = {(int)(ent[k] & 0xffffff), (int)((ent[k] >> 24) & 0xffffff)};
-        else out[k] = {(int)(ent[k] & 0xffffffffu), (int)(ent[k] >> 32)};
-        if (out[k].first > out[k].second) std::swap(out[k].first, out[k].second);   // the half-shell scan meets a pair in either order
+    const CellBin<real>& B = cell_.bin[b];
+    std::vector<int> cnt(B.n);
+    std::vector<unsigned> rows((size_t)B.n * B.stride);
+    if (B.n) {
+        HIP_TRY(hipMemcpy(cnt.data(), B.row_count + (size_t)rep * B.n, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(rows.data(), B.rows + (size_t)rep * B.n * B.stride, rows.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
     }
+    std::vector<std::pair<int, int>> out;
+    for (int i = 0; i < B.n; i++)
+        for (int s = 0; s < cnt[i]; s++) {
+            const int j = (int)(rows[(size_t)i * B.stride + s] & 0xffffffu);
+            if (b == 0) { if (i < j) out.push_back({i, j}); }   // every pair sits in both rows: keep the one of the lower site
+            else { const int a = excl_sorted_atom_[i], c = excl_sorted_atom_[j]; if (a < c) out.push_back({a, c}); }
+        }
     std::sort(out.begin(), out.end());
-    for (unsigned k = 0; k < n && (int)k < capacity; k++) { pairs[2 * k] = out[k].first; pairs[2 * k + 1] = out[k].second; }
-    return (int)n;
+    const int n = (int)out.size();
+    for (int k = 0; k < n && k < capacity; k++) { pairs[2 * k] = out[k].first; pairs[2 * k + 1] = out[k].second; }
+    return n;
 }
 
 }  // namespace

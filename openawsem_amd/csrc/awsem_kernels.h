@@ -581,50 +581,58 @@ template <bool ENERGY, class V> __device__ void contact_single(const ContactD<ty
     for (int i = rot_tid(rot); i < d.nsites; i += blockDim.x) single_body<ENERGY>(d, L, i, satom[i], e);
     flush_energy<ENERGY>(L, d.group, e);
 }
-// pass 2: pair energy (direct + mediated), its explicit radial force, and dE/drho through sigma_water
+// pass 2: pair energy (direct + mediated), its explicit radial force, and dE/drho through sigma_water.
+// contact_pair_math: the arithmetic for one pair at distance r (shared by the list-driven passes of both paths):
+// E, dE/dr, dE/d(sigma_water) and, for the z-dependent variant, M - W (membrane minus water energy).
+template <class real> struct PairTerms { real E, dEdr, dEdsw, MW; };
+template <class real> __device__ __forceinline__ PairTerms<real> contact_pair_math(const ContactD<real>& d, const real* g0, int ty, real r, real sw, real aa) {
+    const real* g1 = g0 + 1200;
+    const real one = (real)1;
+    const real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
+    const real s3 = sigmoid(d.eta2 * (r - d.rminII)), s4 = sigmoid(d.eta2 * (d.rmaxII - r));
+    const real th1 = s1 * s2, dth1 = d.eta2 * th1 * (s2 - s1);
+    const real th2 = s3 * s4, dth2 = d.eta2 * th2 * (s4 - s3);
+    PairTerms<real> o;
+    if (!(d.flags & 1)) {
+        const real gd = g0[ty], gp = g0[400 + ty], gw = g0[800 + ty];
+        const real med = sw * gw + (one - sw) * gp;
+        o.E = -d.k * (gd * th1 + th2 * med);
+        o.dEdr = -d.k * (gd * dth1 + dth2 * med);
+        o.dEdsw = -d.k * th2 * (gw - gp);
+        o.MW = 0;
+    } else {
+        const real med0 = sw * g0[800 + ty] + (one - sw) * g0[400 + ty];
+        const real med1 = sw * g1[800 + ty] + (one - sw) * g1[400 + ty];
+        const real W = -d.k * (g0[ty] * th1 + th2 * med0), Mm = -d.k * (g1[ty] * th1 + th2 * med1);
+        const real dW = -d.k * (g0[ty] * dth1 + dth2 * med0), dM = -d.k * (g1[ty] * dth1 + dth2 * med1);
+        o.E = (one - aa) * W + aa * Mm;
+        o.dEdr = (one - aa) * dW + aa * dM;
+        o.dEdsw = -d.k * th2 * ((one - aa) * (g0[800 + ty] - g0[400 + ty]) + aa * (g1[800 + ty] - g1[400 + ty]));
+        o.MW = Mm - W;
+    }
+    return o;
+}
 template <bool ENERGY, class V> __device__ __forceinline__ void pairs_body(const ContactD<typename V::real_t>& d, const V& L, int i, int j, int ty, int a, int b, bool v, Energy& e) {
     typedef typename V::real_t real;
     const bool zdep = d.flags & 1;
-    const real* g0 = L.gamma;
-    const real* g1 = L.gamma + 1200;
     const real one = (real)1;
     const R3<real> dd = L.pos(a) - L.pos(b);
     const real r2 = dist2(dd);
     const bool pass = v && r2 < d.cutoff2;
     if (__ballot(pass) == 0) return;
     const real ir = M<real>::rsqrt(pass ? r2 : one), r = r2 * ir;
-    const real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
-    const real s3 = sigmoid(d.eta2 * (r - d.rminII)), s4 = sigmoid(d.eta2 * (d.rmaxII - r));
-    const real th1 = s1 * s2, dth1 = d.eta2 * th1 * (s2 - s1);
-    const real th2 = s3 * s4, dth2 = d.eta2 * th2 * (s4 - s3);
-    const real si = L.rhov[i], sj = L.rhov[j], sw = si * sj;
-    real E, dEdr, dEdsw, fzi = 0, fzj = 0;
-    if (!zdep) {
-        const real gd = g0[ty], gp = g0[400 + ty], gw = g0[800 + ty];
-        const real med = sw * gw + (one - sw) * gp;
-        E = -d.k * (gd * th1 + th2 * med);
-        dEdr = -d.k * (gd * dth1 + dth2 * med);
-        dEdsw = -d.k * th2 * (gw - gp);
-    } else {
-        const real med0 = sw * g0[800 + ty] + (one - sw) * g0[400 + ty];
-        const real med1 = sw * g1[800 + ty] + (one - sw) * g1[400 + ty];
-        const real W = -d.k * (g0[ty] * th1 + th2 * med0), Mm = -d.k * (g1[ty] * th1 + th2 * med1);
-        const real dW = -d.k * (g0[ty] * dth1 + dth2 * med0), dM = -d.k * (g1[ty] * dth1 + dth2 * med1);
-        const real ai = L.alpha[i], aj = L.alpha[j], aa = ai * aj;
-        E = (one - aa) * W + aa * Mm;
-        dEdr = (one - aa) * dW + aa * dM;
-        dEdsw = -d.k * th2 * ((one - aa) * (g0[800 + ty] - g0[400 + ty]) + aa * (g1[800 + ty] - g1[400 + ty]));
-        fzi = -(Mm - W) * aj * L.dalpha[i];
-        fzj = -(Mm - W) * ai * L.dalpha[j];
-    }
+    const real si = L.rhov[i], sj = L.rhov[j];
+    real ai = 0, aj = 0;
+    if (zdep) { ai = L.alpha[i]; aj = L.alpha[j]; }
+    const PairTerms<real> t = contact_pair_math(d, L.gamma, ty, r, si * sj, ai * aj);
     if (pass) {
-        if (ENERGY) e += (double)E;
-        L.pair_force(a, b, dd.x, dd.y, dd.z, -dEdr * ir);
-        fixed_add(&L.drho[i], to_fixed(dEdsw * sj * (-d.eta_s2 * si * (one - si))));
-        fixed_add(&L.drho[j], to_fixed(dEdsw * si * (-d.eta_s2 * sj * (one - sj))));
+        if (ENERGY) e += (double)t.E;
+        L.pair_force(a, b, dd.x, dd.y, dd.z, -t.dEdr * ir);
+        fixed_add(&L.drho[i], to_fixed(t.dEdsw * sj * (-d.eta_s2 * si * (one - si))));
+        fixed_add(&L.drho[j], to_fixed(t.dEdsw * si * (-d.eta_s2 * sj * (one - sj))));
         if (zdep) {
-            L.add_fz(a, fzi);
-            L.add_fz(b, fzj);
+            L.add_fz(a, -t.MW * aj * L.dalpha[i]);
+            L.add_fz(b, -t.MW * ai * L.dalpha[j]);
         }
     }
 }
