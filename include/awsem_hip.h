@@ -192,6 +192,15 @@ int awsem_step(awsem_handle h, int nsteps, const double* T_kelvin, double dt_ps,
 int64_t awsem_step_count(awsem_handle h);
 int awsem_set_step_count(awsem_handle h, int64_t step);
 
+/* simulation.minimizeEnergy(tolerance, maxIterations) scripts/mm_run.py:136,153 (OpenMM LocalEnergyMinimizer).
+ * Every replica is relaxed on the device until the RMS force over its massive degrees of freedom is <= tolerance
+ * (kJ/mol/nm) or max_iterations force evaluations are spent (0 = no limit); virtual sites follow their parents,
+ * velocities are left untouched.  The algorithm is FIRE, not OpenMM's L-BFGS: the reference pins only the contract
+ * (a nearby local minimum within the force tolerance).  iterations / rms_force: n_replicas values each, or NULL.
+ * Replica-resident path only (AWSEM_ELIMIT on the cell-list path). */
+int awsem_minimize(awsem_handle h, double tolerance_kj_mol_nm, int max_iterations, int32_t* iterations,
+                   double* rms_force);
+
 /* Wall time of the last awsem_step / awsem_energy* / awsem_forces kernel launch measured with HIP events on
  * the handle's stream (ms); used by bench.py for the roofline line. */
 int awsem_last_kernel_ms(awsem_handle h, double* ms);

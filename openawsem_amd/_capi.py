@@ -50,6 +50,7 @@ _SIGNATURES = {
     "energy_by_group": (C.c_int, ["H", c_dbl_p]),
     "forces": (C.c_int, ["H", C.c_uint32, C.c_int, c_dbl_p]),
     "step": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_double, C.c_double, C.c_uint64]),
+    "minimize": (C.c_int, ["H", C.c_double, C.c_int, c_int_p, c_dbl_p]),
     "step_count": (C.c_int64, ["H"]),
     "set_step_count": (C.c_int, ["H", C.c_int64]),
     "neighbors": (C.c_int, ["H", C.c_int, C.c_int, C.c_int, C.c_double, c_int_p, C.c_int, c_int_p]),
@@ -263,6 +264,13 @@ class Context:
     def step(self, nsteps, T, dt_ps, friction_per_ps, seed):
         T = np.broadcast_to(_f64(T), (self.n_replicas,)).copy()
         self._call("step", int(nsteps), _dp(T), float(dt_ps), float(friction_per_ps), C.c_uint64(int(seed)))
+
+    def minimize(self, tolerance=10.0, max_iterations=0):
+        """FIRE on the device for every replica at once (awsem_minimize); returns (iterations, rms_force) per replica."""
+        it = np.zeros(self.n_replicas, dtype=np.int32)
+        rms = np.zeros(self.n_replicas)
+        self._call("minimize", float(tolerance), int(max_iterations), it.ctypes.data_as(c_int_p), _dp(rms))
+        return it, rms
 
     @property
     def step_count(self):

@@ -82,6 +82,7 @@ struct EngineBase {
     virtual void forces(unsigned mask, int redistribute, double* f) = 0;
     virtual void step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) = 0;
     virtual void synchronize() = 0;
+    virtual void minimize(double tolerance, int max_iterations, int32_t* iterations, double* rms) = 0;
     virtual int neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) = 0;
     double last_ms = 0.0;
 };
@@ -184,6 +185,22 @@ public:
         HIP_TRY(hipEventRecord(ev1_, stream_));
         timing_pending_ = true;   // asynchronous: resolved by synchronize()/last_kernel_ms
     }
+    void minimize(double tolerance, int max_iterations, int32_t* iterations, double* rms) override {
+        if (cell_mode_) throw std::string("minimize: the device minimiser runs on the replica-resident path only (this system takes the cell-list path)");
+        if (!step_ok_) throw std::string("minimize: the replica does not fit the LDS of one CU together with its velocities in this precision");
+        HIP_TRY(hipSetDevice(device_));
+        if (!dmin_it_) { dmin_it_ = dalloc<int>(nrep_); dmin_rms_ = dalloc<double>(nrep_); }
+        HIP_TRY(hipEventRecord(ev0_, stream_));
+        hipLaunchKernelGGL(awsem_minimize_kernel<real>, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, tolerance,
+                           max_iterations > 0 ? max_iterations : 100000, dmin_it_, dmin_rms_);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev1_, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        record_ms();
+        check_status();
+        if (iterations) HIP_TRY(hipMemcpy(iterations, dmin_it_, sizeof(int) * nrep_, hipMemcpyDeviceToHost));
+        if (rms) HIP_TRY(hipMemcpy(rms, dmin_rms_, sizeof(double) * nrep_, hipMemcpyDeviceToHost));
+    }
     void synchronize() override {
         HIP_TRY(hipSetDevice(device_));
         HIP_TRY(hipStreamSynchronize(stream_));
@@ -260,6 +277,8 @@ private:
     double *dT_ = nullptr, *dE_ = nullptr, *dF_ = nullptr;
     const HostSystem* host_ = nullptr;   // owned by the handle, outlives the engine
     int* dstatus_ = nullptr;
+    int* dmin_it_ = nullptr;
+    double* dmin_rms_ = nullptr;
     unsigned* dcounts_ = nullptr;
     double skin_ = 0.15;
     size_t lds_list_ = 0, lds_max_ = 0;
@@ -722,6 +741,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<true, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<false, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
+    if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_minimize_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_list_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     block_ = natoms_ > 1024 ? 512 : 256;
     if (const char* env = getenv("AWSEM_BLOCK")) {
@@ -1250,6 +1270,11 @@ int awsem_scale_velocities(awsem_handle h, const double* scale) {
     NEED_RUN(h);
     if (!scale) return fail(AWSEM_EINVAL, "scale_velocities: null factors");
     GUARD_BEGIN h->eng->scale_velocities(scale); return AWSEM_OK; GUARD_END
+}
+int awsem_minimize(awsem_handle h, double tolerance, int max_iterations, int32_t* iterations, double* rms_force) {
+    NEED_RUN(h);
+    if (!(tolerance > 0) || max_iterations < 0) return fail(AWSEM_EINVAL, "minimize: tolerance must be positive, max_iterations >= 0");
+    GUARD_BEGIN h->eng->minimize(tolerance, max_iterations, iterations, rms_force); return AWSEM_OK; GUARD_END
 }
 int awsem_energy_by_group(awsem_handle h, double* e) {
     NEED_RUN(h);

@@ -1153,3 +1153,123 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
         gv[i] = v.x; gv[natoms + i] = v.y; gv[2 * natoms + i] = v.z;
     }
 }
+
+// ------------------------------------------------------------------ energy minimiser (simulation.minimizeEnergy())
+// FIRE (Bitzek et al. 2006) on the massive particles with unit masses, every replica in its own workgroup with the
+// state LDS-resident and the same force phases as the step kernel; restated in fp64 in oracle/awsem_oracle.c
+// (awsem_oracle_minimize).  OpenMM's LocalEnergyMinimizer is L-BFGS; the reference pins nothing about the minimiser
+// beyond its contract (a local minimum with RMS force <= tolerance), which is what the tests check.
+// The three sums an iteration needs (F.v, F.F, v.v) are fixed-point LDS accumulators (L.eg[0..2]), so a minimisation is
+// bit-reproducible; F.v and F.F are scaled by 2^-10 / 2^-20 to stay inside Q31.32 for the clashing start structures.
+template <class real>
+__global__ void awsem_minimize_kernel(const DevSys<real> S, real* __restrict__ pos, double tolerance, int max_iterations,
+                                      int* __restrict__ iterations /* [R] */, double* __restrict__ rms_out /* [R] */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int natoms = S.natoms, rep = blockIdx.x;
+    Lds<real> L = carve_lds((real)0, smem, natoms, S.max_contact_sites, S.n_contact, true);
+    L.lists = S.lists + (size_t)rep * S.list_stride;
+    real* gp = pos + (size_t)rep * 3 * natoms;
+    load_positions(gp, L, natoms);
+    for (int i = threadIdx.x; i < natoms; i += blockDim.x) L.set_vel(i, R3<real>{0, 0, 0});
+    for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
+    stage_tables(S, L);
+    if (threadIdx.x < 2) L.flag[threadIdx.x] = 0;
+    __syncthreads();
+    compute_virtual_sites(S, L);
+    __syncthreads();
+    real dt = (real)0.001, alpha = (real)0.1;
+    const real dt_max = (real)0.01, dmax2 = (real)(0.02 * 0.02);
+    const double sP = 1.0 / 1024.0, sF = 1.0 / (1024.0 * 1024.0);
+    int npos = 0, it = 0;
+    double rms = 0;
+    AWSEM_STAMP_INIT;
+    for (; it < max_iterations; it++) {
+        const int cur = it & 1;
+        if (it == 0 || __uint_as_float(L.flag[cur]) > (float)S.skin_half2) {   // uniform across the workgroup
+            if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
+            for (int i = threadIdx.x; i < natoms; i += blockDim.x) L.set_ref(i, L.pos(i));
+            __syncthreads();
+            build_lists(S, L, 0xffffffffu);
+            __syncthreads();
+        }
+        if (threadIdx.x < 3) L.eg[threadIdx.x] = 0;   // visible before anyone adds: the evaluation has barriers
+        evaluate_terms<false>(S, L, 0xffffffffu AWSEM_STAMP_PASS);
+        if (threadIdx.x == 0) L.flag[cur] = 0;
+        {   // pass 1: the sums
+            Energy eP, eF, eV;
+            for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {
+                const GatherItem<real> gi = S.gather[k];
+                const int i = S.massive[k].atom;
+                R3<real> F = L.force(i);
+#pragma unroll
+                for (int q = 0; q < AWSEM_MAX_GATHER; q++) {
+                    if (gi.vs[q] < 0) continue;
+                    const R3<real> fv = L.force(gi.vs[q]);
+                    F.x += gi.w[q] * fv.x; F.y += gi.w[q] * fv.y; F.z += gi.w[q] * fv.z;
+                }
+                const R3<real> v = L.vel(i);
+                eP += (double)(F.x * v.x + F.y * v.y + F.z * v.z) * sP;
+                eF += (double)(F.x * F.x + F.y * F.y + F.z * F.z) * sF;
+                eV += (double)(v.x * v.x + v.y * v.y + v.z * v.z);
+            }
+            flush_energy<true>(L, 0, eP); flush_energy<true>(L, 1, eF); flush_energy<true>(L, 2, eV);
+        }
+        __syncthreads();
+        const double P = fixed_to_double(L.eg[0]) / sP, FF = fixed_to_double(L.eg[1]) / sF, VV = fixed_to_double(L.eg[2]);
+        rms = ::sqrt(FF / (3.0 * (S.nmassive > 0 ? S.nmassive : 1)));
+        if (rms <= tolerance) break;   // uniform
+        real keep = 0, mix = 0;
+        if (P >= 0) {   // not uphill (the first iteration has v = 0)
+            keep = (real)1 - alpha; mix = alpha * (real)::sqrt(VV / FF);
+            if (++npos > 5) { dt = dt * (real)1.1 < dt_max ? dt * (real)1.1 : dt_max; alpha *= (real)0.99; }
+        } else { npos = 0; dt *= (real)0.5; alpha = (real)0.1; }
+        {   // pass 2: velocity mixing, Euler step with the displacement clamp
+            float m = 0;
+            for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {
+                const GatherItem<real> gi = S.gather[k];
+                const int i = S.massive[k].atom;
+                R3<real> F = L.force(i);
+                L.zero_force(i);
+#pragma unroll
+                for (int q = 0; q < AWSEM_MAX_GATHER; q++) {
+                    if (gi.vs[q] < 0) continue;
+                    const R3<real> fv = L.force(gi.vs[q]);
+                    F.x += gi.w[q] * fv.x; F.y += gi.w[q] * fv.y; F.z += gi.w[q] * fv.z;
+                }
+                R3<real> v = L.vel(i), x = L.pos(i);
+                v.x = keep * v.x + mix * F.x + dt * F.x;
+                v.y = keep * v.y + mix * F.y + dt * F.y;
+                v.z = keep * v.z + mix * F.z + dt * F.z;
+                real dx = dt * v.x, dy = dt * v.y, dz = dt * v.z;
+                const real d2 = dx * dx + dy * dy + dz * dz;
+                if (d2 > dmax2) { const real sc = M<real>::sqrt(dmax2 / d2); dx *= sc; dy *= sc; dz *= sc; }
+                x.x += dx; x.y += dy; x.z += dz;
+                L.set_vel(i, v); L.set_pos(i, x);
+                m = fmaxf(m, (float)dist2(x - L.refpos(i)));
+            }
+            book_displacement(&L.flag[cur ^ 1], m);
+        }
+        __syncthreads();
+        {
+            float m = 0;
+            for (int i = threadIdx.x; i < S.nvs; i += blockDim.x) {
+                const Int4 v = S.vs[i];
+                const real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
+                const R3<real> pa = L.pos(v.y), pb = L.pos(v.z), pc = L.pos(v.w);
+                const R3<real> x = R3<real>{w0 * pa.x + w1 * pb.x + w2 * pc.x, w0 * pa.y + w1 * pb.y + w2 * pc.y, w0 * pa.z + w1 * pb.z + w2 * pc.z};
+                L.set_pos(v.x, x);
+                L.zero_force(v.x);
+                m = fmaxf(m, (float)dist2(x - L.refpos(v.x)));
+            }
+            for (int i = threadIdx.x; i < S.nfixed; i += blockDim.x) L.zero_force(S.fixed[i]);
+            for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
+            book_displacement(&L.flag[cur ^ 1], m);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
+        const R3<real> x = L.pos(i);
+        gp[i] = x.x; gp[natoms + i] = x.y; gp[2 * natoms + i] = x.z;
+    }
+    if (threadIdx.x == 0) { iterations[rep] = it; rms_out[rep] = rms; }
+}

@@ -296,8 +296,17 @@ class Simulation:
         self.currentStep = 0
 
     def minimizeEnergy(self, tolerance=10.0, maxIterations=0):
-        for r in range(self.context.n_replicas):
-            minimize(self.context, tolerance, maxIterations, replica=r)
+        """All replicas at once on the device (FIRE, awsem_minimize); systems on the cell-list path fall back to the
+        host-driven L-BFGS of `minimize`, one replica at a time."""
+        from ._capi import AwsemError
+        tol = _value(tolerance, u.kilojoule_per_mole / u.nanometer)
+        try:
+            self.last_minimization = self.context._ctx.minimize(tol, int(maxIterations))
+        except AwsemError as err:
+            if err.code != -4:   # AWSEM_ELIMIT: not available for this system
+                raise
+            for r in range(self.context.n_replicas):
+                minimize(self.context, tolerance, maxIterations, replica=r)
 
     def step(self, steps):
         steps = int(steps)

@@ -755,6 +755,62 @@ int awsem_oracle_step(ctx_t* c, int nsteps, const double* T, double dt, double f
     c->step += nsteps;
     return 0;
 }
+/* simulation.minimizeEnergy() (scripts/mm_run.py:136,153).  OpenMM's LocalEnergyMinimizer is L-BFGS; nothing in the
+ * reference pins the minimiser beyond "a local minimum within the force tolerance", so this is the engine's own
+ * algorithm restated in fp64 (parity unpinned): FIRE (Bitzek et al. 2006) on the massive particles with unit masses,
+ *   P = F.v;  v <- (1-alpha) v + alpha |v| F/|F|;  P >= 0 for more than 5 steps: dt <- min(1.1 dt, dt_max), alpha *= 0.99;
+ *   P < 0: v <- 0, dt <- dt/2, alpha <- 0.1;   v <- v + dt F;  x <- x + clamp(dt v, |.| <= 0.02 nm);  virtual sites re-derived,
+ * until the RMS force over the massive degrees of freedom is <= tolerance (kJ/mol/nm) or max_iterations is reached. */
+int awsem_oracle_minimize(ctx_t* c, double tolerance, int max_iterations, int* iterations, double* rms_force) {
+    CHECK_RUN(c);
+    if (!(tolerance > 0) || max_iterations < 0) return fail(-1, "minimize: bad arguments");
+    if (max_iterations == 0) max_iterations = 100000;
+    const int n = c->natoms;
+    int nm = 0;
+    for (int i = 0; i < n; i++) if (c->mass[i] != 0) nm++;
+#pragma omp parallel for num_threads(c->nthreads) schedule(dynamic)
+    for (int r = 0; r < c->nrep; r++) {
+        double* x = c->pos + (size_t)r * n * 3;
+        double* f = malloc((size_t)n * 3 * sizeof(double));
+        double* v = calloc((size_t)n * 3, sizeof(double));
+        double dt = 0.001, alpha = 0.1, rms = 0;
+        const double dt_max = 0.01, dmax = 0.02;
+        int npos = 0, it;
+        for (it = 0; it < max_iterations; it++) {
+            virtual_sites(c, x);
+            memset(f, 0, (size_t)n * 3 * sizeof(double));
+            evaluate(c, x, 0xffffffffu, NULL, f);
+            redistribute(c, f);
+            double P = 0, FF = 0, VV = 0;
+            for (int i = 0; i < n; i++) {
+                if (c->mass[i] == 0) continue;
+                for (int k = 0; k < 3; k++) { P += f[3 * i + k] * v[3 * i + k]; FF += f[3 * i + k] * f[3 * i + k]; VV += v[3 * i + k] * v[3 * i + k]; }
+            }
+            rms = sqrt(FF / (3.0 * (nm > 0 ? nm : 1)));
+            if (rms <= tolerance) break;
+            double keep = 0, mix = 0;
+            if (P >= 0) {   /* not uphill (the first iteration has v = 0) */
+                keep = 1.0 - alpha; mix = alpha * sqrt(VV / FF);
+                if (++npos > 5) { dt = dt * 1.1 < dt_max ? dt * 1.1 : dt_max; alpha *= 0.99; }
+            } else { npos = 0; dt *= 0.5; alpha = 0.1; }
+            for (int i = 0; i < n; i++) {
+                if (c->mass[i] == 0) continue;
+                double d[3], d2 = 0;
+                for (int k = 0; k < 3; k++) {
+                    const double vn = keep * v[3 * i + k] + mix * f[3 * i + k] + dt * f[3 * i + k];
+                    v[3 * i + k] = vn; d[k] = dt * vn; d2 += d[k] * d[k];
+                }
+                const double sc = d2 > dmax * dmax ? dmax / sqrt(d2) : 1.0;
+                for (int k = 0; k < 3; k++) x[3 * i + k] += sc * d[k];
+            }
+        }
+        virtual_sites(c, x);
+        if (iterations) iterations[r] = it;
+        if (rms_force) rms_force[r] = rms;
+        free(f); free(v);
+    }
+    return 0;
+}
 int64_t awsem_oracle_step_count(ctx_t* c) { return c ? c->step : -1; }
 int awsem_oracle_set_step_count(ctx_t* c, int64_t s) { if (!c) return fail(-1, "null handle"); c->step = s; return 0; }
 

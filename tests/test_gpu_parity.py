@@ -208,3 +208,62 @@ def test_trajectory_does_not_depend_on_list_skin(monkeypatch):
     assert np.isfinite(out[0]).all()
     assert np.abs(out[0][2] - traj[3]).max() > 0.05          # the chain really moved further than the small skins
     assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+
+
+# --------------------------------------------------------------------------- minimiser (awsem_minimize)
+# Parity unpinned by the reference: OpenMM's LocalEnergyMinimizer (L-BFGS) is only specified by its contract, a
+# nearby local minimum whose RMS force is below the tolerance.  The device minimiser (FIRE) is checked against that
+# contract, against the fp64 CPU restatement of the same algorithm, and for bit reproducibility.
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol_rms", [(FP32, 10.0), (FP64, 10.0)])
+def test_minimizer_reaches_the_force_tolerance(precision, tol_rms):
+    oa, traj, _ = golden_system("1ubq")
+    frames = [0, 5, 11]
+    gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=len(frames), precision=precision)
+    oa.system.upload(gpu)
+    for r, f in enumerate(frames):
+        gpu.set_positions(traj[f], replica=r)
+    gpu.compute_virtual_sites()
+    e0 = gpu.energy()
+    it, rms = gpu.minimize(tol_rms, 20000)
+    e1 = gpu.energy()
+    massive = oa.system.masses > 0
+    f = gpu.forces(redistribute=True)
+    rms_check = np.sqrt((f[:, massive] ** 2).sum(axis=(1, 2)) / (3 * massive.sum()))
+    assert np.all(it < 20000), it
+    assert np.all(rms <= tol_rms) and np.all(rms_check <= tol_rms * 1.01), (rms, rms_check)
+    assert np.all(e1 < e0 - 50.0), (e0, e1)            # the DCD frames are thermal structures: hundreds of kJ/mol above a minimum
+    x = np.stack([gpu.get_positions(r) for r in range(len(frames))])
+    assert np.isfinite(x).all()
+    # virtual sites sit where their parents put them
+    y = x.copy()
+    gpu.compute_virtual_sites()
+    assert np.allclose(y, np.stack([gpu.get_positions(r) for r in range(len(frames))]), atol=1e-5 if precision == FP32 else 1e-12)
+    # bit reproducible
+    for r, fr in enumerate(frames):
+        gpu.set_positions(traj[fr], replica=r)
+    gpu.compute_virtual_sites()
+    it2, rms2 = gpu.minimize(tol_rms, 20000)
+    assert np.array_equal(it, it2) and np.array_equal(rms, rms2)
+    assert np.array_equal(x, np.stack([gpu.get_positions(r) for r in range(len(frames))]))
+
+
+@pytest.mark.gpu
+def test_minimizer_follows_the_oracle_restatement():
+    """fp64 device FIRE vs the fp64 C restatement: same algorithm, so the first iterations agree closely and both end
+    in minima of comparable depth (the paths separate slowly: summation order only)."""
+    oa, traj, _ = golden_system("1ubq")
+    gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=1, precision=FP64)
+    oa.system.upload(gpu)
+    cpu = awsem_oracle.make_context(oa.system, n_replicas=1)
+    for c in (gpu, cpu):
+        c.set_positions(traj[3], replica=0)
+        c.compute_virtual_sites()
+    for c in (gpu, cpu):
+        c.minimize(1e-6, 25)       # 25 iterations, tolerance out of reach
+    assert np.abs(gpu.get_positions(0) - cpu.get_positions(0)).max() < 1e-7
+    ig, rg = gpu.minimize(10.0, 20000)
+    ic, rc = cpu.minimize(10.0, 20000)
+    assert rg[0] <= 10.0 and rc[0] <= 10.0
+    eg, ec = gpu.energy()[0], cpu.energy()[0]
+    assert abs(eg - ec) < 0.02 * abs(ec), (eg, ec, ig, ic)
