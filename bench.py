@@ -25,6 +25,16 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 
+# workload -> (builder name in openawsem_amd.workloads, builder kwargs, default replicas per GPU, default MD steps per launch, description)
+WORKLOADS = {
+    "1r69": ("build_1r69", {}, 1024, 50, "1r69 batched annealing ensemble, default forces_setup.py terms, 800->200 K Langevin (dt 2 fs, friction 1/ps)"),
+    "1r69-fraglib": ("build_1r69", {"fragment_library": True}, 1024, 50, "1r69 with the 1100-memory fragment library (examples/1r69/frags.mem), default terms, annealing ensemble"),
+    "t0958": ("build_t0958", {}, 768, 50, "T0958 (96 residues), default terms + helical + rama_ssweight, fragment memory, annealing ensemble"),
+    "2xov": ("build_2xov", {}, 256, 50, "2xov membrane protein (276 residues), membrane_term + z-dependent contact, annealing ensemble"),
+    "2xov-remd": ("build_2xov", {}, 64, 200, "2xov membrane protein, temperature replica exchange 300-600 K, exchange every launch (all-gather of energies, label swap)"),
+    "synthetic": ("build_synthetic", {}, 1, 20, "synthetic multi-chain system (122 x 2lzm), con/chain/chi/excl/rama/contact+burial, cell-list path, Langevin (dt 2 fs, friction 1/ps)"),
+}
+
 
 def cpu_baseline(oa, md_steps, budget_s=15.0):
     """The fp64 CPU oracle (kind "port": a restatement, OpenMM itself is not installable here) timed on the host
@@ -70,13 +80,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--replicas", type=int, default=1024, help="replicas per GPU")
-    ap.add_argument("--md-steps", type=int, default=50, help="Langevin steps per launch")
+    ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU (default: 1024 for 1r69, see WORKLOADS)")
+    ap.add_argument("--md-steps", type=int, default=None, help="Langevin steps per launch (default 50; 200 for 2xov-remd)")
     ap.add_argument("--precision", choices=["fp32", "fp64"], default="fp32")
-    ap.add_argument("--workload", choices=["1r69", "synthetic"], default="1r69",
-                    help="1r69: BASELINE.json configs[1], the configuration the metric is quoted on (default); synthetic: configs[4], "
-                         "one ~20k-residue multi-chain system on the cell-list path (pass --replicas 1 --md-steps 20)")
+    ap.add_argument("--workload", choices=list(WORKLOADS), default="1r69",
+                    help="1r69: BASELINE.json configs[1], the configuration the metric is quoted on (default); 1r69-fraglib / t0958: "
+                         "configs[2] (many-memory fragment library, all H-bond terms); 2xov / 2xov-remd: configs[3] (membrane protein; "
+                         "-remd adds a temperature replica exchange after every launch: all-gather of energies over RCCL, label swap, "
+                         "velocity rescale); synthetic: configs[4], one ~20k-residue multi-chain system on the cell-list path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--minimize", action="store_true", help="relax the start structure on the device first (awsem_minimize), as awsem_run does")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,20 +110,37 @@ def main():
 
     from openawsem_amd import _capi, workloads
     synthetic = args.workload == "synthetic"
-    if synthetic and args.replicas == 1024:
-        args.replicas, args.md_steps = 1, 20
-    oa = workloads.build_synthetic() if synthetic else workloads.build_1r69()
+    builder, kwargs, def_replicas, def_steps, description = WORKLOADS[args.workload]
+    if args.replicas is None:
+        args.replicas = def_replicas
+    if args.md_steps is None:
+        args.md_steps = def_steps
+    oa = getattr(workloads, builder)(**kwargs)
+    remd = None
+    if args.workload.endswith("-remd"):
+        from openawsem_amd import ensemble
+        n_total = args.replicas * world
+        remd = ensemble.ReplicaExchange(np.linspace(300.0, 600.0, n_total), rank=rank, world=world, seed=2026,
+                                        device=torch.device("cuda", local_rank))
     api = _capi.load_hip_library()
     R = args.replicas
     ctx = _capi.Context(api, oa.natoms, n_replicas=R, device=local_rank, precision=0 if args.precision == "fp32" else 1)
     oa.system.upload(ctx)
     ctx.set_positions(oa.pdb.positions, replica=-1)
+    if args.minimize and not synthetic:   # as scripts/mm_run.py:153 does before the annealing loop (untimed set-up)
+        ctx.minimize(10.0, 0)
     seed = 2026 + 7919 * rank     # independent streams per rank (replica ids repeat across ranks)
     Tstart, Tend, stages = 800.0, 200.0, 400
     ctx.set_velocities_to_temperature(np.full(R, Tstart), seed)
 
     def stage_T(i):
+        if remd is not None:
+            return remd.local_temperatures()
         return np.full(R, Tstart + (Tend - Tstart) / stages * (i % stages))
+
+    def after_launch():
+        if remd is not None:   # one exchange sweep: energies -> all-gather -> Metropolis on every rank -> labels, velocity rescale
+            ctx.scale_velocities(remd.exchange(ctx.energy()))
 
     def barrier():
         ctx.synchronize()
@@ -121,14 +151,16 @@ def main():
     it = 0
     for _ in range(args.warmup):
         ctx.step(args.md_steps, stage_T(it), 0.002, 1.0, seed)
+        after_launch()
         it += 1
     barrier()
     kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctx.step(args.md_steps, stage_T(it), 0.002, 1.0, seed)
-        it += 1
         kernel_ms.append(ctx.last_kernel_ms())     # HIP events on the engine's stream around the launch
+        after_launch()
+        it += 1
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -153,11 +185,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f64",
             "data": ("synthetic (122 rigidly rotated copies of the reference's 2lzm test structure on a jittered lattice, seed 2026)" if synthetic else
-                     "synthetic (1r69 extended chain from the reference's examples/1r69, Maxwell-Boltzmann velocities, Philox seed 2026)"),
-            "config": {"workload": ("synthetic multi-chain system (122 x 2lzm), con/chain/chi/excl/rama/contact+burial, cell-list path, "
-                                    "Langevin (dt 2 fs, friction 1/ps)") if synthetic else
-                                   "1r69 batched annealing ensemble, default forces_setup.py terms, 800->200 K Langevin "
-                                   "(dt 2 fs, friction 1/ps)", "replicas_per_gpu": R, "md_steps_per_launch": args.md_steps,
+                     f"synthetic ({args.workload.split('-')[0]} start structure from the reference's examples/, Maxwell-Boltzmann velocities, Philox seed 2026)"),
+            "config": {"workload": description, "replicas_per_gpu": R, "md_steps_per_launch": args.md_steps,
                        "residues": oa.nres, "atoms": oa.natoms, "parallelism": f"replica-sharded x{world}"},
             "force_eval_us_per_replica_step": k_ms * 1e3 / (R * args.md_steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -168,7 +197,9 @@ def main():
                                  ("state is LDS-resident across the launch, so the kernel is VALU/LDS-bound, not HBM-bound "
                                   "(see DESIGN.md); the HBM fraction is reported because the metric asks for it")},
         }
-        if not args.no_cpu_baseline and world == 1 and not synthetic:
+        if remd is not None:
+            out["config"]["remd_acceptance"] = [round(float(a), 3) for a in remd.acceptance()[:8]]
+        if not args.no_cpu_baseline and world == 1 and args.workload == "1r69":
             out["cpu_baseline"] = cpu_baseline(oa, args.md_steps)
         print(json.dumps(out), flush=True)
     if world > 1:

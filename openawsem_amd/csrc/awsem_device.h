@@ -78,6 +78,8 @@ template <class real> struct BetaD {
     const Int4* acc;                      // a1, a2, a3, residue
     const Int4* don;                      // d1, d2, d3, residue
     const real* lambda;                   // nres x nres, row = donor residue, pre-multiplied by -k
+    const unsigned* nzmask;               // bit (don_res * nres + acc_res) set where lambda != 0
+    int nz_lds;                           // the mask fits the list builder's LDS scratch next to the acceptor / donor words
     real r_ON, r_OH, inv_sNO2, inv_sHO2, cutoff2;   // inv_s*2 = 1/sigma^2
     real screen2, max_expo;               // fp32 pre-screen: r_ON^2 bound and largest Gaussian exponent evaluated
     int band_lo, band_hi;                 // lambda[q][p] == 0 whenever band_lo < q - p < band_hi (zero band around the diagonal)
@@ -89,6 +91,8 @@ template <class real> struct PapD {
     const Int4* acc;                      // a1, a2, residue, -
     const Int4* don;                      // d1, d2, residue, -
     const real* gamma;                    // nres x nres, row = donor residue, pre-multiplied by -k
+    const unsigned* nzmask;               // bit (don_res * nres + acc_res) set where gamma != 0
+    int nz_lds;
     real eta2, r0, d_i4, cutoff2;
     real min_arg;                         // fp32 pre-screen: switches with argument below this are treated as 0
     int band_lo, band_hi;                 // gamma[q][p] == 0 whenever band_lo < q - p < band_hi

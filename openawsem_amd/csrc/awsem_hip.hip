@@ -106,6 +106,7 @@ public:
                 long long tot = 0;
                 for (int k = 0; k < 10; k++) tot += p[k];
                 if (tot > 0) for (int k = 0; k < 10; k++) fprintf(stderr, "[awsem prof] %-24s %14lld cycles  %5.1f %%\n", names[k], p[k], 100.0 * p[k] / tot);
+                fprintf(stderr, "[awsem prof] list rebuilds: %lld (all replicas, all launches)\n", p[10]);
             }
         }
         for (auto& G : cell_graph_) if (G.exec) (void)hipGraphExecDestroy(G.exec);
@@ -361,6 +362,13 @@ static void zero_band(const std::vector<double>& t, int nres, int* lo, int* hi) 
     *lo = l; *hi = h;
 }
 
+// one bit per table entry: set where t[q][p] != 0 (the list builders test it instead of loading the table)
+static std::vector<unsigned> nonzero_mask(const std::vector<double>& t, int nres) {
+    std::vector<unsigned> m(((size_t)nres * nres + 31) / 32, 0u);
+    for (size_t i = 0; i < (size_t)nres * nres; i++) if (t[i] != 0.0) m[i >> 5] |= 1u << (i & 31);
+    return m;
+}
+
 template <class real> void Engine<real>::finalize(const HostSystem& H) {
     HIP_TRY(hipSetDevice(device_));
     host_ = &H;
@@ -572,6 +580,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             for (int i = 0; i < d.ndon; i++) don[i] = Int4{h.don_atoms[3 * i], h.don_atoms[3 * i + 1], h.don_atoms[3 * i + 2], h.don_res[i]};
             d.acc = upload(acc); d.don = upload(don);
             d.lambda = upload_real(h.lambda, -h.k);
+            d.nzmask = upload(nonzero_mask(h.lambda, h.nres));
+            d.nz_lds = ((size_t)d.nacc + d.ndon + ((size_t)h.nres * h.nres + 31) / 32) * 4 <= (size_t)natoms_ * (sizeof(real) == 4 ? 16 : 24);
             zero_band(h.lambda, h.nres, &d.band_lo, &d.band_hi);
             d.r_ON = (real)h.r_ON; d.r_OH = (real)h.r_OH; d.inv_sNO2 = (real)(1.0 / (h.s_NO * h.s_NO)); d.inv_sHO2 = (real)(1.0 / (h.s_HO * h.s_HO));
             d.cutoff2 = (real)(h.cutoff * h.cutoff);
@@ -599,6 +609,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
             for (int i = 0; i < d.ndon; i++) don[i] = Int4{h.don_atoms[2 * i], h.don_atoms[2 * i + 1], h.don_res[i], 0};
             d.acc = upload(acc); d.don = upload(don);
             d.gamma = upload_real(h.gamma, -h.k);
+            d.nzmask = upload(nonzero_mask(h.gamma, h.nres));
+            d.nz_lds = ((size_t)d.nacc + d.ndon + ((size_t)h.nres * h.nres + 31) / 32) * 4 <= (size_t)natoms_ * (sizeof(real) == 4 ? 16 : 24);
             zero_band(h.gamma, h.nres, &d.band_lo, &d.band_hi);
             d.eta2 = (real)(2 * h.eta); d.r0 = (real)h.r0; d.d_i4 = (real)h.d_i4; d.cutoff2 = (real)(h.cutoff * h.cutoff);
             d.min_arg = sizeof(real) == 4 ? (real)-30 : (real)-1e300;

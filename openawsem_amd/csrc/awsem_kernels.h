@@ -126,6 +126,8 @@ template <> struct Lds<float> : ViewCommon<float> {
     __device__ __forceinline__ R3<float> refpos(int a) const { const float4 q = ref[a]; return R3<float>{q.x, q.y, q.z}; }
     __device__ __forceinline__ void set_ref(int a, const R3<float>& r) const { ref[a] = make_float4(r.x, r.y, r.z, 0.0f); }
     __device__ __forceinline__ void zero_force(int a) const { *(int4*)&f[a] = make_int4(0, 0, 0, 0); }
+    // the accumulators are all zero while the pair lists are (re)built: 16 bytes per atom of scratch for the builders
+    __device__ __forceinline__ unsigned* scratch() const { return (unsigned*)f; }
     __device__ __forceinline__ R3<float> force(int a) const {
         const int4 q = *(const int4*)&f[a];   // {xy.lo, xy.hi, z, pad}
         const int y = q.x, x = q.y + (int)((unsigned)y >> 31);   // undo the borrow of a negative y
@@ -169,6 +171,7 @@ template <class real> struct SoaOps {
 };
 template <> struct Lds<double> : ViewCommon<double>, SoaOps<double> {
     typedef double real_t;
+    __device__ __forceinline__ unsigned* scratch() const { return (unsigned*)fx; }   // fx, fy, fz are contiguous: 24 bytes per atom
     double *vx, *vy, *vz, *rx, *ry, *rz;
     __device__ __forceinline__ R3<double> vel(int a) const { return R3<double>{vx[a], vy[a], vz[a]}; }
     __device__ __forceinline__ void set_vel(int a, const R3<double>& r) const { vx[a] = r.x; vy[a] = r.y; vz[a] = r.z; }
@@ -424,6 +427,7 @@ template <bool ENERGY, class V> __device__ void term_dh(const DhD<typename V::re
 // sides of the pair with fixed-point LDS atomics (conflict-light thanks to the diagonal order).  The evaluators
 // re-apply the exact cutoff of the reference, so the result does not depend on when a list was built.
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#define AWSEM_BUILD_UNROLL 1   // measured: 4 chunks in flight do not help (the builders are LDS-throughput bound) and cost small systems 10 %
 
 __device__ __forceinline__ void list_append(unsigned* __restrict__ e, unsigned* cnt, int cap, int* status, bool pass, unsigned entry) {
     const u64 m = __ballot(pass);
@@ -451,29 +455,48 @@ template <class V> __device__ __forceinline__ ListView list_view(const V& L, con
 }
 
 // ---- excluded volume: same-class site pairs that are not bonded partners
+// The builders' candidate loops read their per-site tables (site -> atom, site info, acceptor / donor words) from LDS:
+// a table is staged into the force accumulators' memory, which is all zero and unused while lists are built
+// (build_lists clears it again afterwards).  A global load per candidate would put ~1 us of latency into every
+// iteration of these loops.
 template <class V> __device__ void build_excl(const ExclD<typename V::real_t>& d, const V& L, int* status) {
     typedef typename V::real_t real;
     AWSEM_WAVE_VARS;
     unsigned* e = L.lists + d.ls.list_off;
     unsigned* cnt = &L.lcount[d.ls.list_id];
+    unsigned* tab = L.scratch();
+    for (int i = threadIdx.x; i < d.nsites; i += blockDim.x) tab[i] = (unsigned)d.atom[i];
+    __syncthreads();
+    constexpr int U = AWSEM_BUILD_UNROLL;   // candidate chunks in flight: the LDS round trips of one chunk hide behind the others
     for (int c = 0; c < d.nclass; c++) {
         const int base = d.class_start[c], n = d.class_start[c + 1] - base;
         for (int dd = 1 + wave; dd < n; dd += nw) {
-            for (int i0 = 0; i0 + dd < n; i0 += 64) {
-                const int i = i0 + lane, j = i + dd;
-                const bool v = j < n;
-                const int si = base + (v ? i : 0), sj = base + (v ? j : 0);
-                const int a = d.atom[si], b = d.atom[sj];
-                const real r2 = dist2(L.pos(a) - L.pos(b));
-                bool pass = v && r2 < d.list_rc2;
-                if (pass) {
-                    const Int4 p = d.partners[si];
-                    pass = p.x != b && p.y != b && p.z != b && p.w != b;
+            for (int i0 = 0; i0 + dd < n; i0 += 64 * U) {
+                int a[U], b[U], si[U];
+                bool pass[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int i = i0 + 64 * u + lane, j = i + dd;
+                    const bool v = j < n;
+                    si[u] = base + (v ? i : 0);
+                    a[u] = (int)tab[si[u]]; b[u] = (int)tab[base + (v ? j : 0)];
+                    pass[u] = v;
                 }
-                list_append(e, cnt, d.ls.list_cap, status, pass, ((unsigned)a << 16) | (unsigned)b);
+#pragma unroll
+                for (int u = 0; u < U; u++) pass[u] = pass[u] && dist2(L.pos(a[u]) - L.pos(b[u])) < d.list_rc2;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (__ballot(pass[u]) == 0) continue;
+                    if (pass[u]) {
+                        const Int4 p = d.partners[si[u]];
+                        pass[u] = p.x != b[u] && p.y != b[u] && p.z != b[u] && p.w != b[u];
+                    }
+                    list_append(e, cnt, d.ls.list_cap, status, pass[u], ((unsigned)a[u] << 16) | (unsigned)b[u]);
+                }
             }
         }
     }
+    __syncthreads();
 }
 // one candidate pair per lane (v = lane holds a pair); shared by the replica-resident and the cell-list path
 template <bool ENERGY, class V> __device__ __forceinline__ void excl_body(const ExclD<typename V::real_t>& d, const V& L, int a, int b, bool v, Energy& e) {
@@ -506,24 +529,39 @@ template <class V> __device__ void build_contact(const ContactD<typename V::real
     unsigned* e = L.lists + d.ls.list_off;
     unsigned* cnt = &L.lcount[d.ls.list_id];
     const int n = d.nsites;
+    unsigned* tab = L.scratch();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) tab[i] = (unsigned)d.info[i];
+    __syncthreads();
+    constexpr int U = AWSEM_BUILD_UNROLL;
     for (int dd = 1 + wave; dd < n; dd += nw) {
-        for (int i0 = 0; i0 + dd < n; i0 += 64) {
-            const int i = i0 + lane, j = i + dd;
-            const bool v = j < n;
-            const int si = v ? i : 0, sj = v ? j : 0;
-            const int info_i = d.info[si], info_j = d.info[sj], a = satom[si], b = satom[sj];
-            const int dres = (info_j & 0xffff) - (info_i & 0xffff);
-            const real r2 = dist2(L.pos(a) - L.pos(b));
-            // the density counts |resid_i - resid_j| >= 2 whatever the chains (contactTerms.py:255); the pair energy
-            // counts different chains or |resid_i - resid_j| >= min_seq_sep (res_table, contactTerms.py:200-210)
-            const bool in_rho = dres >= 2 || dres <= -2;
-            const bool pair_e = !(d.flags & 2) && ((((info_i ^ info_j) >> 16) & 0x7ff) != 0 || dres >= d.min_seq_sep || -dres >= d.min_seq_sep);
-            const bool pass = v && (in_rho || pair_e) && r2 < d.list_rc2;
-            const unsigned ty = (unsigned)(((info_i >> 27) & 31) * 20 + ((info_j >> 27) & 31));
-            list_append(e, cnt, d.ls.list_cap, status, pass,
-                        (unsigned)si | ((unsigned)sj << 10) | (ty << 20) | (in_rho ? 0x40000000u : 0u) | (pair_e ? 0x80000000u : 0u));
+        for (int i0 = 0; i0 + dd < n; i0 += 64 * U) {
+            int si[U], sj[U], info_i[U], info_j[U], a[U], b[U];
+            bool v[U];
+            real r2[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + 64 * u + lane, j = i + dd;
+                v[u] = j < n;
+                si[u] = v[u] ? i : 0; sj[u] = v[u] ? j : 0;
+                info_i[u] = (int)tab[si[u]]; info_j[u] = (int)tab[sj[u]]; a[u] = satom[si[u]]; b[u] = satom[sj[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) r2[u] = dist2(L.pos(a[u]) - L.pos(b[u]));
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int dres = (info_j[u] & 0xffff) - (info_i[u] & 0xffff);
+                // the density counts |resid_i - resid_j| >= 2 whatever the chains (contactTerms.py:255); the pair energy
+                // counts different chains or |resid_i - resid_j| >= min_seq_sep (res_table, contactTerms.py:200-210)
+                const bool in_rho = dres >= 2 || dres <= -2;
+                const bool pair_e = !(d.flags & 2) && ((((info_i[u] ^ info_j[u]) >> 16) & 0x7ff) != 0 || dres >= d.min_seq_sep || -dres >= d.min_seq_sep);
+                const bool pass = v[u] && (in_rho || pair_e) && r2[u] < d.list_rc2;
+                const unsigned ty = (unsigned)(((info_i[u] >> 27) & 31) * 20 + ((info_j[u] >> 27) & 31));
+                list_append(e, cnt, d.ls.list_cap, status, pass,
+                            (unsigned)si[u] | ((unsigned)sj[u] << 10) | (ty << 20) | (in_rho ? 0x40000000u : 0u) | (pair_e ? 0x80000000u : 0u));
+            }
         }
     }
+    __syncthreads();
 }
 // pass 1: density rho_i = sum_j theta_I(r_ij) inside the cutoff
 template <class V> __device__ __forceinline__ void density_body(const ContactD<typename V::real_t>& d, const V& L, int i, int j, int a, int b, bool v) {
@@ -676,30 +714,58 @@ template <class V> __device__ void contact_chain_rule(const ContactD<typename V:
 // ---- acceptor x donor terms (CustomHbondForce shape)
 // In fp32 the lists use a conservative pre-screen (Gaussian factors below e^-30 of their maximum are skipped, far
 // under fp32 resolution); the fp64 check mode applies only the reference's cutoff.
-template <class V, class Desc> __device__ void build_hbond(const Desc& d, const typename V::real_t* __restrict__ table, const V& L, int* status) {
+template <class V, class Desc> __device__ void build_hbond(const Desc& d, const V& L, int* status) {
     typedef typename V::real_t real;
     AWSEM_WAVE_VARS;
     unsigned* e = L.lists + d.ls.list_off;
     unsigned* cnt = &L.lcount[d.ls.list_id];
     const int resw = Desc::res_slot;   // which Int4 component carries the residue index
+    // staged words: screening atom (a1 / d1) | residue << 16
+    unsigned* sa = L.scratch();
+    unsigned* sd = sa + d.nacc;
+    for (int i = threadIdx.x; i < d.nacc; i += blockDim.x) { const Int4 A = d.acc[i]; sa[i] = (unsigned)A.x | ((unsigned)(resw == 3 ? A.w : A.z) << 16); }
+    for (int i = threadIdx.x; i < d.ndon; i += blockDim.x) { const Int4 D = d.don[i]; sd[i] = (unsigned)D.x | ((unsigned)(resw == 3 ? D.w : D.z) << 16); }
+    // which (donor residue, acceptor residue) pairs have a non-zero table entry: one bit each, staged as well when it fits
+    const unsigned* nz = d.nzmask;
+    if (d.nz_lds) {
+        unsigned* sm = sd + d.ndon;
+        const int words = (d.nres * d.nres + 31) >> 5;
+        for (int i = threadIdx.x; i < words; i += blockDim.x) sm[i] = d.nzmask[i];
+        nz = sm;
+    }
+    __syncthreads();
     for (int a0 = 0; a0 < d.nacc; a0 += 64) {
         const int ia = a0 + lane;
         const bool va = ia < d.nacc;
-        const Int4 A = d.acc[va ? ia : 0];
-        const R3<real> pa = L.pos(A.x);
-        const int ares = resw == 3 ? A.w : A.z;
+        const unsigned A = sa[va ? ia : 0];
+        const R3<real> pa = L.pos((int)(A & 0xffffu));
+        const int ares = (int)(A >> 16);
         const int q0 = (va ? ia : 0) % d.ndon;
-        for (int dd = wave; dd < d.ndon; dd += nw) {
-            int q = q0 + dd;
-            q = q >= d.ndon ? q - d.ndon : q;
-            const Int4 D = d.don[q];
-            const int dres = resw == 3 ? D.w : D.z, dq = dres - ares;
-            const real r2 = dist2(pa - L.pos(D.x));
-            bool pass = va && r2 < d.list_rc2 && (dq <= d.band_lo || dq >= d.band_hi);
-            if (pass) pass = table[(size_t)dres * d.nres + ares] != (real)0;
-            list_append(e, cnt, d.ls.list_cap, status, pass, ((unsigned)ia << 16) | (unsigned)q);
+        constexpr int U = AWSEM_BUILD_UNROLL;
+        for (int dd0 = wave; dd0 < d.ndon; dd0 += nw * U) {
+            int q[U];
+            unsigned D[U];
+            bool pass[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int dd = dd0 + u * nw;
+                pass[u] = va && dd < d.ndon;
+                int t = q0 + (dd < d.ndon ? dd : 0);
+                q[u] = t >= d.ndon ? t - d.ndon : t;
+                D[u] = sd[q[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int dres = (int)(D[u] >> 16), dq = dres - ares;
+                const real r2 = dist2(pa - L.pos((int)(D[u] & 0xffffu)));
+                pass[u] = pass[u] && r2 < d.list_rc2 && (dq <= d.band_lo || dq >= d.band_hi);
+                if (pass[u]) { const unsigned bit = (unsigned)(dres * d.nres + ares); pass[u] = (nz[bit >> 5] >> (bit & 31)) & 1u; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) list_append(e, cnt, d.ls.list_cap, status, pass[u], ((unsigned)ia << 16) | (unsigned)q[u]);
         }
     }
+    __syncthreads();
 }
 
 template <bool ENERGY, class V> __device__ void eval_beta(const BetaD<typename V::real_t>& d, const V& L) {
@@ -821,8 +887,9 @@ template <class V> __device__ void stage_tables(const DevSys<typename V::real_t>
 template <class V> __device__ void build_lists(const DevSys<typename V::real_t>& S, const V& L, unsigned mask) {
     for (int t = 0; t < S.n_contact; t++) if (AWSEM_ON(S.contact[t])) build_contact(S.contact[t], L, L.satom + t * S.max_contact_sites, S.status);
     for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) build_excl(S.excl[t], L, S.status);
-    for (int t = 0; t < S.n_beta; t++) if (AWSEM_ON(S.beta[t])) build_hbond(S.beta[t], S.beta[t].lambda, L, S.status);
-    for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) build_hbond(S.pap[t], S.pap[t].gamma, L, S.status);
+    for (int t = 0; t < S.n_beta; t++) if (AWSEM_ON(S.beta[t])) build_hbond(S.beta[t], L, S.status);
+    for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) build_hbond(S.pap[t], L, S.status);
+    for (int i = threadIdx.x; i < S.natoms; i += blockDim.x) L.zero_force(i);   // the builders staged their tables in the accumulators
 }
 
 // Evaluate every term whose group is in `mask` from the current pair lists.  Forces accumulate into the view and the
@@ -1096,6 +1163,9 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
             build_lists(S, L, 0xffffffffu);
             __syncthreads();
             AWSEM_STAMP(S, 2);
+#ifdef AWSEM_PROF
+            if (threadIdx.x == 0) atomicAdd((unsigned long long*)&S.prof[10], 1ull);   // number of list rebuilds
+#endif
         }
         evaluate_terms<false>(S, L, 0xffffffffu AWSEM_STAMP_PASS);
         if (threadIdx.x == 0) L.flag[cur] = 0;   // read by everyone before the barriers of the evaluation; written again next step

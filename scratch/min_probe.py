@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openawsem_amd import _capi, workloads
 oa = workloads.build_1r69()
 ctx = _capi.Context(_capi.load_hip_library(), oa.natoms, 1024)
