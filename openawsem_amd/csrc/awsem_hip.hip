@@ -281,7 +281,7 @@ private:
     int* dmin_it_ = nullptr;
     double* dmin_rms_ = nullptr;
     unsigned* dcounts_ = nullptr;
-    double skin_ = 0.15;
+    double skin_ = 0.2;    // nm; AWSEM_SKIN overrides (0.15-0.3 measured: 0.2 and above rebuild rarely enough on the hot, extended stage of an annealing run)
     size_t lds_list_ = 0, lds_max_ = 0;
     bool step_ok_ = false;
 
