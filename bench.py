@@ -157,12 +157,15 @@ def main():
     kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.step(args.md_steps, stage_T(it), 0.002, 1.0, seed)
-        kernel_ms.append(ctx.last_kernel_ms())     # HIP events on the engine's stream around the launch
+        ctx.step(args.md_steps, stage_T(it), 0.002, 1.0, seed)   # asynchronous: the launches queue up back to back
+        if remd is not None:
+            kernel_ms.append(ctx.last_kernel_ms())
         after_launch()
         it += 1
     barrier()
     elapsed = time.perf_counter() - t0
+    if remd is None:
+        kernel_ms.append(ctx.last_kernel_ms())     # mean over the timed launches: HIP events on the engine's stream around each
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

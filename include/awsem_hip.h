@@ -201,8 +201,11 @@ int awsem_set_step_count(awsem_handle h, int64_t step);
 int awsem_minimize(awsem_handle h, double tolerance_kj_mol_nm, int max_iterations, int32_t* iterations,
                    double* rms_force);
 
-/* Wall time of the last awsem_step / awsem_energy* / awsem_forces kernel launch measured with HIP events on
- * the handle's stream (ms); used by bench.py for the roofline line. */
+/* awsem_step returns as soon as the launch is enqueued (up to 32 launches may be in flight; the temperatures are
+ * copied before it returns).  awsem_synchronize waits for them; every other call on the handle synchronises first.
+ * awsem_last_kernel_ms: duration of the last awsem_energy* / awsem_forces / awsem_minimize operation, or the MEAN
+ * duration of the awsem_step launches since the previous synchronisation, measured with HIP events on the handle's
+ * stream (ms); used by bench.py for the roofline line. */
 int awsem_last_kernel_ms(awsem_handle h, double* ms);
 int awsem_synchronize(awsem_handle h);
 

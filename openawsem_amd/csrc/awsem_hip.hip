@@ -111,6 +111,7 @@ public:
         }
         for (auto& G : cell_graph_) if (G.exec) (void)hipGraphExecDestroy(G.exec);
         for (void* p : allocs_) (void)hipFree(p);
+        for (int k = 0; k < NRING; k++) { if (ring0_[k]) (void)hipEventDestroy(ring0_[k]); if (ring1_[k]) (void)hipEventDestroy(ring1_[k]); if (ringT_[k]) (void)hipHostFree(ringT_[k]); }
         if (ev0_) (void)hipEventDestroy(ev0_);
         if (ev1_) (void)hipEventDestroy(ev1_);
         if (stream_) (void)hipStreamDestroy(stream_);
@@ -178,13 +179,11 @@ public:
             throw std::string(msg);
         }
         HIP_TRY(hipSetDevice(device_));
-        upload_T(T);
-        HIP_TRY(hipEventRecord(ev0_, stream_));
+        begin_async(T);
         hipLaunchKernelGGL(awsem_step_kernel<real>, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, dT_, nsteps, dt, friction,
                            (unsigned long long)seed, (long long)step0);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(ev1_, stream_));
-        timing_pending_ = true;   // asynchronous: resolved by synchronize()/last_kernel_ms
+        end_async();   // asynchronous: resolved by synchronize() / last_kernel_ms
     }
     void minimize(double tolerance, int max_iterations, int32_t* iterations, double* rms) override {
         if (cell_mode_) throw std::string("minimize: the device minimiser runs on the replica-resident path only (this system takes the cell-list path)");
@@ -205,7 +204,7 @@ public:
     void synchronize() override {
         HIP_TRY(hipSetDevice(device_));
         HIP_TRY(hipStreamSynchronize(stream_));
-        if (timing_pending_) { record_ms(); check_status(); }
+        if (timing_pending_) { record_ring_ms(); check_status(); }
     }
     int neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) override;
 
@@ -226,6 +225,20 @@ private:
         for (size_t i = 0; i < v.size(); i++) t[i] = (real)(v[i] * scale);
         return upload(t);
     }
+    // start / end of an asynchronous launch: temperatures through a pinned ring buffer, events from the ring
+    void begin_async(const double* T) {
+        if (npend_ == NRING) synchronize();
+        const int k = npend_;
+        if (!ring0_[k]) { HIP_TRY(hipEventCreate(&ring0_[k])); HIP_TRY(hipEventCreate(&ring1_[k])); HIP_TRY(hipHostMalloc((void**)&ringT_[k], sizeof(double) * nrep_, hipHostMallocDefault)); }
+        memcpy(ringT_[k], T, sizeof(double) * nrep_);
+        HIP_TRY(hipMemcpyAsync(dT_, ringT_[k], sizeof(double) * nrep_, hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipEventRecord(ring0_[k], stream_));
+    }
+    void end_async() {
+        HIP_TRY(hipEventRecord(ring1_[npend_], stream_));
+        npend_++;
+        timing_pending_ = true;
+    }
     void upload_T(const double* T) {
         HIP_TRY(hipMemcpyAsync(dT_, T, sizeof(double) * nrep_, hipMemcpyHostToDevice, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));   // T is a caller-owned pageable buffer
@@ -242,8 +255,17 @@ private:
             throw std::string("pair list overflow on the device (internal error: list capacity below the candidate pair count)");
         }
     }
-    void record_ms() {
+    void record_ring_ms() {   // mean over the asynchronous launches since the last synchronisation (the stream is idle)
         float ms = 0;
+        double sum = 0;
+        for (int k = 0; k < npend_; k++) { HIP_TRY(hipEventElapsedTime(&ms, ring0_[k], ring1_[k])); sum += ms; }
+        if (npend_ > 0) last_ms = sum / npend_;
+        npend_ = 0;
+        timing_pending_ = false;
+    }
+    void record_ms() {        // synchronous operations: ev0_ / ev1_ bracket the operation that just completed
+        float ms = 0;
+        npend_ = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev0_, ev1_));
         last_ms = ms;
         timing_pending_ = false;
@@ -272,6 +294,12 @@ private:
     hipStream_t stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     bool timing_pending_ = false;
+    // asynchronous launches (awsem_step): a ring of event pairs and pinned temperature buffers, so that the host can
+    // enqueue launch after launch without waiting; drained by synchronize()
+    static constexpr int NRING = 32;
+    hipEvent_t ring0_[NRING] = {}, ring1_[NRING] = {};
+    double* ringT_[NRING] = {};
+    int npend_ = 0;
     std::vector<void*> allocs_;
     DevSys<real> dsys_;
     real *pos_ = nullptr, *vel_ = nullptr;
@@ -983,10 +1011,9 @@ template <class real> void Engine<real>::cell_one_step(double dt, double frictio
 #define AWSEM_CELL_CHUNK 10
 template <class real> void Engine<real>::cell_step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) {
     HIP_TRY(hipSetDevice(device_));
-    upload_T(T);
     if (!cell_step_base_) cell_step_base_ = dalloc<long long>(1);
+    begin_async(T);
     static const bool use_graph = !(getenv("AWSEM_CELL_GRAPH") && atoi(getenv("AWSEM_CELL_GRAPH")) == 0);
-    HIP_TRY(hipEventRecord(ev0_, stream_));
     HIP_TRY(hipMemsetAsync(cell_.f, 0, (size_t)nrep_ * 3 * natoms_ * sizeof(u64), stream_));
     int s = 0;
     auto set_base = [&](long long v) { hipLaunchKernelGGL(cell_set_word_kernel<long long>, dim3(1), dim3(1), 0, stream_, cell_step_base_, v); };
@@ -1017,8 +1044,7 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
     }
     hipLaunchKernelGGL(cell_vsite_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, pos_);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev1_, stream_));
-    timing_pending_ = true;
+    end_async();
 }
 template <class real> int Engine<real>::cell_neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) {
     if (index != 0 || (kind != AWSEM_LIST_EXCL && kind != AWSEM_LIST_CONTACT)) throw std::string("neighbors (cell-list path): kind must be AWSEM_LIST_EXCL or AWSEM_LIST_CONTACT, index 0");
