@@ -250,7 +250,7 @@ private:
             HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
             if (st & 2) {
                 cell_stale_ = true;
-                throw std::string("neighbour list overflow on the cell-list path during dynamics: raise AWSEM_CELL_NEIGHBORS (partners reserved per contact site, default 64)");
+                throw std::string("neighbour list overflow on the cell-list path during dynamics: raise AWSEM_CELL_NEIGHBORS (partners reserved per contact site, default 96, grown to twice the fullest row when dynamics start)");
             }
             throw std::string("pair list overflow on the device (internal error: list capacity below the candidate pair count)");
         }
@@ -330,7 +330,7 @@ private:
     bool cell_mode_ = false, cell_stale_ = true;
     CellSys<real> cell_;
     const CellJob* cell_jobs_ = nullptr;
-    int cell_njobs_ = 0, cell_per_site_ = 64, cell_cur_ = 0;
+    int cell_njobs_ = 0, cell_per_site_ = 96, cell_cur_ = 0;
     double cell_rc_contact_ = 0, cell_rc_excl_ = 0;
     std::vector<int> excl_sorted_atom_, excl_sorted_cls_;   // class-sorted site table of excl term 0
     std::vector<int> cell_wstart_, cell_nlocal_;            // per local bonded term (harm, chi, rama, helical, fm, memb order): window starts, local item count
@@ -1012,6 +1012,31 @@ template <class real> void Engine<real>::cell_one_step(double dt, double frictio
 template <class real> void Engine<real>::cell_step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) {
     HIP_TRY(hipSetDevice(device_));
     if (!cell_step_base_) cell_step_base_ = dalloc<long long>(1);
+    if (cell_stale_) {
+        // first launch after the coordinates were set: build the rows now and leave head room, because a row that
+        // overflows in the middle of a trajectory cannot be repaired (the rows are sized to twice the fullest one)
+        synchronize();
+        for (int attempt = 0;; attempt++) {
+            cell_pre(false);
+            cell_stale_ = true;
+            cell_refresh(cell_);
+            HIP_TRY(hipStreamSynchronize(stream_));
+            int st = 0;
+            HIP_TRY(hipMemcpy(&st, dstatus_, sizeof st, hipMemcpyDeviceToHost));
+            int fullest = 0;
+            if (!(st & 2) && cell_.bin[0].n) {
+                std::vector<int> cnt((size_t)cell_.bin[0].n * nrep_);
+                HIP_TRY(hipMemcpy(cnt.data(), cell_.bin[0].row_count, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+                for (int c : cnt) fullest = std::max(fullest, c);
+            }
+            if (!(st & 2) && 2 * fullest <= cell_.bin[0].stride) break;
+            HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
+            if (attempt >= 6) throw std::string("cell-list path: neighbour rows keep overflowing");
+            cell_per_site_ = std::max(2 * cell_per_site_ * ((st & 2) ? 1 : 0), 2 * fullest);
+            cell_alloc_lists();
+        }
+        cell_stale_ = true;   // the step sequence below rebuilds once more through the ordinary path (virtual sites placed first)
+    }
     begin_async(T);
     static const bool use_graph = !(getenv("AWSEM_CELL_GRAPH") && atoi(getenv("AWSEM_CELL_GRAPH")) == 0);
     HIP_TRY(hipMemsetAsync(cell_.f, 0, (size_t)nrep_ * 3 * natoms_ * sizeof(u64), stream_));
