@@ -1,0 +1,102 @@
+"""Size-independent properties of the HIP path (no oracle needed) and edge cases of the C ABI:
+exact momentum balance of the fixed-point pair forces, asynchronous launches, empty / tiny systems, bench-size ensembles."""
+import numpy as np
+import pytest
+
+from openawsem_amd import _capi, workloads
+from openawsem_amd.forces import HarmonicBondForce, System
+from tests.common import golden_system
+
+pytestmark = pytest.mark.gpu
+FP32, FP64 = 0, 1
+
+
+def _ctx(system, natoms, R=1, precision=FP32):
+    ctx = _capi.Context(_capi.load_hip_library(), natoms, n_replicas=R, precision=precision)
+    system.upload(ctx)
+    return ctx
+
+
+@pytest.mark.parametrize("precision", [FP32, FP64])
+def test_pair_terms_obey_newtons_third_law_exactly(precision):
+    """A pair term books +F on one atom and the bit-identical -F on the other in fixed point, so the raw (not
+    redistributed) forces of the pair-only groups sum to exactly zero, component by component, whatever the order the
+    lists were walked in: fragment memory (23), beta (27), P-AP (28), helical (29), Debye-Hueckel (30)."""
+    oa, traj, _ = golden_system("1brs")
+    gpu = _ctx(oa.system, oa.natoms, R=3, precision=precision)
+    for r, f in enumerate((0, 5, 11)):
+        gpu.set_positions(traj[f], replica=r)
+    for group in (23, 27, 28, 29, 30):
+        f = gpu.forces(1 << group, redistribute=False)
+        assert np.abs(f).max() > 0, group
+        # the sums are exact in fixed point; in double the 1e3 terms of up to 1e3 kJ/mol/nm leave at most rounding of the readout
+        assert np.all(f.sum(axis=1) == 0.0), (group, f.sum(axis=1))
+
+
+def test_asynchronous_launches_equal_synchronised_ones():
+    """awsem_step returns before the kernel has run; 40 launches in a row (more than the 32-deep ring) with changing
+    temperatures give the same trajectory as launches that are synchronised one by one."""
+    oa, traj, _ = golden_system("1ubq")
+    out = []
+    for sync in (False, True):
+        gpu = _ctx(oa.system, oa.natoms, R=2)
+        gpu.set_positions(traj[0])
+        gpu.compute_virtual_sites()
+        gpu.set_velocities_to_temperature([300.0, 300.0], 5)
+        for k in range(40):
+            T = np.array([300.0 + k, 350.0 - k])
+            gpu.step(3, T, 0.002, 1.0, 5)
+            T[:] = -1.0            # the library has copied the temperatures: the caller may reuse its buffer at once
+            if sync:
+                gpu.synchronize()
+        out.append((gpu.get_positions(0), gpu.get_positions(1), gpu.get_velocities(1)))
+        assert gpu.step_count == 120
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+
+
+def test_empty_and_tiny_systems():
+    """Two bonded particles and a spectator, an empty bond list next to it: energies, forces and dynamics behave."""
+    system = System(np.array([12.0, 12.0, 12.0]))
+    bond = HarmonicBondForce()
+    bond.addBond(0, 1, 0.38, 1000.0)
+    bond.setForceGroup(20)
+    empty = HarmonicBondForce()
+    empty.setForceGroup(21)
+    system.addForce(bond)
+    system.addForce(empty)
+    for precision in (FP32, FP64):
+        gpu = _ctx(system, 3, R=2, precision=precision)
+        x = np.array([[0.0, 0.0, 0.0], [0.5, 0.0, 0.0], [3.0, 3.0, 3.0]])
+        gpu.set_positions(x)
+        e = gpu.energy_by_group()
+        assert np.allclose(e[:, 20], 0.5 * 1000.0 * 0.12 ** 2, rtol=1e-6) and np.all(e[:, 21] == 0)
+        f = gpu.forces()
+        assert np.allclose(f[0, 0], [120.0, 0, 0], atol=1e-3) and np.allclose(f[0, 1], [-120.0, 0, 0], atol=1e-3) and np.all(f[0, 2] == 0)
+        gpu.set_velocities(np.zeros((3, 3)))
+        gpu.step(200, [0.0, 0.0], 0.002, 5.0, 1)      # T = 0: pure damped relaxation towards r0
+        y = gpu.get_positions(1)
+        assert abs(np.linalg.norm(y[1] - y[0]) - 0.38) < 0.02 and np.allclose(y[2], x[2])
+        it, rms = gpu.minimize(1e-3, 5000)
+        z = gpu.get_positions(0)
+        assert np.all(rms <= 1e-3) and abs(np.linalg.norm(z[1] - z[0]) - 0.38) < 1e-4
+
+
+def test_bench_size_ensemble_stays_finite_and_reproducible():
+    """BASELINE.json's full size (1024 replicas of 1r69): two identical runs agree bit for bit, replicas with different
+    random streams differ, all energies stay finite."""
+    oa = workloads.build_1r69()
+    R = 1024
+    runs = []
+    for _ in range(2):
+        gpu = _ctx(oa.system, oa.natoms, R=R)
+        gpu.set_positions(oa.pdb.positions)
+        gpu.set_velocities_to_temperature(np.full(R, 800.0), 2026)
+        for stage in range(3):
+            gpu.step(50, np.full(R, 800.0 - 1.5 * stage), 0.002, 1.0, 2026)
+        e = gpu.energy()
+        assert np.isfinite(e).all()
+        runs.append((e, gpu.get_positions(0), gpu.get_positions(R - 1)))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    assert np.abs(runs[0][1] - runs[0][2]).max() > 1e-3
+    assert len(np.unique(runs[0][0])) > R // 2
