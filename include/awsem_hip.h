@@ -137,6 +137,11 @@ int awsem_add_membrane(awsem_handle h, int group, int n, const int32_t* atoms, c
 int awsem_add_debye_huckel(awsem_handle h, int group, int n, const int32_t* pairs, const double* qq,
                            double k_dh, double screening_length);
 
+/* er_term templateTerms.py:643-693 and additive_amhgo_term templateTerms.py:600-640 (CustomBondForce with per-bond
+ * parameters): E = -kgamma exp(-(r - r0)^2 / (2 sigma^2)), kgamma = k_er gamma_ij (resp. k_amhgo gamma_ij). */
+int awsem_add_gaussian_bonds(awsem_handle h, int group, int n, const int32_t* pairs, const double* r0,
+                             const double* sigma, const double* kgamma);
+
 /* Uploads tables and index arrays to the device; no add_* / set_masses / set_virtual_sites afterwards.
  * Replaces Simulation(topology, system, integrator, platform) -> Context creation (scripts/mm_run.py:148). */
 int awsem_finalize(awsem_handle h);

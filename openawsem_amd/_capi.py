@@ -38,6 +38,7 @@ _SIGNATURES = {
     "add_fragment_memory": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, C.c_int, c_dbl_p, C.c_double, C.c_double]),
     "add_membrane": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double, C.c_double, C.c_double]),
     "add_debye_huckel": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double]),
+    "add_gaussian_bonds": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p]),
     "finalize": (C.c_int, ["H"]),
     "set_positions": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_int]),
     "get_positions": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_int]),
@@ -211,6 +212,10 @@ class Context:
     def add_debye_huckel(self, group, pairs, qq, k_dh, screening_length):
         p, q = _i32(pairs).reshape(-1), _f64(qq)
         self._call("add_debye_huckel", group, len(q), _ip(p), _dp(q), float(k_dh), float(screening_length))
+
+    def add_gaussian_bonds(self, group, pairs, r0, sigma, kgamma):
+        p, a, b, c = _i32(pairs).reshape(-1), _f64(r0), _f64(sigma), _f64(kgamma)
+        self._call("add_gaussian_bonds", group, len(a), _ip(p), _dp(a), _dp(b), _dp(c))
 
     def finalize(self):
         self._call("finalize")

@@ -502,7 +502,7 @@ template <class real> __global__ void cell_chain_kernel(DevSys<real> S, CellSys<
 
 // Bonded terms: one workgroup per 256 items of one term (job table built at finalize).
 struct CellJob { int kind, term, first; };
-enum { CJ_HARM, CJ_CHI, CJ_RAMA, CJ_HELICAL, CJ_FM, CJ_MEMB, CJ_DH };
+enum { CJ_HARM, CJ_CHI, CJ_RAMA, CJ_HELICAL, CJ_FM, CJ_MEMB, CJ_DH, CJ_GAUSS };
 template <bool ENERGY, class real> __global__ void cell_bonded_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos, const CellJob* __restrict__ jobs, unsigned mask) {
     const int rep = blockIdx.y;
     const CellView<real> L = cell_view(S, C, pos, rep);
@@ -516,6 +516,7 @@ template <bool ENERGY, class real> __global__ void cell_bonded_kernel(DevSys<rea
     case CJ_FM: { FmD<real> d = S.fm[job.term]; if (!AWSEM_ON(d)) return; d.pairs2 += 2 * (size_t)f; d.table2 += (size_t)f * (d.ntab - 1); d.n = min(256, d.n - f); term_fm<ENERGY, false>(d, L); } break;
     case CJ_MEMB: { MembD<real> d = S.memb[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f); term_memb<ENERGY>(d, L); } break;
     case CJ_DH: { DhD<real> d = S.dh[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f); term_dh<ENERGY>(d, L); } break;
+    case CJ_GAUSS: { GaussD<real> d = S.gauss[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f); term_gauss<ENERGY>(d, L); } break;
     }
 }
 

@@ -23,6 +23,7 @@
 #define AWSEM_MAX_FM 2
 #define AWSEM_MAX_MEMB 2
 #define AWSEM_MAX_DH 2
+#define AWSEM_MAX_GAUSS 2
 #define AWSEM_FIXED_SCALE 4294967296.0   // 2^32: forces, energies and densities are accumulated as int64 fixed point
 #define AWSEM_MAX_LISTS (AWSEM_MAX_EXCL + AWSEM_MAX_CONTACT + AWSEM_MAX_BETA + AWSEM_MAX_PAP)
 
@@ -35,6 +36,7 @@ struct ListSlot { int list_off, list_cap, list_id; };
 template <class real> struct HarmItem { int i, j; real r0, k; };
 template <class real> struct HelicalItem { int o, n, h; real coef; };
 template <class real> struct DhItem { int i, j; real qq, pad; };
+template <class real> struct GaussItem { int i, j; real r0, a, c; };   // a = 1/(2 sigma^2), c = k gamma
 template <class real> struct MembItem { int atom; real scale; };
 template <class real> struct alignas(16) MassiveItem { int atom; real inv_mass, sqrt_inv_mass, pad; };
 // the virtual sites a massive particle parents (-1 padded) and its weight in each: the step kernel gathers their forces
@@ -104,6 +106,7 @@ template <class real> struct HelicalD { int group, n; const HelicalItem<real>* i
 template <class real> struct FmD { int group, n, ntab; const unsigned* pairs; const int* pairs2; const real2_t<real>* table2; real k, dr, inv_dr; };
 template <class real> struct MembD { int group, n; const MembItem<real>* items; real k, k_m2, z_m, center; };
 template <class real> struct DhD { int group, n; const DhItem<real>* items; real k, inv_lam; };
+template <class real> struct GaussD { int group, n; const GaussItem<real>* items; };
 
 template <class real> struct DevSys {
     int natoms;
@@ -117,11 +120,11 @@ template <class real> struct DevSys {
     int nmassive;
     int nfixed;                           // massless particles that are not virtual sites (they never move)
     const int* fixed;
-    int n_harm, n_chi, n_rama, n_excl, n_contact, n_beta, n_pap, n_helical, n_fm, n_memb, n_dh;
+    int n_harm, n_chi, n_rama, n_excl, n_contact, n_beta, n_pap, n_helical, n_fm, n_memb, n_dh, n_gauss;
     HarmD<real> harm[AWSEM_MAX_HARM]; ChiD<real> chi[AWSEM_MAX_CHI]; RamaD<real> rama[AWSEM_MAX_RAMA];
     ExclD<real> excl[AWSEM_MAX_EXCL]; ContactD<real> contact[AWSEM_MAX_CONTACT]; BetaD<real> beta[AWSEM_MAX_BETA];
     PapD<real> pap[AWSEM_MAX_PAP]; HelicalD<real> helical[AWSEM_MAX_HELICAL]; FmD<real> fm[AWSEM_MAX_FM];
-    MembD<real> memb[AWSEM_MAX_MEMB]; DhD<real> dh[AWSEM_MAX_DH];
+    MembD<real> memb[AWSEM_MAX_MEMB]; DhD<real> dh[AWSEM_MAX_DH]; GaussD<real> gauss[AWSEM_MAX_GAUSS];
     int max_contact_sites;                // LDS scratch sizing
     int any_zdep;
     unsigned* lists;                      // [n_replicas][list_stride] pair-list entries

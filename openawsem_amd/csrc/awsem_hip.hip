@@ -56,6 +56,7 @@ struct HHelical { int group; std::vector<int> atoms; std::vector<double> coef; d
 struct HFm { int group, ntab; std::vector<int> pairs; std::vector<double> table; double k, dr; };
 struct HMemb { int group; std::vector<int> atoms; std::vector<double> scale; double k, k_m, z_m, center; };
 struct HDh { int group; std::vector<int> pairs; std::vector<double> qq; double k, lam; };
+struct HGauss { int group; std::vector<int> pairs; std::vector<double> r0, sigma, kg; };
 
 struct HostSystem {
     int natoms = 0;
@@ -64,7 +65,7 @@ struct HostSystem {
     std::vector<double> vs_w;
     std::vector<HHarm> harm; std::vector<HChi> chi; std::vector<HRama> rama; std::vector<HExcl> excl;
     std::vector<HContact> contact; std::vector<HBeta> beta; std::vector<HPap> pap; std::vector<HHelical> helical;
-    std::vector<HFm> fm; std::vector<HMemb> memb; std::vector<HDh> dh;
+    std::vector<HFm> fm; std::vector<HMemb> memb; std::vector<HDh> dh; std::vector<HGauss> gauss;
 };
 
 // ---- precision-specific engine ---------------------------------------------------------------------------
@@ -699,6 +700,20 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         if (D.size() > AWSEM_MAX_DH) throw std::string("too many dh terms: at most " + std::to_string(AWSEM_MAX_DH) + " per system");
         S.n_dh = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.dh[t] = D[t];
     }
+    {   // Gaussian-well bonds (pairs anywhere in the system, like Debye-Hueckel: never window-local on the cell-list path)
+        std::vector<GaussD<real>> D;
+        for (auto& h : H.gauss) {
+            std::vector<GaussItem<real>> it(h.r0.size());
+            const std::vector<int> perm = spread_order((int)it.size(), 2, h.pairs.data(), natoms_);
+            for (size_t b = 0; b < it.size(); b++) {
+                const int o = perm[b];
+                it[b] = GaussItem<real>{h.pairs[2 * o], h.pairs[2 * o + 1], (real)h.r0[o], (real)(0.5 / (h.sigma[o] * h.sigma[o])), (real)h.kg[o]};
+            }
+            D.push_back(GaussD<real>{h.group, (int)it.size(), upload(it)});
+        }
+        if (D.size() > AWSEM_MAX_GAUSS) throw std::string("too many Gaussian-bond terms: at most " + std::to_string(AWSEM_MAX_GAUSS) + " per system");
+        S.n_gauss = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.gauss[t] = D[t];
+    }
     // pair lists: one slot per pair term, capacity = number of candidate pairs (cannot overflow)
     if (const char* env = getenv("AWSEM_SKIN")) {
         double v = atof(env);
@@ -900,6 +915,7 @@ template <class real> void Engine<real>::cell_setup(DevSys<real>& S, const HostS
     for (int t = 0; t < S.n_fm; t++) add(CJ_FM, t, S.fm[t].n, true);
     for (int t = 0; t < S.n_memb; t++) add(CJ_MEMB, t, S.memb[t].n, true);
     for (int t = 0; t < S.n_dh; t++) add(CJ_DH, t, S.dh[t].n, false);
+    for (int t = 0; t < S.n_gauss; t++) add(CJ_GAUSS, t, S.gauss[t].n, false);
     cell_nslots_ = slot;
     cell_nwin_ = (natoms_ + AWSEM_WIN - 1) / AWSEM_WIN;
     if ((size_t)cell_nslots_ * (cell_nwin_ + 1) != cell_wstart_.size()) throw std::string("internal error: window tables out of step with the bonded terms");
@@ -1288,6 +1304,13 @@ int awsem_add_debye_huckel(awsem_handle h, int group, int n, const int32_t* pair
     return AWSEM_OK;
 }
 
+int awsem_add_gaussian_bonds(awsem_handle h, int group, int n, const int32_t* pairs, const double* r0, const double* sigma, const double* kgamma) {
+    NEED_BUILD(h, group);
+    if (n < 0 || (n && (!pairs || !r0 || !sigma || !kgamma)) || !atoms_ok(h, pairs, 2 * (size_t)n)) return fail(AWSEM_EINVAL, "add_gaussian_bonds: bad arguments");
+    for (int b = 0; b < n; b++) if (!(sigma[b] > 0)) return fail(AWSEM_EINVAL, "add_gaussian_bonds: sigma must be positive");
+    h->H.gauss.push_back(HGauss{group, vec(pairs, 2 * (size_t)n), vec(r0, n), vec(sigma, n), vec(kgamma, n)});
+    return AWSEM_OK;
+}
 int awsem_finalize(awsem_handle h) {
     if (!h) return fail(AWSEM_EINVAL, "null handle");
     if (h->finalized) return fail(AWSEM_ESTATE, "system already finalized");

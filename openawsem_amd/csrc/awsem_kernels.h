@@ -417,6 +417,21 @@ template <bool ENERGY, class V> __device__ void term_dh(const DhD<typename V::re
     flush_energy<ENERGY>(L, d.group, e);
 }
 
+// Gaussian-well bonds: er_term templateTerms.py:643-693, additive_amhgo_term templateTerms.py:600-640 (CustomBondForce)
+template <bool ENERGY, class V> __device__ void term_gauss(const GaussD<typename V::real_t>& d, const V& L, int rot = 0) {
+    typedef typename V::real_t real;
+    Energy e;
+    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
+        const GaussItem<real> it = d.items[b];
+        const R3<real> dd = L.pos(it.i) - L.pos(it.j);
+        const real r2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z, ir = M<real>::rsqrt(r2), dr = r2 * ir - it.r0;
+        const real E = -it.c * M<real>::exp(-it.a * dr * dr);
+        if (ENERGY) e += (double)E;
+        L.pair_force(it.i, it.j, dd.x, dd.y, dd.z, (real)2 * it.a * dr * E * ir);   // -dE/dr / r, dE/dr = -2 a dr E
+    }
+    flush_energy<ENERGY>(L, d.group, e);
+}
+
 // ------------------------------------------------------------------ Verlet pair lists
 // Every pair term (excl, contact, beta, pap) is evaluated from a per-replica pair list instead of an all-pairs
 // scan.  BUILD (amortised: only when some atom has moved more than skin/2 since the last build) enumerates the
@@ -918,6 +933,7 @@ template <bool ENERGY, class V> __device__ void evaluate_terms(const DevSys<type
     if (c0) contact_single<ENERGY>(*c0, L, satom0, rotor.next(c0->nsites));
     for (int u = 0; u < S.n_harm; u++) if (AWSEM_ON(S.harm[u])) term_harmonic<ENERGY>(S.harm[u], L, rotor.next(S.harm[u].n));
     for (int u = 0; u < S.n_dh; u++) if (AWSEM_ON(S.dh[u])) term_dh<ENERGY>(S.dh[u], L, rotor.next(S.dh[u].n));
+    for (int u = 0; u < S.n_gauss; u++) if (AWSEM_ON(S.gauss[u])) term_gauss<ENERGY>(S.gauss[u], L, rotor.next(S.gauss[u].n));
     for (int u = 0; u < S.n_helical; u++) if (AWSEM_ON(S.helical[u])) term_helical<ENERGY>(S.helical[u], L, rotor.next(S.helical[u].n));
     for (int u = 0; u < S.n_memb; u++) if (AWSEM_ON(S.memb[u])) term_memb<ENERGY>(S.memb[u], L, rotor.next(S.memb[u].n));
     if (c0) __syncthreads();

@@ -275,6 +275,34 @@ class DebyeHuckelForce(Force):
                              self.screening_length)
 
 
+class GaussianBondForce(Force):
+    """CustomBondForce("-k*gamma_ij*exp(-(r-r_ijN)^2/(2*sigma_ij^2))") of er_term / additive_amhgo_term
+    (templateTerms.py:600-693): per bond (gamma_ij, r_ijN, sigma_ij); k is folded into gamma on upload."""
+    kind = "gaussian_bond"
+
+    def __init__(self, k, group=0):
+        super().__init__(group)
+        self.k = float(k)
+        self.pairs, self.gamma, self.r0, self.sigma = [], [], [], []
+
+    def addBond(self, i, j, params):
+        self.pairs.append((int(i), int(j)))
+        self.gamma.append(float(params[0]))
+        r0 = params[1]
+        if hasattr(r0, "value_in_unit"):
+            from . import unit as u
+            r0 = r0.value_in_unit(u.nanometer)
+        self.r0.append(float(r0))
+        self.sigma.append(float(params[2]))
+
+    def getNumBonds(self):
+        return len(self.r0)
+
+    def _upload(self, ctx):
+        ctx.add_gaussian_bonds(self._group, np.array(self.pairs, dtype=np.int32).reshape(-1, 2), self.r0, self.sigma,
+                               self.k * np.asarray(self.gamma, dtype=np.float64))
+
+
 class System:
     """Light stand-in for openmm.System: particle masses, virtual sites and the list of forces."""
 

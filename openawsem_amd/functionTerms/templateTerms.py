@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from ..forces import FragmentMemoryForce
+from ..forces import FragmentMemoryForce, GaussianBondForce
 
 
 def read_memory_list(frag_file_list_file):
@@ -124,3 +124,83 @@ def fragment_memory_term(oa, k_fm=0.04184, frag_file_list_file="./frag.mem", npy
     fm = FragmentMemoryForce(k_fm, pairs, table, frag_table_dr)
     fm.setForceGroup(forceGroup)
     return fm
+
+
+# --------------------------------------------------------------------------- Gaussian-well restraint terms
+def _nm(x):
+    """float nm from a plain number (already nm) or a unit Quantity."""
+    from .. import unit as u
+    return float(x.value_in_unit(u.nanometer)) if hasattr(x, "value_in_unit") else float(x)
+
+
+def _pdb_ca_cb(pdb_file, chain_name):
+    """Per residue of `chain_name` (first model): (residue name, CA xyz, CB xyz or None), coordinates in Angstrom."""
+    residues, index = [], {}
+    with open(pdb_file) as fh:
+        for line in fh:
+            if line.startswith("ENDMDL"):
+                break
+            if not line.startswith(("ATOM", "HETATM")) or line[21] != chain_name:
+                continue
+            name = line[12:16].strip()
+            if name not in ("CA", "CB"):
+                continue
+            key = line[22:27]
+            if key not in index:
+                index[key] = len(residues)
+                residues.append([line[17:20].strip(), None, None])
+            xyz = np.array([float(line[30:38]), float(line[38:46]), float(line[46:54])])
+            residues[index[key]][1 if name == "CA" else 2] = xyz
+    return residues
+
+
+def read_amhgo_structure(oa, pdb_file, chain_name, amhgo_min_seq_sep=4, amhgo_contact_threshold=0.8, amhgo_well_width=0.1):
+    """Native contacts of the AMH-Go term (reference templateTerms.py:535-597): for residues i - j >= min_seq_sep every
+    CA/CB x CA/CB pair (no CB for GLY/IGL) closer than the threshold in `pdb_file` gives a bond
+    [atom_i, atom_j, [gamma = 1, r_native (nm), sigma = well_width |i-j|^0.15]]."""
+    thr = _nm(amhgo_contact_threshold)
+    residues = _pdb_ca_cb(pdb_file, chain_name)
+    out = []
+    for i, (name_i, ca_i, cb_i) in enumerate(residues):
+        for j, (name_j, ca_j, cb_j) in enumerate(residues):
+            if i - j < amhgo_min_seq_sep:
+                continue
+            atoms_i = [(ca_i, oa.ca[i])] + ([(cb_i, oa.cb[i])] if name_i not in ("GLY", "IGL") else [])
+            atoms_j = [(ca_j, oa.ca[j])] + ([(cb_j, oa.cb[j])] if name_j not in ("GLY", "IGL") else [])
+            for xi, ai in atoms_i:
+                for xj, aj in atoms_j:
+                    r = float(np.linalg.norm(xi - xj)) / 10.0
+                    if r <= thr:
+                        out.append([ai, aj, [1.0, r, amhgo_well_width * abs(i - j) ** 0.15]])
+    return out
+
+
+def additive_amhgo_term(oa, pdb_file, chain_name, k_amhgo=4.184, amhgo_min_seq_sep=3, amhgo_contact_threshold=0.8,
+                        amhgo_well_width=0.1, forceGroup=22):
+    """AMH-Go structure-based term (reference templateTerms.py:600-640): Gaussian wells at the native distances."""
+    force = GaussianBondForce(k_amhgo * oa.k_awsem)
+    for a, b, params in read_amhgo_structure(oa, pdb_file, chain_name, amhgo_min_seq_sep, amhgo_contact_threshold, amhgo_well_width):
+        force.addBond(a, b, params)
+    force.setForceGroup(forceGroup)
+    return force
+
+
+def er_term(oa, k_er=4.184, er_min_seq_sep=2, er_cutoff=99.0, er_well_width=0.1, forceGroup=25):
+    """Evolutionary-restraint term (reference templateTerms.py:643-693): Gaussian wells at the predicted CA-CA, CA-CB and
+    CB-CB distances read from go_rnativeCACA.dat / go_rnativeCACB.dat / go_rnativeCBCB.dat (Angstrom, nres x nres) in the
+    current directory, for |i-j| >= er_min_seq_sep and predicted distance < er_cutoff."""
+    force = GaussianBondForce(k_er * oa.k_awsem)
+    caca, cacb, cbcb = (np.loadtxt(f) for f in ("go_rnativeCACA.dat", "go_rnativeCACB.dat", "go_rnativeCBCB.dat"))
+    for i in range(oa.nres):
+        for j in range(oa.nres):
+            if abs(i - j) < er_min_seq_sep:
+                continue
+            sigma = er_well_width * abs(i - j) ** 0.15
+            if caca[i][j] < er_cutoff:
+                force.addBond(oa.ca[i], oa.ca[j], [1.0, caca[i][j] / 10.0, sigma])
+            if cacb[i][j] < er_cutoff and oa.cb[j] != -1:
+                force.addBond(oa.ca[i], oa.cb[j], [1.0, cacb[i][j] / 10.0, sigma])
+            if cbcb[i][j] < er_cutoff and oa.cb[j] != -1 and oa.cb[i] != -1:
+                force.addBond(oa.cb[i], oa.cb[j], [1.0, cbcb[i][j] / 10.0, sigma])
+    force.setForceGroup(forceGroup)
+    return force

@@ -52,8 +52,9 @@ typedef struct { int group, n; int *atoms; double *coef; double r_ON, s_NO, r_OH
 typedef struct { int group, n, ntab; int *pairs; double *table; double k, dr; } fm_t;
 typedef struct { int group, n; int *atoms; double *scale; double k, k_m, z_m, center; } memb_t;
 typedef struct { int group, n; int *pairs; double *qq; double k, lam; } dh_t;
+typedef struct { int group, n; int *pairs; double *r0, *sigma, *kg; } gauss_t;
 
-enum { T_HARM, T_CHI, T_RAMA, T_EXCL, T_CONTACT, T_BETA, T_PAP, T_HELICAL, T_FM, T_MEMB, T_DH };
+enum { T_HARM, T_CHI, T_RAMA, T_EXCL, T_CONTACT, T_BETA, T_PAP, T_HELICAL, T_FM, T_MEMB, T_DH, T_GAUSS };
 typedef struct { int kind; void* p; } term_t;
 
 typedef struct awsem_oracle_ctx {
@@ -124,6 +125,7 @@ static void free_term(term_t* t) {
     case T_FM: { fm_t* x = p; free(x->pairs); free(x->table); } break;
     case T_MEMB: { memb_t* x = p; free(x->atoms); free(x->scale); } break;
     case T_DH: { dh_t* x = p; free(x->pairs); free(x->qq); } break;
+    case T_GAUSS: { gauss_t* x = p; free(x->pairs); free(x->r0); free(x->sigma); free(x->kg); } break;
     }
     free(p);
 }
@@ -261,6 +263,14 @@ int awsem_oracle_add_debye_huckel(ctx_t* c, int group, int n, const int* pairs, 
     dh_t* t = calloc(1, sizeof *t); t->group = group; t->n = n; t->pairs = dup_mem(pairs, 2 * n * sizeof(int)); t->qq = dup_mem(qq, n * sizeof(double));
     t->k = k; t->lam = lam;
     return add_term(c, T_DH, t);
+}
+int awsem_oracle_add_gaussian_bonds(ctx_t* c, int group, int n, const int* pairs, const double* r0, const double* sigma, const double* kg) {
+    CHECK_BUILD(c, group);
+    if (n < 0 || (n && (!pairs || !r0 || !sigma || !kg)) || !check_atoms(c, pairs, 2 * n, 0)) return fail(-1, "add_gaussian_bonds: bad arguments");
+    for (int b = 0; b < n; b++) if (!(sigma[b] > 0)) return fail(-1, "add_gaussian_bonds: sigma must be positive");
+    gauss_t* t = calloc(1, sizeof *t); t->group = group; t->n = n; t->pairs = dup_mem(pairs, 2 * n * sizeof(int));
+    t->r0 = dup_mem(r0, n * sizeof(double)); t->sigma = dup_mem(sigma, n * sizeof(double)); t->kg = dup_mem(kg, n * sizeof(double));
+    return add_term(c, T_GAUSS, t);
 }
 int awsem_oracle_finalize(ctx_t* c) { if (!c) return fail(-1, "null handle"); c->finalized = 1; return 0; }
 
@@ -611,6 +621,20 @@ static double eval_dh(const dh_t* t, const double* x, double* f) {
     return e;
 }
 
+/* er_term templateTerms.py:643-693 and additive_amhgo_term templateTerms.py:600-640 (CustomBondForce):
+ * E = -k gamma_ij exp(-(r - r_ijN)^2 / (2 sigma_ij^2)) */
+static double eval_gauss(const gauss_t* t, const double* x, double* f) {
+    double e = 0, d[3];
+    for (int b = 0; b < t->n; b++) {
+        int i = t->pairs[2 * b], j = t->pairs[2 * b + 1];
+        double r = dist(x, i, j, d), dr = r - t->r0[b], s2 = t->sigma[b] * t->sigma[b];
+        double E = -t->kg[b] * exp(-dr * dr / (2 * s2));
+        e += E;
+        pair_force(f, i, j, d, r, -E * dr / s2);
+    }
+    return e;
+}
+
 /* energies per group (eg[32], may be NULL) and forces f (natoms*3, may be NULL; accumulated into) */
 static void evaluate(const ctx_t* c, const double* x, uint32_t mask, double* eg, double* f) {
     for (int i = 0; i < c->nterms; i++) {
@@ -630,6 +654,7 @@ static void evaluate(const ctx_t* c, const double* x, uint32_t mask, double* eg,
         case T_FM: e = eval_fm(t->p, x, f); break;
         case T_MEMB: e = eval_memb(t->p, x, f); break;
         case T_DH: e = eval_dh(t->p, x, f); break;
+        case T_GAUSS: e = eval_gauss(t->p, x, f); break;
         }
         if (eg) eg[group] += e;
     }

@@ -1,0 +1,120 @@
+"""er_term / additive_amhgo_term (reference templateTerms.py:600-693): Gaussian-well bonds.
+
+Parity unpinned by any reference fixture (the ER column of the golden CSVs is identically zero because the reference test
+adds no ER force), so: the oracle is checked against the closed form and finite differences on CPU, the factories
+against a hand count of the bonds they must create, and the HIP path against the oracle on the golden trajectories."""
+import os
+
+import numpy as np
+import pytest
+
+import openawsem_amd as oa_pkg
+from openawsem_amd import _capi
+from openawsem_amd.forces import GaussianBondForce, System
+from openawsem_amd.functionTerms import templateTerms
+from oracle import awsem_oracle
+from tests.common import GOLDEN, golden_system
+
+
+def _pair_system():
+    system = System(np.array([12.0, 12.0, 12.0, 12.0]))
+    f = GaussianBondForce(4.184, group=25)
+    f.addBond(0, 1, [1.0, 0.5, 0.1])
+    f.addBond(2, 3, [0.5, 0.8, 0.2])
+    system.addForce(f)
+    return system
+
+
+def test_oracle_matches_closed_form_and_finite_differences():
+    system = _pair_system()
+    cpu = awsem_oracle.make_context(system, n_replicas=1)
+    x = np.array([[0.0, 0.0, 0.0], [0.55, 0.1, 0.0], [1.0, 1.0, 1.0], [1.3, 1.6, 1.2]])
+    cpu.set_positions(x, replica=0)
+    r1, r2 = np.linalg.norm(x[1] - x[0]), np.linalg.norm(x[3] - x[2])
+    expect = -4.184 * np.exp(-(r1 - 0.5) ** 2 / (2 * 0.1 ** 2)) - 4.184 * 0.5 * np.exp(-(r2 - 0.8) ** 2 / (2 * 0.2 ** 2))
+    assert abs(cpu.energy_by_group()[0, 25] - expect) < 1e-12
+    f = cpu.forces(redistribute=False)[0]
+    h = 1e-6
+    for a in range(4):
+        for k in range(3):
+            xp, xm = x.copy(), x.copy()
+            xp[a, k] += h
+            xm[a, k] -= h
+            cpu.set_positions(xp, replica=0)
+            ep = cpu.energy()[0]
+            cpu.set_positions(xm, replica=0)
+            em = cpu.energy()[0]
+            assert abs(-(ep - em) / (2 * h) - f[a, k]) < 1e-6
+
+
+def _write_native_tables(oa, x_nm, folder):
+    """go_rnative*.dat as the reference's er_term reads them: nres x nres predicted distances in Angstrom."""
+    nres = oa.nres
+    big = 99.9
+    tabs = {k: np.full((nres, nres), big) for k in ("CACA", "CACB", "CBCB")}
+    for i in range(nres):
+        for j in range(nres):
+            tabs["CACA"][i, j] = 10 * np.linalg.norm(x_nm[oa.ca[i]] - x_nm[oa.ca[j]])
+            if oa.cb[j] != -1:
+                tabs["CACB"][i, j] = 10 * np.linalg.norm(x_nm[oa.ca[i]] - x_nm[oa.cb[j]])
+            if oa.cb[i] != -1 and oa.cb[j] != -1:
+                tabs["CBCB"][i, j] = 10 * np.linalg.norm(x_nm[oa.cb[i]] - x_nm[oa.cb[j]])
+    for k, t in tabs.items():
+        np.savetxt(os.path.join(folder, f"go_rnative{k}.dat"), t, fmt="%.4f")
+
+
+def _restraint_system(tmp_path, monkeypatch):
+    oa, traj, _ = golden_system("1ubq")
+    monkeypatch.chdir(tmp_path)
+    _write_native_tables(oa, traj[0], str(tmp_path))
+    er = templateTerms.er_term(oa, er_cutoff=8.0)                        # contacts predicted below 8 A
+    go = templateTerms.additive_amhgo_term(oa, os.path.join(GOLDEN, "1ubq-crystal_structure.pdb"), "A", forceGroup=26)
+    system = System(oa.system.masses.copy())
+    system.virtual_sites = dict(oa.system.virtual_sites)
+    system.addForce(er)
+    system.addForce(go)
+    return oa, traj, system, er, go
+
+
+def test_factories_create_the_bonds_of_the_reference(tmp_path, monkeypatch):
+    oa, traj, system, er, go = _restraint_system(tmp_path, monkeypatch)
+    x = traj[0]
+    n = 0
+    for i in range(oa.nres):
+        for j in range(oa.nres):
+            if abs(i - j) < 2:
+                continue
+            n += np.linalg.norm(x[oa.ca[i]] - x[oa.ca[j]]) < 0.8 - 1e-6
+            n += oa.cb[j] != -1 and np.linalg.norm(x[oa.ca[i]] - x[oa.cb[j]]) < 0.8 - 1e-6
+            n += oa.cb[i] != -1 and oa.cb[j] != -1 and np.linalg.norm(x[oa.cb[i]] - x[oa.cb[j]]) < 0.8 - 1e-6
+    assert abs(er.getNumBonds() - n) <= 4 and er.getForceGroup() == 25      # +-: distances within the 4-decimal print of 8 A
+    assert go.getNumBonds() > 100 and go.getForceGroup() == 26
+    assert all(0 < s < 0.25 for s in go.sigma) and all(r <= 0.8 for r in go.r0)
+    # at the structure the tables were made from, every ER well sits at its minimum
+    cpu = awsem_oracle.make_context(system, n_replicas=1)
+    cpu.set_positions(x, replica=0)
+    assert abs(cpu.energy_by_group()[0, 25] + 4.184 * er.getNumBonds()) < 1e-3 * er.getNumBonds()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,etol,ftol", [(0, 1e-4, 1e-3), (1, 1e-9, 1e-7)])
+def test_gpu_matches_oracle(precision, etol, ftol, tmp_path, monkeypatch):
+    oa, traj, system, er, go = _restraint_system(tmp_path, monkeypatch)
+    frames = [0, 4, 8, 11]
+    gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=len(frames), precision=precision)
+    system.upload(gpu)
+    cpu = awsem_oracle.make_context(system, n_replicas=len(frames))
+    for r, f in enumerate(frames):
+        gpu.set_positions(traj[f], replica=r)
+        cpu.set_positions(traj[f], replica=r)
+    eg, ec = gpu.energy_by_group(), cpu.energy_by_group()
+    for group in (25, 26):
+        assert np.all(np.abs(ec[:, group]) > 1.0)
+        assert np.abs(eg[:, group] - ec[:, group]).max() <= etol * np.abs(ec[:, group]).max()
+    fg, fc = gpu.forces(redistribute=False), cpu.forces(redistribute=False)
+    assert np.linalg.norm(fg - fc) <= ftol * np.linalg.norm(fc)
+    assert np.all(fg.sum(axis=1) == 0.0)      # pair term: +F / -F bit for bit
+    # and through the integrator: the restrained chain stays near the structure the wells were made from
+    gpu.set_velocities_to_temperature(np.full(len(frames), 300.0), 3)
+    gpu.step(200, np.full(len(frames), 300.0), 0.002, 1.0, 3)
+    assert np.isfinite(gpu.energy()).all()
