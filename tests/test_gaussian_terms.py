@@ -118,3 +118,20 @@ def test_gpu_matches_oracle(precision, etol, ftol, tmp_path, monkeypatch):
     gpu.set_velocities_to_temperature(np.full(len(frames), 300.0), 3)
     gpu.step(200, np.full(len(frames), 300.0), 0.002, 1.0, 3)
     assert np.isfinite(gpu.energy()).all()
+
+
+def test_constraint_by_distance_is_a_harmonic_bond():
+    from openawsem_amd import unit as u
+    from openawsem_amd.functionTerms import constraints
+    oa, traj, _ = golden_system("1ubq")
+    f = constraints.constraint_by_distance(oa, 3, 40, d0=12 * u.angstrom, k=2 * u.kilocalorie_per_mole)
+    assert f.getForceGroup() == 3 and f.pairs == [(oa.ca[3], oa.ca[40])]
+    assert abs(f.r0[0] - 1.2) < 1e-12 and abs(f.k[0] - 2 * 4.184) < 1e-12
+    system = System(oa.system.masses.copy())
+    system.addForce(f)
+    cpu = awsem_oracle.make_context(system, n_replicas=1)
+    cpu.set_positions(traj[0], replica=0)
+    r = np.linalg.norm(traj[0][oa.ca[3]] - traj[0][oa.ca[40]])
+    assert abs(cpu.energy_by_group()[0, 3] - 0.5 * 2 * 4.184 * (r - 1.2) ** 2) < 1e-10
+    with pytest.raises(NotImplementedError):
+        constraints.group_constraint_by_position(oa)
