@@ -29,7 +29,7 @@ HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 WORKLOADS = {
     "1r69": ("build_1r69", {}, 1024, 50, "1r69 batched annealing ensemble, default forces_setup.py terms, 800->200 K Langevin (dt 2 fs, friction 1/ps)"),
     "1r69-fraglib": ("build_1r69", {"fragment_library": True}, 1024, 50, "1r69 with the 1100-memory fragment library (examples/1r69/frags.mem), default terms, annealing ensemble"),
-    "t0958": ("build_t0958", {}, 768, 50, "T0958 (96 residues), default terms + helical + rama_ssweight, fragment memory, annealing ensemble"),
+    "t0958": ("build_t0958", {}, 1024, 50, "T0958 (96 residues), default terms + helical + rama_ssweight, fragment memory, annealing ensemble"),
     "2xov": ("build_2xov", {}, 256, 50, "2xov membrane protein (276 residues), membrane_term + z-dependent contact, annealing ensemble"),
     "2xov-remd": ("build_2xov", {}, 64, 200, "2xov membrane protein, temperature replica exchange 300-600 K, exchange every launch (all-gather of energies, label swap)"),
     "synthetic": ("build_synthetic", {}, 1, 20, "synthetic multi-chain system (122 x 2lzm), con/chain/chi/excl/rama/contact+burial, cell-list path, Langevin (dt 2 fs, friction 1/ps)"),

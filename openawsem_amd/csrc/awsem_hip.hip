@@ -413,7 +413,9 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         int max_sites = 0;
         for (auto& h : H.contact) max_sites = std::max(max_sites, (int)h.atom.size());
         const char* force = getenv("AWSEM_FORCE_CELL");
-        cell_mode_ = lds_bytes<real>(natoms_, max_sites, (int)H.contact.size(), false) > lds_max || (force && atoi(force) != 0);
+        bool zdep = false;
+        for (auto& h : H.contact) zdep = zdep || (h.flags & AWSEM_CONTACT_ZDEP);
+        cell_mode_ = lds_bytes<real>(LdsShape{natoms_, max_sites, (int)H.contact.size(), 0, zdep ? 2400 : 1200}, false) > lds_max || (force && atoi(force) != 0);
     }
     // Item order of the static lists.  Replica-resident path: conflict-aware (spread_order).  Cell-list path: by window of
     // AWSEM_WIN atoms (the window kernel accumulates a window's items in LDS); items spanning more than a window's LDS
@@ -725,8 +727,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
     S.prof = dalloc<long long>(16);
     HIP_TRY(hipMemset(S.prof, 0, 16 * sizeof(long long)));
     const size_t lds_max = lds_max_;
-    lds_eval_ = lds_bytes<real>(natoms_, S.max_contact_sites, S.n_contact, false);
-    lds_step_ = lds_bytes<real>(natoms_, S.max_contact_sites, S.n_contact, true);
+    lds_eval_ = lds_bytes<real>(lds_shape(S), false);
+    lds_step_ = lds_bytes<real>(lds_shape(S), true);
     if (cell_mode_) {
         cell_setup(S, H);
     } else {

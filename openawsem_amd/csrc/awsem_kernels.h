@@ -972,52 +972,62 @@ template <bool ENERGY, class V> __device__ void evaluate_terms(const DevSys<type
 template <class real> struct LdsLayout;
 template <> struct LdsLayout<float> { static constexpr int pos = 16, force = 16, vel = 16, ref = 16; };      // float4, FAcc32, float4, float4
 template <> struct LdsLayout<double> { static constexpr int pos = 24, force = 24, vel = 24, ref = 24; };     // three 8-byte planes each
-template <class real> __host__ __device__ inline size_t lds_bytes(int natoms, int nsites, int ncontact, bool with_vel) {
+// what sizes the LDS image of a replica: velocities exist for the massive particles only (indexed by their position in
+// DevSys::massive), the gamma staging holds one environment (1200) or both (2400, z-dependent contact)
+struct LdsShape { int natoms, nsites, ncontact, nmassive, ngamma; };
+template <class real> __host__ __device__ inline LdsShape lds_shape(const DevSys<real>& S) {
+    return LdsShape{S.natoms, S.max_contact_sites, S.n_contact, S.nmassive, S.any_zdep ? 2400 : 1200};
+}
+template <class real> __host__ __device__ inline size_t lds_bytes(const LdsShape& sh, bool with_vel) {
+    const int natoms = sh.natoms, nsites = sh.nsites, ncontact = sh.ncontact;
     typedef LdsLayout<real> Y;
     size_t b = 0;
-    b += (size_t)natoms * (Y::pos + Y::force + (with_vel ? Y::vel + Y::ref : 0));
+    b += (size_t)natoms * (Y::pos + Y::force + (with_vel ? Y::ref : 0)) + (with_vel ? (size_t)sh.nmassive * Y::vel : 0);
     b += (size_t)2 * nsites * sizeof(u64);            // rho, drho
     b += AWSEM_NGROUPS * sizeof(u64);                 // group energies
     b += (size_t)3 * nsites * sizeof(real);           // rhov, alpha, dalpha
-    b += (size_t)2400 * sizeof(real);                 // gamma staging
+    b += (size_t)sh.ngamma * sizeof(real);            // gamma staging
     b += (size_t)(ncontact > 0 ? ncontact : 1) * nsites * sizeof(int);   // contact site -> atom
     b += (AWSEM_MAX_LISTS + 4) * sizeof(unsigned);    // list counters, flags
     return (b + 15) & ~(size_t)15;
 }
-template <class real> __device__ inline void carve_common(ViewCommon<real>& L, unsigned char* q, int nsites, int ncontact) {
+template <class real> __device__ inline void carve_common(ViewCommon<real>& L, unsigned char* q, const LdsShape& sh) {
+    const int nsites = sh.nsites, ncontact = sh.ncontact;
     u64* w = (u64*)q;
     L.rho = w; w += nsites; L.drho = w; w += nsites;
     L.eg = w; w += AWSEM_NGROUPS;
     real* r = (real*)w;
     L.rhov = r; r += nsites; L.alpha = r; r += nsites; L.dalpha = r; r += nsites;
-    L.gamma = r; r += 2400;
+    L.gamma = r; r += sh.ngamma;
     L.satom = (int*)r;
     L.lcount = (unsigned*)(L.satom + (ncontact > 0 ? ncontact : 1) * nsites);
     L.flag = L.lcount + AWSEM_MAX_LISTS;
     L.lists = nullptr;
 }
-__device__ inline Lds<float> carve_lds(float, unsigned char* base, int natoms, int nsites, int ncontact, bool with_vel) {
+__device__ inline Lds<float> carve_lds(float, unsigned char* base, const LdsShape& sh, bool with_vel) {
     Lds<float> L;
+    const int natoms = sh.natoms;
     unsigned char* q = base;
     L.p = (float4*)q; q += (size_t)16 * natoms;
     L.f = (FAcc32*)q; q += (size_t)16 * natoms;
     L.v = nullptr; L.ref = nullptr;
-    if (with_vel) { L.v = (float4*)q; q += (size_t)16 * natoms; L.ref = (float4*)q; q += (size_t)16 * natoms; }
-    carve_common<float>(L, q, nsites, ncontact);
+    if (with_vel) { L.v = (float4*)q; q += (size_t)16 * sh.nmassive; L.ref = (float4*)q; q += (size_t)16 * natoms; }
+    carve_common<float>(L, q, sh);
     return L;
 }
-__device__ inline Lds<double> carve_lds(double, unsigned char* base, int natoms, int nsites, int ncontact, bool with_vel) {
+__device__ inline Lds<double> carve_lds(double, unsigned char* base, const LdsShape& sh, bool with_vel) {
     Lds<double> L;
+    const int natoms = sh.natoms, nm = sh.nmassive;
     u64* w = (u64*)base;
     L.fx = w; w += natoms; L.fy = w; w += natoms; L.fz = w; w += natoms;
     double* r = (double*)w;
     L.px = r; r += natoms; L.py = r; r += natoms; L.pz = r; r += natoms;
     L.vx = L.vy = L.vz = L.rx = L.ry = L.rz = nullptr;
     if (with_vel) {
-        L.vx = r; r += natoms; L.vy = r; r += natoms; L.vz = r; r += natoms;
+        L.vx = r; r += nm; L.vy = r; r += nm; L.vz = r; r += nm;
         L.rx = r; r += natoms; L.ry = r; r += natoms; L.rz = r; r += natoms;
     }
-    carve_common<double>(L, (unsigned char*)r, nsites, ncontact);
+    carve_common<double>(L, (unsigned char*)r, sh);
     return L;
 }
 
@@ -1033,7 +1043,7 @@ __global__ void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__
                                   double* __restrict__ e_out /* [R][32] or null */, double* __restrict__ f_out /* [R][natoms][3] or null */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = blockIdx.x;
-    Lds<real> L = carve_lds((real)0, smem, natoms, S.max_contact_sites, S.n_contact, false);
+    Lds<real> L = carve_lds((real)0, smem, lds_shape(S), false);
     L.lists = S.lists + (size_t)rep * S.list_stride;
     load_positions(pos + (size_t)rep * 3 * natoms, L, natoms);
     for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
@@ -1061,7 +1071,7 @@ template <class real>
 __global__ void awsem_list_kernel(const DevSys<real> S, const real* __restrict__ pos, unsigned mask, unsigned* __restrict__ counts /* [R][AWSEM_MAX_LISTS] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = blockIdx.x;
-    Lds<real> L = carve_lds((real)0, smem, natoms, S.max_contact_sites, S.n_contact, false);
+    Lds<real> L = carve_lds((real)0, smem, lds_shape(S), false);
     L.lists = S.lists + (size_t)rep * S.list_stride;
     load_positions(pos + (size_t)rep * 3 * natoms, L, natoms);
     if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
@@ -1154,12 +1164,15 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
                                   long long step0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = blockIdx.x;
-    Lds<real> L = carve_lds((real)0, smem, natoms, S.max_contact_sites, S.n_contact, true);
+    Lds<real> L = carve_lds((real)0, smem, lds_shape(S), true);
     L.lists = S.lists + (size_t)rep * S.list_stride;
     real* gp = pos + (size_t)rep * 3 * natoms;
     real* gv = vel + (size_t)rep * 3 * natoms;
     load_positions(gp, L, natoms);
-    for (int i = threadIdx.x; i < natoms; i += blockDim.x) L.set_vel(i, R3<real>{gv[i], gv[natoms + i], gv[2 * natoms + i]});
+    for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {   // velocities live in LDS for the massive particles only, by massive index
+        const int i = S.massive[k].atom;
+        L.set_vel(k, R3<real>{gv[i], gv[natoms + i], gv[2 * natoms + i]});
+    }
     for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
     const double a_d = ::exp(-friction * dt);
     const real a = (real)a_d, fs = (real)(friction == 0.0 ? dt : (1.0 - a_d) / friction);
@@ -1202,12 +1215,12 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
                 real g[3];
                 gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, i, g);
                 const real im = fs * mi.inv_mass, sq = ns * mi.sqrt_inv_mass;
-                R3<real> v = L.vel(i), x = L.pos(i);
+                R3<real> v = L.vel(k), x = L.pos(i);
                 v.x = a * v.x + im * F.x + sq * g[0];
                 v.y = a * v.y + im * F.y + sq * g[1];
                 v.z = a * v.z + im * F.z + sq * g[2];
                 x.x += dtr * v.x; x.y += dtr * v.y; x.z += dtr * v.z;
-                L.set_vel(i, v); L.set_pos(i, x);
+                L.set_vel(k, v); L.set_pos(i, x);
                 m = fmaxf(m, (float)dist2(x - L.refpos(i)));
             }
             book_displacement(&L.flag[cur ^ 1], m);
@@ -1234,8 +1247,12 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
     }
     AWSEM_STAMP_FLUSH(S);
     for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
-        const R3<real> x = L.pos(i), v = L.vel(i);
+        const R3<real> x = L.pos(i);
         gp[i] = x.x; gp[natoms + i] = x.y; gp[2 * natoms + i] = x.z;
+    }
+    for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {
+        const int i = S.massive[k].atom;
+        const R3<real> v = L.vel(k);
         gv[i] = v.x; gv[natoms + i] = v.y; gv[2 * natoms + i] = v.z;
     }
 }
@@ -1252,11 +1269,11 @@ __global__ void awsem_minimize_kernel(const DevSys<real> S, real* __restrict__ p
                                       int* __restrict__ iterations /* [R] */, double* __restrict__ rms_out /* [R] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = blockIdx.x;
-    Lds<real> L = carve_lds((real)0, smem, natoms, S.max_contact_sites, S.n_contact, true);
+    Lds<real> L = carve_lds((real)0, smem, lds_shape(S), true);
     L.lists = S.lists + (size_t)rep * S.list_stride;
     real* gp = pos + (size_t)rep * 3 * natoms;
     load_positions(gp, L, natoms);
-    for (int i = threadIdx.x; i < natoms; i += blockDim.x) L.set_vel(i, R3<real>{0, 0, 0});
+    for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) L.set_vel(k, R3<real>{0, 0, 0});
     for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
     stage_tables(S, L);
     if (threadIdx.x < 2) L.flag[threadIdx.x] = 0;
@@ -1293,7 +1310,7 @@ __global__ void awsem_minimize_kernel(const DevSys<real> S, real* __restrict__ p
                     const R3<real> fv = L.force(gi.vs[q]);
                     F.x += gi.w[q] * fv.x; F.y += gi.w[q] * fv.y; F.z += gi.w[q] * fv.z;
                 }
-                const R3<real> v = L.vel(i);
+                const R3<real> v = L.vel(k);
                 eP += (double)(F.x * v.x + F.y * v.y + F.z * v.z) * sP;
                 eF += (double)(F.x * F.x + F.y * F.y + F.z * F.z) * sF;
                 eV += (double)(v.x * v.x + v.y * v.y + v.z * v.z);
@@ -1322,7 +1339,7 @@ __global__ void awsem_minimize_kernel(const DevSys<real> S, real* __restrict__ p
                     const R3<real> fv = L.force(gi.vs[q]);
                     F.x += gi.w[q] * fv.x; F.y += gi.w[q] * fv.y; F.z += gi.w[q] * fv.z;
                 }
-                R3<real> v = L.vel(i), x = L.pos(i);
+                R3<real> v = L.vel(k), x = L.pos(i);
                 v.x = keep * v.x + mix * F.x + dt * F.x;
                 v.y = keep * v.y + mix * F.y + dt * F.y;
                 v.z = keep * v.z + mix * F.z + dt * F.z;
@@ -1330,7 +1347,7 @@ __global__ void awsem_minimize_kernel(const DevSys<real> S, real* __restrict__ p
                 const real d2 = dx * dx + dy * dy + dz * dz;
                 if (d2 > dmax2) { const real sc = M<real>::sqrt(dmax2 / d2); dx *= sc; dy *= sc; dz *= sc; }
                 x.x += dx; x.y += dy; x.z += dz;
-                L.set_vel(i, v); L.set_pos(i, x);
+                L.set_vel(k, v); L.set_pos(i, x);
                 m = fmaxf(m, (float)dist2(x - L.refpos(i)));
             }
             book_displacement(&L.flag[cur ^ 1], m);
