@@ -154,6 +154,13 @@ int awsem_set_positions(awsem_handle h, int replica, const double* xyz, int nato
 int awsem_get_positions(awsem_handle h, int replica, double* xyz, int natoms);
 int awsem_set_velocities(awsem_handle h, int replica, const double* vxyz, int natoms);
 int awsem_get_velocities(awsem_handle h, int replica, double* vxyz, int natoms);
+/* Whole ensemble at once (what a reporter or a checkpoint of an R-replica run needs: one transfer instead of R):
+ * xyz / vxyz are n_replicas x natoms x 3; either may be NULL.  CheckpointReporter / loadCheckpoint, scripts/mm_run.py:92-94,124-127. */
+int awsem_set_state(awsem_handle h, const double* xyz, const double* vxyz);
+int awsem_get_state(awsem_handle h, double* xyz, double* vxyz);
+/* Kinetic energy of every replica, sum over the massive particles of 1/2 m v^2 (kJ/mol): the temperature column of
+ * StateDataReporter (scripts/mm_run.py:157-158), reduced on the device. */
+int awsem_kinetic_energy(awsem_handle h, double* ke_per_replica);
 int awsem_compute_virtual_sites(awsem_handle h);
 /* context.setVelocitiesToTemperature scripts/mm_run.py:151; T is per replica (n_replicas). */
 int awsem_set_velocities_to_temperature(awsem_handle h, const double* T_kelvin, uint64_t seed);

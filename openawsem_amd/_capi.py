@@ -44,6 +44,9 @@ _SIGNATURES = {
     "get_positions": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_int]),
     "set_velocities": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_int]),
     "get_velocities": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_int]),
+    "set_state": (C.c_int, ["H", c_dbl_p, c_dbl_p]),
+    "get_state": (C.c_int, ["H", c_dbl_p, c_dbl_p]),
+    "kinetic_energy": (C.c_int, ["H", c_dbl_p]),
     "compute_virtual_sites": (C.c_int, ["H"]),
     "set_velocities_to_temperature": (C.c_int, ["H", c_dbl_p, C.c_uint64]),
     "scale_velocities": (C.c_int, ["H", c_dbl_p]),
@@ -238,6 +241,23 @@ class Context:
         v = np.empty((self.natoms, 3))
         self._call("get_velocities", int(replica), _dp(v), self.natoms)
         return v
+
+    def get_state(self, positions=True, velocities=True):
+        """(positions, velocities) of all replicas, each [n_replicas, natoms, 3] (None when not requested)."""
+        x = np.empty((self.n_replicas, self.natoms, 3)) if positions else None
+        v = np.empty((self.n_replicas, self.natoms, 3)) if velocities else None
+        self._call("get_state", _dp(x) if positions else None, _dp(v) if velocities else None)
+        return x, v
+
+    def set_state(self, positions=None, velocities=None):
+        x = None if positions is None else _f64(positions).reshape(self.n_replicas, self.natoms, 3)
+        v = None if velocities is None else _f64(velocities).reshape(self.n_replicas, self.natoms, 3)
+        self._call("set_state", None if x is None else _dp(x), None if v is None else _dp(v))
+
+    def kinetic_energy(self):
+        ke = np.empty(self.n_replicas)
+        self._call("kinetic_energy", _dp(ke))
+        return ke
 
     def compute_virtual_sites(self):
         self._call("compute_virtual_sites")

@@ -83,6 +83,9 @@ struct EngineBase {
     virtual void forces(unsigned mask, int redistribute, double* f) = 0;
     virtual void step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) = 0;
     virtual void synchronize() = 0;
+    virtual void kinetic_energy(double* ke) = 0;
+    virtual void set_state_all(const double* xyz, const double* v) = 0;
+    virtual void get_state_all(double* xyz, double* v) = 0;
     virtual void minimize(double tolerance, int max_iterations, int32_t* iterations, double* rms) = 0;
     virtual int neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) = 0;
     double last_ms = 0.0;
@@ -201,6 +204,42 @@ public:
         check_status();
         if (iterations) HIP_TRY(hipMemcpy(iterations, dmin_it_, sizeof(int) * nrep_, hipMemcpyDeviceToHost));
         if (rms) HIP_TRY(hipMemcpy(rms, dmin_rms_, sizeof(double) * nrep_, hipMemcpyDeviceToHost));
+    }
+    void kinetic_energy(double* ke) override {
+        HIP_TRY(hipSetDevice(device_));
+        synchronize();
+        hipLaunchKernelGGL(awsem_kinetic_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, vel_, dT_);   // dT_: per-replica double scratch
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ke, dT_, sizeof(double) * nrep_, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+    }
+    // whole ensemble at once: one copy of the SoA device array, transposed on the host
+    void set_state_all(const double* xyz, const double* v) override {
+        HIP_TRY(hipSetDevice(device_));
+        synchronize();
+        const size_t n3 = (size_t)3 * natoms_;
+        std::vector<real> t(n3 * nrep_);
+        for (int pass = 0; pass < 2; pass++) {
+            const double* src = pass ? v : xyz;
+            if (!src) continue;
+            for (int r = 0; r < nrep_; r++) for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++)
+                t[r * n3 + (size_t)k * natoms_ + i] = (real)src[r * n3 + 3 * (size_t)i + k];
+            HIP_TRY(hipMemcpy(pass ? vel_ : pos_, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
+            if (!pass) cell_stale_ = true;
+        }
+    }
+    void get_state_all(double* xyz, double* v) override {
+        HIP_TRY(hipSetDevice(device_));
+        synchronize();
+        const size_t n3 = (size_t)3 * natoms_;
+        std::vector<real> t(n3 * nrep_);
+        for (int pass = 0; pass < 2; pass++) {
+            double* dst = pass ? v : xyz;
+            if (!dst) continue;
+            HIP_TRY(hipMemcpy(t.data(), pass ? vel_ : pos_, t.size() * sizeof(real), hipMemcpyDeviceToHost));
+            for (int r = 0; r < nrep_; r++) for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++)
+                dst[r * n3 + 3 * (size_t)i + k] = (double)t[r * n3 + (size_t)k * natoms_ + i];
+        }
     }
     void synchronize() override {
         HIP_TRY(hipSetDevice(device_));
@@ -1363,6 +1402,19 @@ int awsem_minimize(awsem_handle h, double tolerance, int max_iterations, int32_t
     NEED_RUN(h);
     if (!(tolerance > 0) || max_iterations < 0) return fail(AWSEM_EINVAL, "minimize: tolerance must be positive, max_iterations >= 0");
     GUARD_BEGIN h->eng->minimize(tolerance, max_iterations, iterations, rms_force); return AWSEM_OK; GUARD_END
+}
+int awsem_kinetic_energy(awsem_handle h, double* ke) {
+    NEED_RUN(h);
+    if (!ke) return fail(AWSEM_EINVAL, "kinetic_energy: null output");
+    GUARD_BEGIN h->eng->kinetic_energy(ke); return AWSEM_OK; GUARD_END
+}
+int awsem_set_state(awsem_handle h, const double* xyz, const double* vxyz) {
+    NEED_RUN(h);
+    GUARD_BEGIN h->eng->set_state_all(xyz, vxyz); return AWSEM_OK; GUARD_END
+}
+int awsem_get_state(awsem_handle h, double* xyz, double* vxyz) {
+    NEED_RUN(h);
+    GUARD_BEGIN h->eng->get_state_all(xyz, vxyz); return AWSEM_OK; GUARD_END
 }
 int awsem_energy_by_group(awsem_handle h, double* e) {
     NEED_RUN(h);

@@ -1133,6 +1133,28 @@ __global__ void awsem_scale_velocities_kernel(real* __restrict__ vel, const doub
     for (int i = threadIdx.x; i < n3; i += blockDim.x) v[i] *= s;
 }
 
+// kinetic energy of every replica: sum over the massive particles of 1/2 m v^2 (StateDataReporter's temperature column)
+template <class real>
+__global__ void awsem_kinetic_kernel(const DevSys<real> S, const real* __restrict__ vel, double* __restrict__ ke) {
+    const int natoms = S.natoms, rep = blockIdx.x;
+    const real* v = vel + (size_t)rep * 3 * natoms;
+    __shared__ double part[16];
+    double s = 0;
+    for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {
+        const MassiveItem<real> mi = S.massive[k];
+        const double vx = v[mi.atom], vy = v[natoms + mi.atom], vz = v[2 * natoms + mi.atom];
+        s += 0.5 * (vx * vx + vy * vy + vz * vz) / (double)mi.inv_mass;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += part[w];   // fixed order: reproducible
+        ke[rep] = t;
+    }
+}
+
 template <class real>
 __global__ void awsem_vsite_kernel(const DevSys<real> S, real* __restrict__ pos) {
     const int natoms = S.natoms;

@@ -214,8 +214,7 @@ class Context:
         return e
 
     def kineticEnergies(self):
-        m = self.system.masses
-        return np.array([0.5 * float((m[:, None] * self._ctx.get_velocities(r) ** 2).sum()) for r in range(self.n_replicas)])
+        return self._ctx.kinetic_energy()   # reduced on the device: one value per replica
 
     def getState(self, getPositions=False, getVelocities=False, getForces=False, getEnergy=False, groups=-1,
                  enforcePeriodicBox=False, replica=0):
@@ -223,8 +222,7 @@ class Context:
         mask = _group_mask(groups)
         if getEnergy:
             e = float(self.energies(mask)[replica])
-            m = self.system.masses
-            ke = 0.5 * float((m[:, None] * self._ctx.get_velocities(replica) ** 2).sum())
+            ke = float(self._ctx.kinetic_energy()[replica])
         if getPositions:
             x = self._ctx.get_positions(replica)
         if getVelocities:
@@ -327,8 +325,8 @@ class Simulation:
     def saveCheckpoint(self, file):
         c = self.context._ctx
         R = self.context.n_replicas
-        arrays = {"positions": np.stack([c.get_positions(r) for r in range(R)]),
-                  "velocities": np.stack([c.get_velocities(r) for r in range(R)]),
+        x, v = c.get_state()
+        arrays = {"positions": x, "velocities": v,
                   "step": np.array([self.currentStep, c.step_count], dtype=np.int64), "time_ps": np.array([self.context._time_ps])}
         if isinstance(file, str):
             with open(file, "wb") as fh:
@@ -341,9 +339,7 @@ class Simulation:
             x, v, step, t = z["positions"], z["velocities"], z["step"], z["time_ps"]
         if x.shape != (self.context.n_replicas, self.system.getNumParticles(), 3):
             raise ValueError("checkpoint does not match this system / replica count")
-        for r in range(len(x)):
-            self.context._ctx.set_positions(x[r], r)
-            self.context._ctx.set_velocities(v[r], r)
+        self.context._ctx.set_state(x, v)
         self.currentStep = int(step[0])
         self.context._ctx.step_count = int(step[1])
         self.context._time_ps = float(t[0])

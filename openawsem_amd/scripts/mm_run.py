@@ -85,9 +85,7 @@ def run(args):
         movie0 = engine.DCDReporter(os.path.join(toPath, "movie.dcd"), 1)
         native.report(simulation), movie0.report(simulation)
         if not args.noMinimize:
-            engine.minimize(simulation.context, replica=0)
-            x0 = simulation.context._ctx.get_positions(0)
-            simulation.context.setPositions(x0)           # every replica starts from the minimised structure
+            simulation.minimizeEnergy()                   # all replicas on the device (identical start -> identical minimum)
         native.report(simulation), movie0.report(simulation)
         simulation.context.setVelocitiesToTemperature(Tstart * kelvin, args.seed)
 
@@ -117,7 +115,7 @@ def run(args):
     if R > 1:
         c = simulation.context
         np.savez(os.path.join(toPath, "ensemble_final.npz"), energies=c.energies(),
-                 positions=np.stack([c._ctx.get_positions(r) for r in range(R)]))
+                 positions=c._ctx.get_state(velocities=False)[0])
     return simulation
 
 

@@ -305,6 +305,33 @@ int awsem_oracle_get_velocities(ctx_t* c, int rep, double* v, int natoms) {
     return 0;
 }
 /* ThreeParticleAverageSite: x = w1 x1 + w2 x2 + w3 x3 (openAWSEM.py:685-696) */
+/* all replicas at once: n_replicas x natoms x 3 each, either may be NULL */
+int awsem_oracle_set_state(ctx_t* c, const double* xyz, const double* v) {
+    CHECK_RUN(c);
+    size_t n = (size_t)c->nrep * c->natoms * 3;
+    if (xyz) memcpy(c->pos, xyz, n * sizeof(double));
+    if (v) memcpy(c->vel, v, n * sizeof(double));
+    return 0;
+}
+int awsem_oracle_get_state(ctx_t* c, double* xyz, double* v) {
+    CHECK_RUN(c);
+    size_t n = (size_t)c->nrep * c->natoms * 3;
+    if (xyz) memcpy(xyz, c->pos, n * sizeof(double));
+    if (v) memcpy(v, c->vel, n * sizeof(double));
+    return 0;
+}
+/* sum over the massive particles of 1/2 m v^2 (kJ/mol), one value per replica */
+int awsem_oracle_kinetic_energy(ctx_t* c, double* ke) {
+    CHECK_RUN(c);
+    if (!ke) return fail(-1, "kinetic_energy: null output");
+    for (int r = 0; r < c->nrep; r++) {
+        const double* v = c->vel + (size_t)r * c->natoms * 3;
+        double s = 0;
+        for (int i = 0; i < c->natoms; i++) s += 0.5 * c->mass[i] * (v[3 * i] * v[3 * i] + v[3 * i + 1] * v[3 * i + 1] + v[3 * i + 2] * v[3 * i + 2]);
+        ke[r] = s;
+    }
+    return 0;
+}
 static void virtual_sites(const ctx_t* c, double* x) {
     for (int i = 0; i < c->nvs; i++) {
         const int* p = c->vs_par + 3 * i; const double* w = c->vs_w + 3 * i; double* s = x + 3 * c->vs_site[i];

@@ -100,3 +100,27 @@ def test_bench_size_ensemble_stays_finite_and_reproducible():
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
     assert np.abs(runs[0][1] - runs[0][2]).max() > 1e-3
     assert len(np.unique(runs[0][0])) > R // 2
+
+
+def test_bulk_state_and_device_kinetic_energy_match_the_per_replica_calls():
+    oa, traj, _ = golden_system("1ubq")
+    R = 5
+    gpu = _ctx(oa.system, oa.natoms, R=R)
+    for r in range(R):
+        gpu.set_positions(traj[r], replica=r)
+    gpu.set_velocities_to_temperature(np.linspace(200.0, 600.0, R), 11)
+    gpu.step(7, np.linspace(200.0, 600.0, R), 0.002, 1.0, 11)
+    x, v = gpu.get_state()
+    for r in range(R):
+        assert np.array_equal(x[r], gpu.get_positions(r)) and np.array_equal(v[r], gpu.get_velocities(r))
+    m = oa.system.masses
+    ke = np.array([0.5 * (m[:, None] * v[r] ** 2).sum() for r in range(R)])
+    assert np.allclose(gpu.kinetic_energy(), ke, rtol=1e-6)
+    dof = 3 * (m > 0).sum()
+    assert np.all(np.abs(2 * ke / (dof * 0.00831446261815324) / np.linspace(200.0, 600.0, R) - 1) < 0.6)    # kinetic temperature in the range of the bath (666 degrees of freedom, 7 steps after the draw)
+    # round trip through set_state
+    other = _ctx(oa.system, oa.natoms, R=R)
+    other.set_state(x, v)
+    y, w = other.get_state()
+    assert np.array_equal(x, y) and np.array_equal(v, w)
+    assert np.array_equal(other.energy(), gpu.energy())
