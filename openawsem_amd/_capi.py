@@ -142,7 +142,12 @@ class Context:
         except Exception:
             pass
 
+    _READ_ONLY = frozenset(("get_positions", "get_velocities", "get_state", "kinetic_energy", "energy", "energy_by_group",
+                            "forces", "neighbors", "synchronize"))
+
     def _call(self, name, *args):
+        if name not in self._READ_ONLY:
+            self._memo = {}          # any other call may change the state the memoised queries were computed from
         self.api.check(self.api.fn[name](self.h, *args))
 
     # ---- construction
@@ -255,9 +260,12 @@ class Context:
         self._call("set_state", None if x is None else _dp(x), None if v is None else _dp(v))
 
     def kinetic_energy(self):
-        ke = np.empty(self.n_replicas)
-        self._call("kinetic_energy", _dp(ke))
-        return ke
+        memo = self.__dict__.setdefault("_memo", {})
+        if "ke" not in memo:         # several reporters ask at the same step: one device reduction serves them all
+            ke = np.empty(self.n_replicas)
+            self._call("kinetic_energy", _dp(ke))
+            memo["ke"] = ke
+        return memo["ke"].copy()
 
     def compute_virtual_sites(self):
         self._call("compute_virtual_sites")
@@ -272,9 +280,13 @@ class Context:
 
     # ---- evaluation
     def energy(self, group_mask=0xFFFFFFFF):
-        e = np.empty(self.n_replicas)
-        self._call("energy", C.c_uint32(group_mask & 0xFFFFFFFF), _dp(e))
-        return e
+        memo = self.__dict__.setdefault("_memo", {})
+        key = ("e", group_mask & 0xFFFFFFFF)
+        if key not in memo:
+            e = np.empty(self.n_replicas)
+            self._call("energy", C.c_uint32(group_mask & 0xFFFFFFFF), _dp(e))
+            memo[key] = e
+        return memo[key].copy()
 
     def energy_by_group(self):
         e = np.empty((self.n_replicas, 32))
