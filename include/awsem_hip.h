@@ -142,6 +142,23 @@ int awsem_add_debye_huckel(awsem_handle h, int group, int n, const int32_t* pair
 int awsem_add_gaussian_bonds(awsem_handle h, int group, int n, const int32_t* pairs, const double* r0,
                              const double* sigma, const double* kgamma);
 
+/* A sum over bonds S = sum_b g_b(r_b) and an energy E = f(S): OpenMM's CustomBondForce, alone or as the one
+ * collective variable of a CustomCVForce.
+ *   bond_kind AWSEM_BOND_GAUSS: g = coef exp(-(r - r0)^2 / (2 sigma^2))     AWSEM_BOND_R2: g = coef r^2 (r0, sigma unused)
+ *   cv_kind   AWSEM_CV_SUM:          E = S                 q_value biasTerms.py:146-188, qc_value :191-223, partial_q_value :226-267
+ *             AWSEM_CV_HARMONIC:     E = cv_k/2 (S-x0)^2   qbias_term biasTerms.py:270-302 ("0.5*k_qbias*(q-q0)^2")
+ *             AWSEM_CV_SQRT:         E = cv_k sqrt(S)      rg_term biasTerms.py:461-486 ("unit*rg_square^0.5")
+ *             AWSEM_CV_SQRT_SQUARE:  E = cv_k (sqrt(S)-x0)^2   rg_bias_term biasTerms.py:489-528
+ * Collective-variable kinds are available on the replica-resident path only. */
+#define AWSEM_BOND_GAUSS 0
+#define AWSEM_BOND_R2 1
+#define AWSEM_CV_SUM 0
+#define AWSEM_CV_HARMONIC 1
+#define AWSEM_CV_SQRT 2
+#define AWSEM_CV_SQRT_SQUARE 3
+int awsem_add_bond_sum(awsem_handle h, int group, int bond_kind, int n, const int32_t* pairs, const double* r0,
+                       const double* sigma, const double* coef, int cv_kind, double cv_k, double cv_x0);
+
 /* Uploads tables and index arrays to the device; no add_* / set_masses / set_virtual_sites afterwards.
  * Replaces Simulation(topology, system, integrator, platform) -> Context creation (scripts/mm_run.py:148). */
 int awsem_finalize(awsem_handle h);

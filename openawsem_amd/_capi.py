@@ -39,6 +39,7 @@ _SIGNATURES = {
     "add_membrane": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double, C.c_double, C.c_double]),
     "add_debye_huckel": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double]),
     "add_gaussian_bonds": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p]),
+    "add_bond_sum": (C.c_int, ["H", C.c_int, C.c_int, C.c_int, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p, C.c_int, C.c_double, C.c_double]),
     "finalize": (C.c_int, ["H"]),
     "set_positions": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_int]),
     "get_positions": (C.c_int, ["H", C.c_int, c_dbl_p, C.c_int]),
@@ -224,6 +225,14 @@ class Context:
     def add_gaussian_bonds(self, group, pairs, r0, sigma, kgamma):
         p, a, b, c = _i32(pairs).reshape(-1), _f64(r0), _f64(sigma), _f64(kgamma)
         self._call("add_gaussian_bonds", group, len(a), _ip(p), _dp(a), _dp(b), _dp(c))
+
+    def add_bond_sum(self, group, bond_kind, pairs, r0, sigma, coef, cv_kind=0, cv_k=0.0, cv_x0=0.0):
+        """S = sum of coef*exp(-(r-r0)^2/(2 sigma^2)) (bond_kind 0) or coef*r^2 (1); E = S, k/2 (S-x0)^2, k sqrt(S) or
+        k (sqrt(S)-x0)^2 for cv_kind 0..3 (include/awsem_hip.h: awsem_add_bond_sum)."""
+        p, c = _i32(pairs).reshape(-1), _f64(coef)
+        a = None if r0 is None else _f64(r0)
+        b = None if sigma is None else _f64(sigma)
+        self._call("add_bond_sum", group, int(bond_kind), len(c), _ip(p), _dp(a), _dp(b), _dp(c), int(cv_kind), float(cv_k), float(cv_x0))
 
     def finalize(self):
         self._call("finalize")

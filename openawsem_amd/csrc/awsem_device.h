@@ -23,7 +23,7 @@
 #define AWSEM_MAX_FM 2
 #define AWSEM_MAX_MEMB 2
 #define AWSEM_MAX_DH 2
-#define AWSEM_MAX_GAUSS 2
+#define AWSEM_MAX_GAUSS 16
 #define AWSEM_FIXED_SCALE 4294967296.0   // 2^32: forces, energies and densities are accumulated as int64 fixed point
 #define AWSEM_MAX_LISTS (AWSEM_MAX_EXCL + AWSEM_MAX_CONTACT + AWSEM_MAX_BETA + AWSEM_MAX_PAP)
 
@@ -36,7 +36,7 @@ struct ListSlot { int list_off, list_cap, list_id; };
 template <class real> struct HarmItem { int i, j; real r0, k; };
 template <class real> struct HelicalItem { int o, n, h; real coef; };
 template <class real> struct DhItem { int i, j; real qq, pad; };
-template <class real> struct GaussItem { int i, j; real r0, a, c; };   // a = 1/(2 sigma^2), c = k gamma
+template <class real> struct GaussItem { int i, j; real r0, a, c; };   // a = 1/(2 sigma^2), c = k gamma (bond value g = -c exp(-a (r-r0)^2), or c r^2)
 template <class real> struct MembItem { int atom; real scale; };
 template <class real> struct alignas(16) MassiveItem { int atom; real inv_mass, sqrt_inv_mass, pad; };
 // the virtual sites a massive particle parents (-1 padded) and its weight in each: the step kernel gathers their forces
@@ -106,7 +106,11 @@ template <class real> struct HelicalD { int group, n; const HelicalItem<real>* i
 template <class real> struct FmD { int group, n, ntab; const unsigned* pairs; const int* pairs2; const real2_t<real>* table2; real k, dr, inv_dr; };
 template <class real> struct MembD { int group, n; const MembItem<real>* items; real k, k_m2, z_m, center; };
 template <class real> struct DhD { int group, n; const DhItem<real>* items; real k, inv_lam; };
-template <class real> struct GaussD { int group, n; const GaussItem<real>* items; };
+// A sum of bond values S = sum_b g_b(r_b) and an energy E = f(S):
+//   kind 0: g = -c exp(-a (r - r0)^2)   kind 1: g = c r^2
+//   cv 0: E = S (plain bond force)   1: E = k/2 (S - x0)^2   2: E = k sqrt(S)   3: E = k (sqrt(S) - x0)^2
+// cv != 0 is OpenMM's CustomCVForce over one CustomBondForce; S is summed in LDS accumulator `slot` first.
+template <class real> struct GaussD { int group, n; const GaussItem<real>* items; int kind, cv, slot, pad; real cv_k, cv_x0; };
 
 template <class real> struct DevSys {
     int natoms;
@@ -124,7 +128,10 @@ template <class real> struct DevSys {
     HarmD<real> harm[AWSEM_MAX_HARM]; ChiD<real> chi[AWSEM_MAX_CHI]; RamaD<real> rama[AWSEM_MAX_RAMA];
     ExclD<real> excl[AWSEM_MAX_EXCL]; ContactD<real> contact[AWSEM_MAX_CONTACT]; BetaD<real> beta[AWSEM_MAX_BETA];
     PapD<real> pap[AWSEM_MAX_PAP]; HelicalD<real> helical[AWSEM_MAX_HELICAL]; FmD<real> fm[AWSEM_MAX_FM];
-    MembD<real> memb[AWSEM_MAX_MEMB]; DhD<real> dh[AWSEM_MAX_DH]; GaussD<real> gauss[AWSEM_MAX_GAUSS];
+    MembD<real> memb[AWSEM_MAX_MEMB]; DhD<real> dh[AWSEM_MAX_DH];
+    const GaussD<real>* gauss;            // n_gauss descriptors in device memory (read with scalar loads): bond sums come in any number,
+                                          // and run-time indexing of a large array inside the by-value block sends it to scratch
+    int n_cv;                             // Gaussian-bond terms with cv != 0 (each owns one LDS accumulator)
     int max_contact_sites;                // LDS scratch sizing
     int any_zdep;
     unsigned* lists;                      // [n_replicas][list_stride] pair-list entries

@@ -56,7 +56,7 @@ struct HHelical { int group; std::vector<int> atoms; std::vector<double> coef; d
 struct HFm { int group, ntab; std::vector<int> pairs; std::vector<double> table; double k, dr; };
 struct HMemb { int group; std::vector<int> atoms; std::vector<double> scale; double k, k_m, z_m, center; };
 struct HDh { int group; std::vector<int> pairs; std::vector<double> qq; double k, lam; };
-struct HGauss { int group; std::vector<int> pairs; std::vector<double> r0, sigma, kg; };
+struct HGauss { int group; std::vector<int> pairs; std::vector<double> r0, sigma, kg; int kind = 0, cv = 0; double cv_k = 0, cv_x0 = 0; };
 
 struct HostSystem {
     int natoms = 0;
@@ -349,6 +349,7 @@ private:
     int* dmin_it_ = nullptr;
     double* dmin_rms_ = nullptr;
     unsigned* dcounts_ = nullptr;
+    std::vector<GaussD<real>> hgauss_;   // host copy of the bond-sum descriptors (DevSys::gauss points to device memory)
     double skin_ = 0.2;    // nm; AWSEM_SKIN overrides (0.15-0.3 measured: 0.2 and above rebuild rarely enough on the hot, extended stage of an annealing run)
     size_t lds_list_ = 0, lds_max_ = 0;
     bool step_ok_ = false;
@@ -454,7 +455,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         const char* force = getenv("AWSEM_FORCE_CELL");
         bool zdep = false;
         for (auto& h : H.contact) zdep = zdep || (h.flags & AWSEM_CONTACT_ZDEP);
-        cell_mode_ = lds_bytes<real>(LdsShape{natoms_, max_sites, (int)H.contact.size(), 0, zdep ? 2400 : 1200}, false) > lds_max || (force && atoi(force) != 0);
+        cell_mode_ = lds_bytes<real>(LdsShape{natoms_, max_sites, (int)H.contact.size(), 0, zdep ? 2400 : 1200, 0}, false) > lds_max || (force && atoi(force) != 0);
     }
     // Item order of the static lists.  Replica-resident path: conflict-aware (spread_order).  Cell-list path: by window of
     // AWSEM_WIN atoms (the window kernel accumulates a window's items in LDS); items spanning more than a window's LDS
@@ -741,19 +742,24 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         if (D.size() > AWSEM_MAX_DH) throw std::string("too many dh terms: at most " + std::to_string(AWSEM_MAX_DH) + " per system");
         S.n_dh = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.dh[t] = D[t];
     }
-    {   // Gaussian-well bonds (pairs anywhere in the system, like Debye-Hueckel: never window-local on the cell-list path)
+    {   // bond sums (pairs anywhere in the system, like Debye-Hueckel: never window-local on the cell-list path)
         std::vector<GaussD<real>> D;
+        int ncv = 0;
         for (auto& h : H.gauss) {
-            std::vector<GaussItem<real>> it(h.r0.size());
+            std::vector<GaussItem<real>> it(h.kg.size());
             const std::vector<int> perm = spread_order((int)it.size(), 2, h.pairs.data(), natoms_);
             for (size_t b = 0; b < it.size(); b++) {
                 const int o = perm[b];
-                it[b] = GaussItem<real>{h.pairs[2 * o], h.pairs[2 * o + 1], (real)h.r0[o], (real)(0.5 / (h.sigma[o] * h.sigma[o])), (real)h.kg[o]};
+                it[b] = GaussItem<real>{h.pairs[2 * o], h.pairs[2 * o + 1], (real)(h.kind ? 0.0 : h.r0[o]),
+                                        (real)(h.kind ? 0.0 : 0.5 / (h.sigma[o] * h.sigma[o])), (real)h.kg[o]};
             }
-            D.push_back(GaussD<real>{h.group, (int)it.size(), upload(it)});
+            if (h.cv && cell_mode_) throw std::string("collective-variable terms (qbias_term, rg_term, ...) are not available on the cell-list path");
+            D.push_back(GaussD<real>{h.group, (int)it.size(), upload(it), h.kind, h.cv, h.cv ? ncv++ : 0, 0, (real)h.cv_k, (real)h.cv_x0});
         }
-        if (D.size() > AWSEM_MAX_GAUSS) throw std::string("too many Gaussian-bond terms: at most " + std::to_string(AWSEM_MAX_GAUSS) + " per system");
-        S.n_gauss = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.gauss[t] = D[t];
+        if (D.size() > AWSEM_MAX_GAUSS) throw std::string("too many bond-sum terms (Gaussian bonds, Q, Rg): at most " + std::to_string(AWSEM_MAX_GAUSS) + " per system");
+        S.n_gauss = (int)D.size(); S.gauss = D.empty() ? nullptr : upload(D);
+        hgauss_.assign(D.begin(), D.end());
+        S.n_cv = ncv;
     }
     // pair lists: one slot per pair term, capacity = number of candidate pairs (cannot overflow)
     if (const char* env = getenv("AWSEM_SKIN")) {
@@ -956,7 +962,7 @@ template <class real> void Engine<real>::cell_setup(DevSys<real>& S, const HostS
     for (int t = 0; t < S.n_fm; t++) add(CJ_FM, t, S.fm[t].n, true);
     for (int t = 0; t < S.n_memb; t++) add(CJ_MEMB, t, S.memb[t].n, true);
     for (int t = 0; t < S.n_dh; t++) add(CJ_DH, t, S.dh[t].n, false);
-    for (int t = 0; t < S.n_gauss; t++) add(CJ_GAUSS, t, S.gauss[t].n, false);
+    for (int t = 0; t < S.n_gauss; t++) add(CJ_GAUSS, t, hgauss_[t].n, false);
     cell_nslots_ = slot;
     cell_nwin_ = (natoms_ + AWSEM_WIN - 1) / AWSEM_WIN;
     if ((size_t)cell_nslots_ * (cell_nwin_ + 1) != cell_wstart_.size()) throw std::string("internal error: window tables out of step with the bonded terms");
@@ -1350,6 +1356,18 @@ int awsem_add_gaussian_bonds(awsem_handle h, int group, int n, const int32_t* pa
     if (n < 0 || (n && (!pairs || !r0 || !sigma || !kgamma)) || !atoms_ok(h, pairs, 2 * (size_t)n)) return fail(AWSEM_EINVAL, "add_gaussian_bonds: bad arguments");
     for (int b = 0; b < n; b++) if (!(sigma[b] > 0)) return fail(AWSEM_EINVAL, "add_gaussian_bonds: sigma must be positive");
     h->H.gauss.push_back(HGauss{group, vec(pairs, 2 * (size_t)n), vec(r0, n), vec(sigma, n), vec(kgamma, n)});
+    return AWSEM_OK;
+}
+int awsem_add_bond_sum(awsem_handle h, int group, int bond_kind, int n, const int32_t* pairs, const double* r0, const double* sigma,
+                       const double* coef, int cv_kind, double cv_k, double cv_x0) {
+    NEED_BUILD(h, group);
+    if (bond_kind < 0 || bond_kind > 1 || cv_kind < 0 || cv_kind > 3) return fail(AWSEM_EINVAL, "add_bond_sum: unknown bond or collective-variable kind");
+    if (n < 0 || (n && (!pairs || !coef || (bond_kind == 0 && (!r0 || !sigma)))) || !atoms_ok(h, pairs, 2 * (size_t)n)) return fail(AWSEM_EINVAL, "add_bond_sum: bad arguments");
+    for (int b = 0; b < n && bond_kind == 0; b++) if (!(sigma[b] > 0)) return fail(AWSEM_EINVAL, "add_bond_sum: sigma must be positive");
+    HGauss g{group, vec(pairs, 2 * (size_t)n), bond_kind == 0 ? vec(r0, n) : std::vector<double>(), bond_kind == 0 ? vec(sigma, n) : std::vector<double>(), vec(coef, n)};
+    if (bond_kind == 0) for (auto& c : g.kg) c = -c;   // stored as E = -c exp(...), the sign convention of awsem_add_gaussian_bonds
+    g.kind = bond_kind; g.cv = cv_kind; g.cv_k = cv_k; g.cv_x0 = cv_x0;
+    h->H.gauss.push_back(std::move(g));
     return AWSEM_OK;
 }
 int awsem_finalize(awsem_handle h) {

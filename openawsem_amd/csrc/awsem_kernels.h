@@ -99,6 +99,7 @@ template <class real> struct ViewCommon {
     real *alpha, *dalpha;    // z-dependent membrane switch
     real* gamma;             // gamma tables of the current contact term (env-major)
     u64* eg;                 // per-group energies (fixed point)
+    u64* cv;                 // sums of the collective-variable terms (fixed point), DevSys::n_cv of them
     int* satom;              // contact site -> atom, [contact term][max_contact_sites]
     unsigned* lcount;        // pair-list entry counts, one per list
     unsigned* flag;          // [2]: largest squared displacement since the last list build (float bits), double buffered
@@ -417,19 +418,65 @@ template <bool ENERGY, class V> __device__ void term_dh(const DhD<typename V::re
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-// Gaussian-well bonds: er_term templateTerms.py:643-693, additive_amhgo_term templateTerms.py:600-640 (CustomBondForce)
-template <bool ENERGY, class V> __device__ void term_gauss(const GaussD<typename V::real_t>& d, const V& L, int rot = 0) {
+// Bond sums: er_term templateTerms.py:643-693, additive_amhgo_term :600-640, q_value biasTerms.py:146-188 (CustomBondForce)
+// and the CustomCVForce wrappers over one: qbias_term biasTerms.py:270-302, rg_term :461-486, rg_bias_term :489-528.
+// bond_value: g and s = -(dg/dr)/r of one bond.
+template <class real> __device__ __forceinline__ void bond_value(const GaussD<real>& d, const GaussItem<real>& it, const R3<real>& dd, real& g, real& s) {
+    const real r2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z;
+    if (d.kind == 1) { g = it.c * r2; s = (real)-2 * it.c; return; }
+    const real ir = M<real>::rsqrt(r2), dr = r2 * ir - it.r0;
+    g = -it.c * M<real>::exp(-it.a * dr * dr);
+    s = (real)2 * it.a * dr * g * ir;   // dg/dr = -2 a dr g
+}
+template <bool ENERGY, class V> __device__ __forceinline__ void term_gauss(const GaussD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
         const GaussItem<real> it = d.items[b];
         const R3<real> dd = L.pos(it.i) - L.pos(it.j);
-        const real r2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z, ir = M<real>::rsqrt(r2), dr = r2 * ir - it.r0;
-        const real E = -it.c * M<real>::exp(-it.a * dr * dr);
-        if (ENERGY) e += (double)E;
-        L.pair_force(it.i, it.j, dd.x, dd.y, dd.z, (real)2 * it.a * dr * E * ir);   // -dE/dr / r, dE/dr = -2 a dr E
+        real g, s;
+        bond_value(d, it, dd, g, s);
+        if (ENERGY) e += (double)g;
+        L.pair_force(it.i, it.j, dd.x, dd.y, dd.z, s);
     }
     flush_energy<ENERGY>(L, d.group, e);
+}
+// first pass of a collective-variable term: S into L.cv[d.slot] (zero on entry; fixed point, so order-independent).
+// 2^-48 resolution (|S| < 32768): the 2^-32 of the energy accumulators would round the ~10^4 nearly equal bonds of a
+// native structure coherently and shift Q by 2e-7, which a stiff umbrella turns into 1e-5 kJ/mol.
+#define AWSEM_CV_SCALE 281474976710656.0
+template <class V> __device__ __forceinline__ void cv_sum(const GaussD<typename V::real_t>& d, const V& L, int rot = 0) {
+    typedef typename V::real_t real;
+    u64 t = 0;
+    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
+        const GaussItem<real> it = d.items[b];
+        real g, s;
+        bond_value(d, it, L.pos(it.i) - L.pos(it.j), g, s);
+        t += (u64)__double2ll_rn((double)g * AWSEM_CV_SCALE);
+    }
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+    if ((threadIdx.x & 63) == 0 && t != 0) fixed_add(&L.cv[d.slot], t);
+}
+// second pass (after a barrier): E = f(S) once, forces f'(S) * (-dg/dr) along every bond
+template <bool ENERGY, class V> __device__ __forceinline__ void cv_apply(const GaussD<typename V::real_t>& d, const V& L, int rot = 0) {
+    typedef typename V::real_t real;
+    const double S = (double)(long long)L.cv[d.slot] * (1.0 / AWSEM_CV_SCALE), k = (double)d.cv_k, x0 = (double)d.cv_x0;
+    double E, fp;
+    if (d.cv == 1) { E = 0.5 * k * (S - x0) * (S - x0); fp = k * (S - x0); }
+    else {
+        const double q = S > 0 ? ::sqrt(S) : 0.0, iq = q > 0 ? 1.0 / q : 0.0;
+        if (d.cv == 2) { E = k * q; fp = 0.5 * k * iq; }
+        else { E = k * (q - x0) * (q - x0); fp = k * (q - x0) * iq; }
+    }
+    if (ENERGY && threadIdx.x == 0) fixed_add(&L.eg[d.group], (u64)__double2ll_rn(E * AWSEM_FIXED_SCALE));
+    const real fpr = (real)fp;
+    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
+        const GaussItem<real> it = d.items[b];
+        const R3<real> dd = L.pos(it.i) - L.pos(it.j);
+        real g, s;
+        bond_value(d, it, dd, g, s);
+        L.pair_force(it.i, it.j, dd.x, dd.y, dd.z, fpr * s);
+    }
 }
 
 // ------------------------------------------------------------------ Verlet pair lists
@@ -858,7 +905,7 @@ template <bool ENERGY, class V> __device__ void eval_pap(const PapD<typename V::
 }
 
 // ------------------------------------------------------------------ virtual sites, whole-system evaluation
-template <class V> __device__ void compute_virtual_sites(const DevSys<typename V::real_t>& S, const V& L) {
+template <class V> __device__ __forceinline__ void compute_virtual_sites(const DevSys<typename V::real_t>& S, const V& L) {
     typedef typename V::real_t real;
     for (int i = threadIdx.x; i < S.nvs; i += blockDim.x) {
         const Int4 v = S.vs[i];
@@ -869,7 +916,7 @@ template <class V> __device__ void compute_virtual_sites(const DevSys<typename V
 }
 // fold the force on each virtual site onto its three parents (ThreeParticleAverageSite chain rule); evaluation API
 // only -- the step kernel gathers instead (every massive atom collects from the sites it parents, no atomics)
-template <class V> __device__ void redistribute_forces(const DevSys<typename V::real_t>& S, const V& L) {
+template <class V> __device__ __forceinline__ void redistribute_forces(const DevSys<typename V::real_t>& S, const V& L) {
     typedef typename V::real_t real;
     for (int i = threadIdx.x; i < S.nvs; i += blockDim.x) {
         const Int4 v = S.vs[i];
@@ -890,7 +937,7 @@ template <class V> __device__ void stage_contact_gamma(const ContactD<typename V
     const real* src = d.gamma + ((d.flags & 1) ? 0 : d.env * 1200);
     for (int i = threadIdx.x; i < ng; i += blockDim.x) L.gamma[i] = src[i];
 }
-template <class V> __device__ void stage_tables(const DevSys<typename V::real_t>& S, const V& L) {
+template <class V> __device__ __forceinline__ void stage_tables(const DevSys<typename V::real_t>& S, const V& L) {
     for (int t = 0; t < S.n_contact; t++)
         for (int i = threadIdx.x; i < S.contact[t].nsites; i += blockDim.x) L.satom[t * S.max_contact_sites + i] = S.contact[t].atom[i];
     if (S.n_contact == 1) stage_contact_gamma(S.contact[0], L);
@@ -899,7 +946,7 @@ template <class V> __device__ void stage_tables(const DevSys<typename V::real_t>
 #define AWSEM_ON(d) ((mask >> (d).group) & 1u)
 // (Re)build the pair list of every pair term in `mask` from the current positions.  The caller zeroes L.lcount
 // before (and synchronises), and synchronises after.
-template <class V> __device__ void build_lists(const DevSys<typename V::real_t>& S, const V& L, unsigned mask) {
+template <class V> __device__ __forceinline__ void build_lists(const DevSys<typename V::real_t>& S, const V& L, unsigned mask) {
     for (int t = 0; t < S.n_contact; t++) if (AWSEM_ON(S.contact[t])) build_contact(S.contact[t], L, L.satom + t * S.max_contact_sites, S.status);
     for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) build_excl(S.excl[t], L, S.status);
     for (int t = 0; t < S.n_beta; t++) if (AWSEM_ON(S.beta[t])) build_hbond(S.beta[t], L, S.status);
@@ -910,15 +957,18 @@ template <class V> __device__ void build_lists(const DevSys<typename V::real_t>&
 // Evaluate every term whose group is in `mask` from the current pair lists.  Forces accumulate into the view and the
 // density of the first contact term into L.rho: both zeroed by the caller and visible (call after a __syncthreads());
 // ends with all contributions visible to the workgroup.
+// Everything that takes the descriptor block by reference is force-inlined: an out-of-line call would need its
+// address, and the compiler then copies the whole by-value kernarg block to scratch (2.7 KB per lane, half the speed).
 // The contact passes need workgroup barriers between them, which cuts the evaluation into four phases; every other
 // term is issued in one of the phases so that each phase keeps all waves busy.
-template <bool ENERGY, class V> __device__ void evaluate_terms(const DevSys<typename V::real_t>& S, const V& L, unsigned mask AWSEM_STAMP_ARG) {
+template <bool ENERGY, class V> __device__ __forceinline__ void evaluate_terms(const DevSys<typename V::real_t>& S, const V& L, unsigned mask AWSEM_STAMP_ARG) {
     typedef typename V::real_t real;
     int first = -1;   // the contact term whose passes define the phases
     for (int t = S.n_contact - 1; t >= 0; t--) if (AWSEM_ON(S.contact[t])) first = t;
     const ContactD<real>* c0 = first >= 0 ? &S.contact[first] : nullptr;
     const int* satom0 = L.satom + (first >= 0 ? first : 0) * S.max_contact_sites;
     const bool multi = S.n_contact > 1;
+    const bool bar = c0 || S.n_cv > 0;   // the phases need barriers: contact passes, or a collective variable's sum before its forces
     if (c0 && multi) { stage_contact_gamma(*c0, L); __syncthreads(); }
     Rotor rotor;
     // phase A
@@ -926,22 +976,29 @@ template <bool ENERGY, class V> __device__ void evaluate_terms(const DevSys<type
     for (int u = 0; u < S.n_fm; u++) if (AWSEM_ON(S.fm[u])) term_fm<ENERGY>(S.fm[u], L, rotor.next(S.fm[u].n));
     for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
     for (int u = 0; u < S.n_chi; u++) if (AWSEM_ON(S.chi[u])) term_chi<ENERGY>(S.chi[u], L, rotor.next(S.chi[u].n));
-    if (c0) __syncthreads();
+    for (int u = 0; u < S.n_gauss; u++) { const GaussD<real> d = S.gauss[u]; if (d.cv && AWSEM_ON(d)) cv_sum(d, L, rotor.next(d.n)); }
+    if (bar) __syncthreads();
     AWSEM_STAMP(S, 4);
     // phase B
     rotor.acc = 0;
     if (c0) contact_single<ENERGY>(*c0, L, satom0, rotor.next(c0->nsites));
     for (int u = 0; u < S.n_harm; u++) if (AWSEM_ON(S.harm[u])) term_harmonic<ENERGY>(S.harm[u], L, rotor.next(S.harm[u].n));
     for (int u = 0; u < S.n_dh; u++) if (AWSEM_ON(S.dh[u])) term_dh<ENERGY>(S.dh[u], L, rotor.next(S.dh[u].n));
-    for (int u = 0; u < S.n_gauss; u++) if (AWSEM_ON(S.gauss[u])) term_gauss<ENERGY>(S.gauss[u], L, rotor.next(S.gauss[u].n));
+    for (int u = 0; u < S.n_gauss; u++) {
+        const GaussD<real> d = S.gauss[u];   // uniform: scalar loads
+        if (!AWSEM_ON(d)) continue;
+        if (d.cv) cv_apply<ENERGY>(d, L, rotor.next(d.n));
+        else term_gauss<ENERGY>(d, L, rotor.next(d.n));
+    }
     for (int u = 0; u < S.n_helical; u++) if (AWSEM_ON(S.helical[u])) term_helical<ENERGY>(S.helical[u], L, rotor.next(S.helical[u].n));
     for (int u = 0; u < S.n_memb; u++) if (AWSEM_ON(S.memb[u])) term_memb<ENERGY>(S.memb[u], L, rotor.next(S.memb[u].n));
-    if (c0) __syncthreads();
+    if (bar) __syncthreads();
     AWSEM_STAMP(S, 5);
     // phase C
+    if (threadIdx.x < S.n_cv) L.cv[threadIdx.x] = 0;   // read for the last time in phase B; the next evaluation starts from zero
     if (c0 && !(c0->flags & 2)) contact_pairs<ENERGY>(*c0, L, satom0);
     for (int u = 0; u < S.n_beta; u++) if (AWSEM_ON(S.beta[u])) eval_beta<ENERGY>(S.beta[u], L);
-    if (c0) __syncthreads();
+    if (bar) __syncthreads();
     AWSEM_STAMP(S, 6);
     // phase D
     if (c0) contact_chain_rule(*c0, L, satom0);
@@ -974,9 +1031,9 @@ template <> struct LdsLayout<float> { static constexpr int pos = 16, force = 16,
 template <> struct LdsLayout<double> { static constexpr int pos = 24, force = 24, vel = 24, ref = 24; };     // three 8-byte planes each
 // what sizes the LDS image of a replica: velocities exist for the massive particles only (indexed by their position in
 // DevSys::massive), the gamma staging holds one environment (1200) or both (2400, z-dependent contact)
-struct LdsShape { int natoms, nsites, ncontact, nmassive, ngamma; };
+struct LdsShape { int natoms, nsites, ncontact, nmassive, ngamma, ncv; };
 template <class real> __host__ __device__ inline LdsShape lds_shape(const DevSys<real>& S) {
-    return LdsShape{S.natoms, S.max_contact_sites, S.n_contact, S.nmassive, S.any_zdep ? 2400 : 1200};
+    return LdsShape{S.natoms, S.max_contact_sites, S.n_contact, S.nmassive, S.any_zdep ? 2400 : 1200, S.n_cv};
 }
 template <class real> __host__ __device__ inline size_t lds_bytes(const LdsShape& sh, bool with_vel) {
     const int natoms = sh.natoms, nsites = sh.nsites, ncontact = sh.ncontact;
@@ -984,7 +1041,7 @@ template <class real> __host__ __device__ inline size_t lds_bytes(const LdsShape
     size_t b = 0;
     b += (size_t)natoms * (Y::pos + Y::force + (with_vel ? Y::ref : 0)) + (with_vel ? (size_t)sh.nmassive * Y::vel : 0);
     b += (size_t)2 * nsites * sizeof(u64);            // rho, drho
-    b += AWSEM_NGROUPS * sizeof(u64);                 // group energies
+    b += (AWSEM_NGROUPS + (size_t)sh.ncv) * sizeof(u64);   // group energies, collective-variable sums
     b += (size_t)3 * nsites * sizeof(real);           // rhov, alpha, dalpha
     b += (size_t)sh.ngamma * sizeof(real);            // gamma staging
     b += (size_t)(ncontact > 0 ? ncontact : 1) * nsites * sizeof(int);   // contact site -> atom
@@ -996,6 +1053,8 @@ template <class real> __device__ inline void carve_common(ViewCommon<real>& L, u
     u64* w = (u64*)q;
     L.rho = w; w += nsites; L.drho = w; w += nsites;
     L.eg = w; w += AWSEM_NGROUPS;
+    L.cv = w; w += sh.ncv;
+    if ((int)threadIdx.x < sh.ncv) L.cv[threadIdx.x] = 0;   // every kernel has a barrier between the carve-up and its first evaluation
     real* r = (real*)w;
     L.rhov = r; r += nsites; L.alpha = r; r += nsites; L.dalpha = r; r += nsites;
     L.gamma = r; r += sh.ngamma;

@@ -163,11 +163,7 @@ class Context:
         api = _capi.load_hip_library()
         self._ctx = _capi.Context(api, system.getNumParticles(), self.n_replicas, self.platform.device,
                                   1 if self.platform.properties.get("Precision") == "double" else 0)
-        self._host_forces = [f for f in system.forces if getattr(f, "host_only", False)]
-        gpu_system = System(system.masses.copy())
-        gpu_system.virtual_sites = dict(system.virtual_sites)
-        gpu_system.forces = [f for f in system.forces if not getattr(f, "host_only", False)]
-        gpu_system.upload(self._ctx)
+        system.upload(self._ctx)
         self.temperatures = None        # per-replica override of the integrator temperature
         self._time_ps = 0.0
         self._have_positions = False
@@ -200,18 +196,10 @@ class Context:
     # ---- queries
     def energies(self, groups=-1):
         """Potential energy of every replica (kJ/mol) for the given force groups."""
-        mask = _group_mask(groups)
-        e = self._ctx.energy(mask)
-        for f in self._host_forces:
-            if (mask >> f.getForceGroup()) & 1:
-                e = e + np.array([f.host_energy(self._ctx.get_positions(r)) for r in range(self.n_replicas)])
-        return e
+        return self._ctx.energy(_group_mask(groups))
 
     def energiesByGroup(self):
-        e = self._ctx.energy_by_group()
-        for f in self._host_forces:
-            e[:, f.getForceGroup()] += [f.host_energy(self._ctx.get_positions(r)) for r in range(self.n_replicas)]
-        return e
+        return self._ctx.energy_by_group()
 
     def kineticEnergies(self):
         return self._ctx.kinetic_energy()   # reduced on the device: one value per replica
@@ -246,9 +234,6 @@ class Context:
         if isinstance(integ, CustomIntegrator):
             self._ctx.step_count = self._ctx.step_count + n
         else:
-            if self._host_forces:
-                raise NotImplementedError("the system contains analysis-only order parameters (q_value / rg_term); "
-                                          "they cannot bias a dynamics run on the MI355X engine")
             T = self.temperatures if self.temperatures is not None else integ._T
             self._ctx.step(n, T, integ._dt, integ._friction, integ._seed)
         self._time_ps += n * _value(integ.getStepSize(), u.picosecond)

@@ -303,6 +303,42 @@ class GaussianBondForce(Force):
                                self.k * np.asarray(self.gamma, dtype=np.float64))
 
 
+class BondSumForce(Force):
+    """A CustomBondForce sum S = sum_b g_b(r_b), alone or as the collective variable of a CustomCVForce E = f(S)
+    (biasTerms.py: q_value 146-188, qc_value 191-223, partial_q_value 226-267, qbias_term 270-302, rg_term 461-486,
+    rg_bias_term 489-528).  bond_kind "gauss": g = coef exp(-(r-r0)^2/(2 sigma^2)); "r2": g = coef r^2.
+    cv: "sum" E = S; "harmonic" E = k/2 (S-x0)^2; "sqrt" E = k sqrt(S); "sqrt_square" E = k (sqrt(S)-x0)^2."""
+    kind = "bond_sum"
+    BOND = {"gauss": 0, "r2": 1}
+    CV = {"sum": 0, "harmonic": 1, "sqrt": 2, "sqrt_square": 3}
+
+    def __init__(self, bond_kind="gauss", cv="sum", k=0.0, x0=0.0, group=0):
+        super().__init__(group)
+        self.bond_kind, self.cv, self.k, self.x0 = bond_kind, cv, float(k), float(x0)
+        self.pairs, self.coef, self.r0, self.sigma = [], [], [], []
+
+    def addBond(self, i, j, params=()):
+        """params = [coef, r0, sigma] for Gaussian bonds (the reference's [gamma_ij, r_ijN, sigma_ij]), [coef] or [] for r^2."""
+        from . import unit as u
+        self.pairs.append((int(i), int(j)))
+        self.coef.append(float(params[0]) if len(params) else 1.0)
+        if self.bond_kind == "gauss":
+            r0 = params[1]
+            self.r0.append(float(r0.value_in_unit(u.nanometer) if hasattr(r0, "value_in_unit") else r0))
+            self.sigma.append(float(params[2]))
+
+    def getNumBonds(self):
+        return len(self.coef)
+
+    def scale(self, factor):
+        self.coef = [c * factor for c in self.coef]
+
+    def _upload(self, ctx):
+        gauss = self.bond_kind == "gauss"
+        ctx.add_bond_sum(self._group, self.BOND[self.bond_kind], np.array(self.pairs, dtype=np.int32).reshape(-1, 2),
+                         self.r0 if gauss else None, self.sigma if gauss else None, self.coef, self.CV[self.cv], self.k, self.x0)
+
+
 class System:
     """Light stand-in for openmm.System: particle masses, virtual sites and the list of forces."""
 

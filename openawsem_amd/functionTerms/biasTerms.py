@@ -1,56 +1,18 @@
-"""Order parameters used by awsem_analyze: Q (fraction of native contacts) and Rg.
+"""Order parameters and the biases built on them: Q (fraction of native contacts), Qc, partial Q, the umbrella bias on Q,
+the radius of gyration and its bias.
 
-Mirrors q_value (openawsem/functionTerms/biasTerms.py:146-188, reference reader :13-87) and rg_term (:461-486).
-In the reference these are OpenMM forces whose "energy" is the order parameter (force groups 1 and 2, printed by
-scripts/mm_analyze.py:139-182).  Here they are analysis-only descriptors evaluated on the host from the
-coordinates the engine returns (`host_only`); they exert no force in MD, so adding one to a system that is then
-stepped raises instead of silently ignoring the bias.
+Mirrors openawsem/functionTerms/biasTerms.py: q_value 146-188 (reader 13-83), qc_value 191-223 and partial_q_value 226-267
+(reader 86-143), qbias_term 270-302, rg_term 461-486, rg_bias_term 489-528.  In the reference these are OpenMM
+CustomBondForce sums, alone or wrapped in a CustomCVForce; here each is one `BondSumForce` descriptor evaluated on the
+device (awsem_add_bond_sum), so the order parameters printed by awsem_analyze are force-group energies exactly as in
+the reference (groups 1 and 2, scripts/mm_analyze.py:139-182) and the biases act in dynamics.
 """
 from __future__ import annotations
 
 import numpy as np
 
 from .. import unit as _u
-from ..forces import Force
-
-
-class HostOnlyForce(Force):
-    host_only = True
-
-    def _upload(self, ctx):
-        raise NotImplementedError(f"{type(self).__name__} is an analysis-only order parameter, not a dynamics term")
-
-    def host_energy(self, x_nm):
-        raise NotImplementedError
-
-
-class QValueForce(HostOnlyForce):
-    kind = "q_value"
-
-    def __init__(self, pairs, r_native, sigma, group=1):
-        super().__init__(group)
-        self.pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
-        self.r_native, self.sigma = np.asarray(r_native, float), np.asarray(sigma, float)
-
-    def host_energy(self, x):
-        if len(self.pairs) == 0:
-            return 0.0
-        r = np.linalg.norm(x[self.pairs[:, 0]] - x[self.pairs[:, 1]], axis=1)
-        return float(np.exp(-(r - self.r_native) ** 2 / (2 * self.sigma ** 2)).sum() / len(self.pairs))
-
-
-class RgForce(HostOnlyForce):
-    kind = "rg"
-
-    def __init__(self, ca, unit=10.0, group=2):
-        super().__init__(group)
-        self.ca, self.unit = np.asarray(ca, dtype=np.int64), float(unit)
-
-    def host_energy(self, x):
-        c = x[self.ca]
-        n = len(c)
-        d2 = ((c[:, None, :] - c[None, :, :]) ** 2).sum(-1)
-        return float(self.unit * np.sqrt(np.triu(d2, 1).sum() / (n * n)))
+from ..forces import BondSumForce
 
 
 def _reference_ca_by_chain(pdb_file):
@@ -70,27 +32,112 @@ def _reference_ca_by_chain(pdb_file):
     return [(cid, np.array(xyz)) for cid, xyz in chains]
 
 
-def q_value(oa, reference_pdb_file, reference_chain_name="ALL", min_seq_sep=3, max_seq_sep=np.inf,
-            contact_threshold=0.95 * _u.nanometers, forceGroup=1):
-    """Canonical Q_w: mean over intra-chain CA pairs with |i-j| >= min_seq_sep (both orders, as the reference's
-    double loop produces them) of exp(-(r - r_native)^2 / (2 sigma_ij^2)), sigma_ij = 0.1 |i-j|^0.15 nm."""
-    pairs, rn, sg = [], [], []
+def _kj(k):
+    return k.value_in_unit(_u.kilojoule_per_mole) if hasattr(k, "value_in_unit") else float(k)
+
+
+def read_reference_structure_for_q_calculation_3(oa, pdb_file, reference_chain_name="ALL", min_seq_sep=3, max_seq_sep=np.inf,
+                                                 contact_threshold=0.95 * _u.nanometers, Qflag=0, a=0.1, removeDNAchains=True):
+    """[atom_i, atom_j, [gamma_ij, r_ijN (nm), sigma_ij]] for the intra-chain CA pairs with min_seq_sep <= |i-j| <= max_seq_sep,
+    in both orders as the reference's double loop produces them; Qflag 1 (Q_o) keeps native contacts below the threshold only.
+    Chains without CA atoms (DNA, ligands) never enter, which is what removeDNAchains does in the reference."""
+    thr = contact_threshold.value_in_unit(_u.nanometer) if hasattr(contact_threshold, "value_in_unit") else float(contact_threshold)
+    out = []
     chain_start = 0
-    for cid, xyz in _reference_ca_by_chain(reference_pdb_file):
+    for cid, xyz in _reference_ca_by_chain(pdb_file):
         n = len(xyz)
         for i in range(n):
             for j in range(n):
                 sep = abs(i - j)
                 if sep >= min_seq_sep and sep <= max_seq_sep:
+                    r = float(np.linalg.norm(xyz[i] - xyz[j]) / 10.0)
+                    if Qflag == 1 and r >= thr:
+                        continue
                     if reference_chain_name != "ALL" and cid not in reference_chain_name:
                         continue
-                    pairs.append((oa.ca[i + chain_start], oa.ca[j + chain_start]))
-                    rn.append(np.linalg.norm(xyz[i] - xyz[j]) / 10.0)
-                    sg.append(0.1 * sep ** 0.15)
+                    out.append([oa.ca[i + chain_start], oa.ca[j + chain_start], [1.0, r, a * sep ** 0.15]])
         chain_start += n
-    return QValueForce(pairs, rn, sg, forceGroup)
+    return out
+
+
+def read_reference_structure_for_qc_calculation(oa, pdb_file, min_seq_sep=3, a=0.1, startResidueIndex=0, endResidueIndex=-1,
+                                                residueIndexGroup=None):
+    """Pairs i < j of the same chain with j - i >= min_seq_sep over the residues of the whole structure (global indices),
+    restricted to [startResidueIndex, endResidueIndex] and to residueIndexGroup when given."""
+    chains = _reference_ca_by_chain(pdb_file)
+    xyz = np.concatenate([c for _, c in chains]) if chains else np.zeros((0, 3))
+    chain_of = np.concatenate([[k] * len(c) for k, (_, c) in enumerate(chains)]) if chains else np.zeros(0, int)
+    n = len(xyz)
+    if endResidueIndex == -1:
+        endResidueIndex = n
+    group = set(range(n)) if residueIndexGroup is None else set(residueIndexGroup)
+    out = []
+    for i in range(n):
+        if i < startResidueIndex or i not in group:
+            continue
+        for j in range(n):
+            if j > endResidueIndex or j not in group:
+                continue
+            if j - i >= min_seq_sep and chain_of[i] == chain_of[j]:
+                out.append([oa.ca[i], oa.ca[j], [1.0, float(np.linalg.norm(xyz[i] - xyz[j]) / 10.0), a * abs(i - j) ** 0.15]])
+    return out
+
+
+def _q_force(interactions, forceGroup, cv="sum", k=0.0, x0=0.0):
+    f = BondSumForce("gauss", cv, k, x0, group=forceGroup)
+    norm = len(interactions)
+    for i, j, (gamma, r, sigma) in interactions:
+        f.addBond(i, j, [gamma / norm, r, sigma])      # "(1/normalization)*gamma_ij*exp(-(r-r_ijN)^2/(2*sigma_ij^2))"
+    return f
+
+
+def q_value(oa, reference_pdb_file, reference_chain_name="ALL", min_seq_sep=3, max_seq_sep=np.inf,
+            contact_threshold=0.95 * _u.nanometers, forceGroup=1):
+    """Canonical Q_w: mean over the listed CA pairs of exp(-(r - r_native)^2 / (2 sigma_ij^2)), sigma_ij = 0.1 |i-j|^0.15 nm."""
+    inter = read_reference_structure_for_q_calculation_3(oa, reference_pdb_file, reference_chain_name=reference_chain_name,
+                                                         min_seq_sep=min_seq_sep, max_seq_sep=max_seq_sep,
+                                                         contact_threshold=contact_threshold, Qflag=0)
+    return _q_force(inter, forceGroup)
+
+
+def qc_value(oa, reference_pdb_file, min_seq_sep=10, a=0.2):
+    return _q_force(read_reference_structure_for_qc_calculation(oa, reference_pdb_file, min_seq_sep=min_seq_sep, a=a), 3)
+
+
+def partial_q_value(oa, reference_pdb_file, min_seq_sep=3, a=0.1, startResidueIndex=0, endResidueIndex=-1,
+                    residueIndexGroup=None, forceGroup=4):
+    inter = read_reference_structure_for_qc_calculation(oa, reference_pdb_file, min_seq_sep=min_seq_sep, a=a,
+                                                        startResidueIndex=startResidueIndex, endResidueIndex=endResidueIndex,
+                                                        residueIndexGroup=residueIndexGroup)
+    if len(inter) == 0:
+        raise ValueError("No atom found, Please check your startResidueIndex and endResidueIndex.")
+    return _q_force(inter, forceGroup)
+
+
+def qbias_term(oa, q0, reference_pdb_file, reference_chain_name, k_qbias=100 * _u.kilocalorie_per_mole, qbias_min_seq_sep=3,
+               qbias_max_seq_sep=np.inf, qbias_contact_threshold=0.8 * _u.nanometers, forceGroup=4):
+    """Umbrella bias 0.5 k_qbias (Q - q0)^2 (CustomCVForce over q_value); k_qbias is not scaled by k_awsem, as in the reference."""
+    inter = read_reference_structure_for_q_calculation_3(oa, reference_pdb_file, reference_chain_name=reference_chain_name,
+                                                         min_seq_sep=qbias_min_seq_sep, max_seq_sep=qbias_max_seq_sep,
+                                                         contact_threshold=qbias_contact_threshold, Qflag=0)
+    return _q_force(inter, forceGroup, cv="harmonic", k=_kj(k_qbias), x0=float(q0))
+
+
+def _rg_square(ca_atoms, cv, k, x0, group):
+    f = BondSumForce("r2", cv, k, x0, group=group)
+    n = len(ca_atoms)
+    for a in range(n):
+        for b in range(a + 1, n):
+            f.addBond(ca_atoms[a], ca_atoms[b], [1.0 / (n * n)])
+    return f
 
 
 def rg_term(oa, convertToAngstrom=True):
-    """Radius of gyration of the CA trace, sqrt(sum_{i<j} r_ij^2 / nres^2), in Angstrom by default (group 2)."""
-    return RgForce(oa.ca, 10.0 if convertToAngstrom else 1.0, 2)
+    """Radius of gyration of the CA trace, unit * sqrt(sum_{i<j} r_ij^2 / nres^2), in Angstrom by default (group 2)."""
+    return _rg_square([oa.ca[i] for i in range(oa.nres)], "sqrt", 10.0 if convertToAngstrom else 1.0, 0.0, 2)
+
+
+def rg_bias_term(oa, k=1 * _u.kilocalorie_per_mole, rg0=0.0, atomGroup=-1, forceGroup=27):
+    """k_rg (Rg - rg0)^2 over the CA atoms of the residues in atomGroup (all by default); Rg in nm."""
+    group = list(range(oa.nres)) if (isinstance(atomGroup, int) and atomGroup == -1) else list(atomGroup)
+    return _rg_square([oa.ca[i] for i in group], "sqrt_square", oa.k_awsem * _kj(k), float(rg0), forceGroup)

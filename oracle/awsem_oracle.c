@@ -52,7 +52,7 @@ typedef struct { int group, n; int *atoms; double *coef; double r_ON, s_NO, r_OH
 typedef struct { int group, n, ntab; int *pairs; double *table; double k, dr; } fm_t;
 typedef struct { int group, n; int *atoms; double *scale; double k, k_m, z_m, center; } memb_t;
 typedef struct { int group, n; int *pairs; double *qq; double k, lam; } dh_t;
-typedef struct { int group, n; int *pairs; double *r0, *sigma, *kg; } gauss_t;
+typedef struct { int group, n; int *pairs; double *r0, *sigma, *kg; int kind, cv; double cv_k, cv_x0; } gauss_t;
 
 enum { T_HARM, T_CHI, T_RAMA, T_EXCL, T_CONTACT, T_BETA, T_PAP, T_HELICAL, T_FM, T_MEMB, T_DH, T_GAUSS };
 typedef struct { int kind; void* p; } term_t;
@@ -125,7 +125,7 @@ static void free_term(term_t* t) {
     case T_FM: { fm_t* x = p; free(x->pairs); free(x->table); } break;
     case T_MEMB: { memb_t* x = p; free(x->atoms); free(x->scale); } break;
     case T_DH: { dh_t* x = p; free(x->pairs); free(x->qq); } break;
-    case T_GAUSS: { gauss_t* x = p; free(x->pairs); free(x->r0); free(x->sigma); free(x->kg); } break;
+    case T_GAUSS: { gauss_t* x = p; free(x->pairs); free(x->r0); free(x->sigma); free(x->kg); } break;   /* free(NULL) is fine for the r^2 kind */
     }
     free(p);
 }
@@ -270,6 +270,21 @@ int awsem_oracle_add_gaussian_bonds(ctx_t* c, int group, int n, const int* pairs
     for (int b = 0; b < n; b++) if (!(sigma[b] > 0)) return fail(-1, "add_gaussian_bonds: sigma must be positive");
     gauss_t* t = calloc(1, sizeof *t); t->group = group; t->n = n; t->pairs = dup_mem(pairs, 2 * n * sizeof(int));
     t->r0 = dup_mem(r0, n * sizeof(double)); t->sigma = dup_mem(sigma, n * sizeof(double)); t->kg = dup_mem(kg, n * sizeof(double));
+    return add_term(c, T_GAUSS, t);
+}
+/* q_value / qc_value / partial_q_value, qbias_term, rg_term, rg_bias_term (biasTerms.py:146-302, 461-528):
+ * a CustomBondForce sum S, alone (cv 0) or as the collective variable of a CustomCVForce E = f(S) */
+int awsem_oracle_add_bond_sum(ctx_t* c, int group, int bond_kind, int n, const int* pairs, const double* r0, const double* sigma,
+                              const double* coef, int cv_kind, double cv_k, double cv_x0) {
+    CHECK_BUILD(c, group);
+    if (bond_kind < 0 || bond_kind > 1 || cv_kind < 0 || cv_kind > 3) return fail(-1, "add_bond_sum: unknown bond or collective-variable kind");
+    if (n < 0 || (n && (!pairs || !coef || (bond_kind == 0 && (!r0 || !sigma)))) || !check_atoms(c, pairs, 2 * n, 0)) return fail(-1, "add_bond_sum: bad arguments");
+    for (int b = 0; b < n && bond_kind == 0; b++) if (!(sigma[b] > 0)) return fail(-1, "add_bond_sum: sigma must be positive");
+    gauss_t* t = calloc(1, sizeof *t); t->group = group; t->n = n; t->pairs = dup_mem(pairs, 2 * n * sizeof(int));
+    if (bond_kind == 0) { t->r0 = dup_mem(r0, n * sizeof(double)); t->sigma = dup_mem(sigma, n * sizeof(double)); }
+    t->kg = dup_mem(coef, n * sizeof(double));
+    for (int b = 0; b < n && bond_kind == 0; b++) t->kg[b] = -t->kg[b];   /* eval_gauss: g = -kg exp(...) */
+    t->kind = bond_kind; t->cv = cv_kind; t->cv_k = cv_k; t->cv_x0 = cv_x0;
     return add_term(c, T_GAUSS, t);
 }
 int awsem_oracle_finalize(ctx_t* c) { if (!c) return fail(-1, "null handle"); c->finalized = 1; return 0; }
@@ -650,16 +665,30 @@ static double eval_dh(const dh_t* t, const double* x, double* f) {
 
 /* er_term templateTerms.py:643-693 and additive_amhgo_term templateTerms.py:600-640 (CustomBondForce):
  * E = -k gamma_ij exp(-(r - r_ijN)^2 / (2 sigma_ij^2)) */
+static double bond_value(const gauss_t* t, int b, double r, double* dgdr) {
+    if (t->kind == 1) { *dgdr = 2 * t->kg[b] * r; return t->kg[b] * r * r; }
+    double dr = r - t->r0[b], s2 = t->sigma[b] * t->sigma[b];
+    double g = -t->kg[b] * exp(-dr * dr / (2 * s2));
+    *dgdr = -g * dr / s2;
+    return g;
+}
 static double eval_gauss(const gauss_t* t, const double* x, double* f) {
-    double e = 0, d[3];
+    double S = 0, d[3], dg;
+    for (int b = 0; b < t->n; b++) S += bond_value(t, b, dist(x, t->pairs[2 * b], t->pairs[2 * b + 1], d), &dg);
+    double E = S, fp = 1;   /* E = f(S), fp = f'(S) */
+    if (t->cv == 1) { E = 0.5 * t->cv_k * (S - t->cv_x0) * (S - t->cv_x0); fp = t->cv_k * (S - t->cv_x0); }
+    else if (t->cv == 2 || t->cv == 3) {
+        double q = S > 0 ? sqrt(S) : 0, iq = q > 0 ? 1 / q : 0;
+        if (t->cv == 2) { E = t->cv_k * q; fp = 0.5 * t->cv_k * iq; }
+        else { E = t->cv_k * (q - t->cv_x0) * (q - t->cv_x0); fp = t->cv_k * (q - t->cv_x0) * iq; }
+    }
     for (int b = 0; b < t->n; b++) {
         int i = t->pairs[2 * b], j = t->pairs[2 * b + 1];
-        double r = dist(x, i, j, d), dr = r - t->r0[b], s2 = t->sigma[b] * t->sigma[b];
-        double E = -t->kg[b] * exp(-dr * dr / (2 * s2));
-        e += E;
-        pair_force(f, i, j, d, r, -E * dr / s2);
+        double r = dist(x, i, j, d);
+        bond_value(t, b, r, &dg);
+        pair_force(f, i, j, d, r, fp * dg);
     }
-    return e;
+    return E;
 }
 
 /* energies per group (eg[32], may be NULL) and forces f (natoms*3, may be NULL; accumulated into) */

@@ -52,6 +52,9 @@ def set_up_forces(oa: OpenMMAWSEMSystem, computeQ: bool = False, submode: int = 
         templateTerms.fragment_memory_term(oa, frag_file_list_file="./single_frags.mem", npy_frag_table="./single_frags.npy", UseSavedFragTable=False),
         debyeHuckelTerms.debye_huckel_term(oa, chargeFile="charge.txt"),
     ]
+    if computeQ:      # scripts/forces_setup.py:67-69 of the reference
+        forces.append(biasTerms.rg_term(oa))
+        forces.append(biasTerms.q_value(oa, "crystal_structure-cleaned.pdb", forceGroup=1))
     return forces
 '''
 
@@ -89,6 +92,33 @@ def test_awsem_analyze_reproduces_golden_energies(protein, tmp_path, monkeypatch
     total = sum(golden[c] for c in COLUMNS)
     dh = data[:, header.index("Debye_huckel")]
     assert np.abs(data[:, header.index("Total")] - (total / 4.184 + dh)).max() <= 0.05
+
+
+def test_awsem_analyze_prints_q_and_rg_from_the_device(tmp_path, monkeypatch):
+    """Q and Rg are force-group "energies" (groups 1 and 2) as in the reference; no fixture pins them (parity unpinned):
+    compared with a direct numpy evaluation of biasTerms.py:13-83, 146-188 and 461-486."""
+    from openawsem_amd.scripts import mm_analyze
+    d = _golden_project(tmp_path, "1ubq")
+    shutil.copy(d / "crystal_structure.pdb", d / "crystal_structure-cleaned.pdb")
+    monkeypatch.chdir(d)
+    out = mm_analyze.main(["1ubq", "-t", "movie.dcd", "-f", "forces_setup.py", "-p", "Reference"])
+    rows = [ln.split() for ln in open(out).read().strip().split("\n")]
+    header, data = rows[0], np.array(rows[1:], dtype=float)
+    oa, traj, golden = golden_system("1ubq")
+    nat = []
+    for line in open(d / "crystal_structure.pdb"):
+        if line.startswith("ATOM") and line[12:16].strip() == "CA":
+            nat.append([float(line[30:38]), float(line[38:46]), float(line[46:54])])
+    nat = np.array(nat) / 10.0
+    i, j = np.nonzero(np.abs(np.subtract.outer(np.arange(oa.nres), np.arange(oa.nres))) >= 3)
+    r0, sig = np.linalg.norm(nat[i] - nat[j], axis=1), 0.1 * np.abs(i - j) ** 0.15
+    for f in range(12):
+        ca = traj[f][oa.ca]
+        q = np.exp(-(np.linalg.norm(ca[i] - ca[j], axis=1) - r0) ** 2 / (2 * sig ** 2)).mean()
+        rg = 10 * np.sqrt(((ca[:, None] - ca[None]) ** 2).sum(-1).sum() / 2) / oa.nres
+        assert abs(data[f, header.index("Q")] - q) <= 0.0051 and abs(data[f, header.index("Rg")] - rg) <= 0.0051
+    assert data[0, header.index("Q")] > 0.9 > data[11, header.index("Q")]
+    assert np.abs(data[:, header.index("Contact")] - golden["Contact"] / 4.184).max() <= 0.0051     # the other columns are untouched
 
 
 def test_awsem_run_anneals_an_ensemble_and_writes_the_reference_files(tmp_path, monkeypatch):
