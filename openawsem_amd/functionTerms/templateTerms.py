@@ -204,3 +204,40 @@ def er_term(oa, k_er=4.184, er_min_seq_sep=2, er_cutoff=99.0, er_well_width=0.1,
                 force.addBond(oa.cb[i], oa.cb[j], [1.0, cbcb[i][j] / 10.0, sigma])
     force.setForceGroup(forceGroup)
     return force
+
+
+def read_reference_structure_for_q_calculation_4(oa, contact_threshold, rnative_dat, min_seq_sep=3, max_seq_sep=np.inf):
+    """[ca_i, ca_j, [1.0, r_ijN (nm), sigma_ij]] for j - i in [min_seq_sep, max_seq_sep] from an nres x nres table of native
+    CA distances in Angstrom; pairs whose native distance is BELOW the threshold are skipped, as in the reference
+    (templateTerms.py:17-58)."""
+    thr = _nm(contact_threshold)
+    table = np.loadtxt(rnative_dat)
+    out = []
+    for i in range(oa.nres):
+        for j in range(oa.nres):
+            if j - i >= min_seq_sep and j - i <= max_seq_sep:
+                r = table[i][j] / 10.0
+                if r < thr:
+                    continue
+                out.append([oa.ca[i], oa.ca[j], [1.0, float(r), 0.1 * abs(i - j) ** 0.15]])
+    return out
+
+
+def q_value_dat(oa, contact_threshold, rnative_dat="rnative.dat", min_seq_sep=3, max_seq_sep=np.inf, forceGroup=0):
+    """Q against the distances of rnative.dat (templateTerms.py:60-91): a plain bond sum."""
+    from ..forces import BondSumForce
+    inter = read_reference_structure_for_q_calculation_4(oa, contact_threshold, rnative_dat, min_seq_sep, max_seq_sep)
+    f = BondSumForce("gauss", "sum", group=forceGroup)
+    for i, j, (gamma, r, sigma) in inter:
+        f.addBond(i, j, [gamma / len(inter), r, sigma])
+    return f
+
+
+def tbm_q_term(oa, k_tbm_q, rnative_dat="rnative.dat", tbm_q_min_seq_sep=3, tbm_q_cutoff=0.2, tbm_q_well_width=0.1,
+               target_q=1.0, forceGroup=26):
+    """Template-based-modelling bias k_tbm_q (q - target_q)^2 (templateTerms.py:94-121, CustomCVForce over q_value_dat);
+    tbm_q_cutoff in nm or a Quantity (the reference's default is 0.2 nm)."""
+    print("TBM_Q term ON")
+    f = q_value_dat(oa, tbm_q_cutoff, rnative_dat, tbm_q_min_seq_sep, np.inf, forceGroup)
+    f.cv, f.k, f.x0 = "harmonic", 2.0 * float(k_tbm_q), float(target_q)      # k/2 (S - x0)^2 with k = 2 k_tbm_q
+    return f

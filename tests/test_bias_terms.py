@@ -93,6 +93,26 @@ def test_factories_and_oracle_match_the_reference_formulas():
         biasTerms.partial_q_value(oa, NATIVE, startResidueIndex=10_000)
 
 
+def test_tbm_q_term_is_a_harmonic_bias_on_q_from_rnative_dat(tmp_path):
+    from openawsem_amd.functionTerms import templateTerms
+    oa, traj, _ = golden_system("1ubq")
+    nat = _native_ca()
+    table = 10 * np.linalg.norm(nat[:, None] - nat[None], axis=-1)
+    np.savetxt(tmp_path / "rnative.dat", table, fmt="%.5f")
+    table = np.loadtxt(tmp_path / "rnative.dat")
+    f = templateTerms.tbm_q_term(oa, k_tbm_q=1000.0, rnative_dat=str(tmp_path / "rnative.dat"), target_q=0.9)
+    n = oa.nres
+    assert f.getForceGroup() == 26 and f.getNumBonds() == sum(j - i >= 3 for i in range(n) for j in range(n))   # no CA pair within 2 A
+    system = System(oa.system.masses.copy())
+    system.addForce(f)
+    cpu = awsem_oracle.make_context(system, n_replicas=1)
+    cpu.set_positions(traj[6], replica=0)
+    ca = traj[6][oa.ca]
+    i, j = np.nonzero(np.subtract.outer(np.arange(n), np.arange(n)) <= -3)
+    q = np.exp(-(np.linalg.norm(ca[i] - ca[j], axis=1) - table[i, j] / 10) ** 2 / (2 * (0.1 * (j - i) ** 0.15) ** 2)).mean()
+    assert abs(cpu.energy_by_group()[0, 26] - 1000.0 * (q - 0.9) ** 2) < 1e-6
+
+
 def test_oracle_forces_are_the_gradient_of_the_collective_variable_energies():
     oa, traj, _ = golden_system("1ubq")
     system = _bias_system(oa)
