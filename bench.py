@@ -32,6 +32,7 @@ WORKLOADS = {
     "t0958": ("build_t0958", {}, 1024, 50, "T0958 (96 residues), default terms + helical + rama_ssweight, fragment memory, annealing ensemble"),
     "2xov": ("build_2xov", {}, 256, 50, "2xov membrane protein (276 residues), membrane_term + z-dependent contact, annealing ensemble"),
     "2xov-remd": ("build_2xov", {}, 64, 200, "2xov membrane protein, temperature replica exchange 300-600 K, exchange every launch (all-gather of energies, label swap)"),
+    "synthetic-hb": ("build_synthetic", {"n_chains": 16, "seed": 3, "hbonds": True}, 1, 100, "synthetic multi-chain system (16 x 2lzm, 2624 residues) with the full backbone + contact + beta 1-3 + P-AP 1-2 + helical force field on the cell-list path"),
     "synthetic": ("build_synthetic", {}, 1, 20, "synthetic multi-chain system (122 x 2lzm), con/chain/chi/excl/rama/contact+burial, cell-list path, Langevin (dt 2 fs, friction 1/ps)"),
 }
 
@@ -109,7 +110,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from openawsem_amd import _capi, workloads
-    synthetic = args.workload == "synthetic"
+    synthetic = args.workload.startswith("synthetic")
     builder, kwargs, def_replicas, def_steps, description = WORKLOADS[args.workload]
     if args.replicas is None:
         args.replicas = def_replicas
@@ -187,7 +188,7 @@ def main():
             "metric": "MD steps/sec (all replicas)", "value": total_steps / elapsed, "unit": "replica-MD-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f64",
-            "data": ("synthetic (122 rigidly rotated copies of the reference's 2lzm test structure on a jittered lattice, seed 2026)" if synthetic else
+            "data": (f"synthetic ({kwargs.get('n_chains', 122)} rigidly rotated copies of the reference's 2lzm test structure on a jittered lattice, seed {kwargs.get('seed', 2026)})" if synthetic else
                      f"synthetic ({args.workload.split('-')[0]} start structure from the reference's examples/, Maxwell-Boltzmann velocities, Philox seed 2026)"),
             "config": {"workload": description, "replicas_per_gpu": R, "md_steps_per_launch": args.md_steps,
                        "residues": oa.nres, "atoms": oa.natoms, "parallelism": f"replica-sharded x{world}"},

@@ -500,6 +500,84 @@ template <class real> __global__ void cell_chain_kernel(DevSys<real> S, CellSys<
     }
 }
 
+// ------------------------------------------------------------------ hydrogen-bond terms (beta 1-3, P-AP 1-2)
+// Every acceptor owns a fixed-stride row of the donors whose screening atom (N) lies within the term's screening
+// distance of the acceptor's (O resp. CA) and whose table entry is non-zero.  The rows are rebuilt with the other
+// lists by a brute-force scan -- 16 lanes per acceptor test 16 donors at a time and compact the passing ones with a
+// ballot, the row count is a register: O(acceptors x donors) per REBUILD, which is what OpenMM's CustomHbondForce
+// does every step.  The rebuild flag watches the list members of the contact and excluded-volume terms (CA, CB, O);
+// a donor's N is a virtual site of CA_{i-1}, CA_i, O_{i-1} with |weights| summing to 1.373, so while no member has
+// moved further than skin/2 an O-N or CA-N distance has changed by less than 1.19 skin: the rows are cut at the
+// screening distance + 1.2 skin.  Evaluation: 16 lanes walk a row, same per-pair code as the resident path
+// (beta_pair / pap_pair), forces through global fixed-point atomics (a pair touches up to five atoms).
+struct HbRows { unsigned* rows; int* row_count; int stride; };   // [R][nacc][stride] donor indices, [R][nacc]
+
+template <class real> __device__ inline CellView<real> cell_view_plain(const CellSys<real>& C, const real* pos, int rep) {
+    CellView<real> L;
+    const size_t n = C.natoms;
+    real* p = const_cast<real*>(pos) + (size_t)rep * 3 * n;
+    L.px = p; L.py = p + n; L.pz = p + 2 * n;
+    u64* f = C.f + (size_t)rep * 3 * n;
+    L.fx = f; L.fy = f + n; L.fz = f + 2 * n;
+    L.rho = L.drho = nullptr; L.rhov = L.alpha = L.dalpha = L.gamma = nullptr; L.satom = nullptr;
+    L.eg = C.eg + (size_t)rep * AWSEM_NGROUPS;
+    L.lcount = nullptr; L.flag = nullptr; L.lists = nullptr;
+    return L;
+}
+template <bool ENERGY, class V> __device__ __forceinline__ void hb_pair(const BetaD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e) { beta_pair<ENERGY>(d, L, A, D, e); }
+template <bool ENERGY, class V> __device__ __forceinline__ void hb_pair(const PapD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e) { pap_pair<ENERGY>(d, L, A, D, e); }
+
+// grid (blocks, R)
+template <class real, class Desc> __global__ void cell_hb_rows_kernel(Desc d, CellSys<real> C, HbRows H, const real* __restrict__ pos, real rc2, int cur, int force) {
+    const int rep = blockIdx.y;
+    if (!cell_rebuild(C, rep, cur, force)) return;
+    const size_t n = C.natoms;
+    const real* p = pos + (size_t)rep * 3 * n;
+    const int sub = threadIdx.x & (AWSEM_ROW - 1), row_in_wave = (threadIdx.x & 63) / AWSEM_ROW;
+    const int nrows_total = (d.nacc + 3) & ~3;   // whole waves: the ballots are wave collectives
+    unsigned* rows = H.rows + (size_t)rep * d.nacc * H.stride;
+    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows_total; k += gridDim.x * blockDim.x / AWSEM_ROW) {
+        const bool vi = k < d.nacc;
+        const Int4 A = d.acc[vi ? k : 0];
+        const int ares = Desc::res_slot == 3 ? A.w : A.z;
+        const real ax = p[A.x], ay = p[n + A.x], az = p[2 * n + A.x];
+        int cnt = 0;
+        for (int q0 = 0; q0 < d.ndon; q0 += AWSEM_ROW) {   // the same trip count for every lane
+            const int q = q0 + sub;
+            const bool vq = vi && q < d.ndon;
+            const Int4 D = d.don[vq ? q : 0];
+            const int dres = Desc::res_slot == 3 ? D.w : D.z, dq = dres - ares;
+            const real r2 = dist2(ax - p[D.x], ay - p[n + D.x], az - p[2 * n + D.x]);
+            bool pass = vq && r2 < rc2 && (dq <= d.band_lo || dq >= d.band_hi);
+            if (pass) { const size_t bit = (size_t)dres * d.nres + ares; pass = (d.nzmask[bit >> 5] >> (bit & 31)) & 1u; }
+            const unsigned rowmask = (unsigned)(__ballot(pass) >> (row_in_wave * AWSEM_ROW)) & 0xffffu;
+            if (pass) {
+                const int slot = cnt + __popc(rowmask & ((1u << sub) - 1u));
+                if (slot < H.stride) rows[(size_t)k * H.stride + slot] = (unsigned)q;
+                else atomicOr(C.status, 2);
+            }
+            cnt += __popc(rowmask);
+        }
+        if (vi && sub == 0) H.row_count[(size_t)rep * d.nacc + k] = min(cnt, H.stride);
+    }
+}
+
+template <bool ENERGY, class real, class Desc> __global__ void cell_hb_eval_kernel(Desc d, CellSys<real> C, HbRows H, const real* __restrict__ pos) {
+    const int rep = blockIdx.y;
+    const CellView<real> L = cell_view_plain(C, pos, rep);
+    const int sub = threadIdx.x & (AWSEM_ROW - 1);
+    const unsigned* rows = H.rows + (size_t)rep * d.nacc * H.stride;
+    const int* rc = H.row_count + (size_t)rep * d.nacc;
+    Energy e;
+    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / AWSEM_ROW; k < d.nacc; k += gridDim.x * blockDim.x / AWSEM_ROW) {
+        const int cnt = rc[k];
+        if (cnt == 0) continue;
+        const Int4 A = d.acc[k];
+        for (int s = sub; s < cnt; s += AWSEM_ROW) hb_pair<ENERGY>(d, L, A, d.don[rows[(size_t)k * H.stride + s]], e);
+    }
+    flush_energy<ENERGY>(L, d.group, e);
+}
+
 // Bonded terms: one workgroup per 256 items of one term (job table built at finalize).
 struct CellJob { int kind, term, first; };
 enum { CJ_HARM, CJ_CHI, CJ_RAMA, CJ_HELICAL, CJ_FM, CJ_MEMB, CJ_DH, CJ_GAUSS };

@@ -363,7 +363,11 @@ private:
     void cell_evaluate(bool energy, unsigned mask, int redistribute, double* e, double* f);
     void cell_step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0);
     void cell_one_step(double dt, double friction, uint64_t seed, int offset);
-    struct CellGraph { hipGraphExec_t exec = nullptr; double dt = 0, friction = 0; uint64_t seed = 0; const void *rows0 = nullptr, *rows1 = nullptr; };
+    struct CellGraph { hipGraphExec_t exec = nullptr; double dt = 0, friction = 0; uint64_t seed = 0; long long gen = -1; };
+    long long cell_rows_gen_ = 0;          // bumped whenever the neighbour rows are re-allocated (captured graphs hold their addresses)
+    HbRows cell_hb_beta_[AWSEM_MAX_BETA] = {}, cell_hb_pap_[AWSEM_MAX_PAP] = {};   // donor rows of the hydrogen-bond terms
+    real cell_hb_rc2_beta_[AWSEM_MAX_BETA] = {}, cell_hb_rc2_pap_[AWSEM_MAX_PAP] = {};
+    int dsys_beta_n_ = 0, dsys_pap_n_ = 0, cell_nacc_beta_[AWSEM_MAX_BETA] = {}, cell_nacc_pap_[AWSEM_MAX_PAP] = {};   // known before dsys_ is set
     CellGraph cell_graph_[2];
     long long* cell_step_base_ = nullptr;
     int cell_neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity);
@@ -898,9 +902,14 @@ template <class real> int Engine<real>::neighbors(int rep, int kind, int index, 
 
 // ------------------------------------------------------------------------------------------------ cell-list path
 template <class real> void Engine<real>::cell_setup(DevSys<real>& S, const HostSystem& H) {
-    if (S.n_beta || S.n_pap)
-        throw std::string("this system does not fit the LDS of one CU, and the hydrogen-bond terms (dense nres x nres tables) are "
-                          "only available on the replica-resident path: the cell-list path takes contact/burial, excluded volume and the bonded terms");
+    if ((S.n_beta || S.n_pap) && !S.n_excl)
+        throw std::string("cell-list path: the hydrogen-bond terms need the excluded-volume term in the system (its CA and O atoms drive the list rebuilds)");
+    // rows of the hydrogen-bond terms: screening distance + 1.2 skin (the donor's N is a virtual site, see awsem_cell.h)
+    for (int t = 0; t < S.n_beta; t++) { const double r = std::sqrt((double)S.beta[t].screen2) + 1.2 * skin_; cell_hb_rc2_beta_[t] = (real)(r * r); }
+    for (int t = 0; t < S.n_pap; t++) { const double r = H.pap[t].cutoff + 1.2 * skin_; cell_hb_rc2_pap_[t] = (real)(r * r); }
+    dsys_beta_n_ = S.n_beta; dsys_pap_n_ = S.n_pap;
+    for (int t = 0; t < S.n_beta; t++) cell_nacc_beta_[t] = S.beta[t].nacc;
+    for (int t = 0; t < S.n_pap; t++) cell_nacc_pap_[t] = S.pap[t].nacc;
     if (S.n_contact > 1 || S.n_excl > 1) throw std::string("cell-list path: at most one contact and one excluded-volume term");
     if (S.n_contact && (H.contact[0].flags & AWSEM_CONTACT_NOCUTOFF)) throw std::string("cell-list path: the contact term needs a cutoff");
     if (S.n_contact && S.contact[0].nsites >= (1 << 24)) throw std::string("cell-list path: at most 2^24 contact sites");
@@ -981,6 +990,16 @@ template <class real> void Engine<real>::cell_alloc_lists() {
         if (n > 0x7fffffffULL) throw std::string("cell-list path: neighbour rows exceed 2^31 entries per replica");
         C.bin[b].rows = dalloc<unsigned>(n * nrep_);
     }
+    auto hb_alloc = [&](HbRows& Hb, int nacc) {
+        Hb.stride = C.bin[0].stride;
+        const size_t n = (size_t)std::max(1, nacc) * Hb.stride;
+        if (n > 0x7fffffffULL) throw std::string("cell-list path: hydrogen-bond rows exceed 2^31 entries per replica");
+        Hb.rows = dalloc<unsigned>(n * nrep_);
+        if (!Hb.row_count) { Hb.row_count = dalloc<int>((size_t)std::max(1, nacc) * nrep_); HIP_TRY(hipMemset(Hb.row_count, 0, (size_t)std::max(1, nacc) * nrep_ * sizeof(int))); }
+    };
+    for (int t = 0; t < dsys_beta_n_; t++) hb_alloc(cell_hb_beta_[t], cell_nacc_beta_[t]);
+    for (int t = 0; t < dsys_pap_n_; t++) hb_alloc(cell_hb_pap_[t], cell_nacc_pap_[t]);
+    cell_rows_gen_++;
     cell_stale_ = true;
 }
 // member records, displacement test, bounding box (and, when asked, the virtual sites)
@@ -1002,6 +1021,11 @@ template <class real> void Engine<real>::cell_refresh(const CellSys<real>& C) {
     hipLaunchKernelGGL(cell_scan_kernel<real>, dim3(AWSEM_CELL_MAXCELLS / 1024, 2 * nrep_), dim3(1024), 0, stream_, C, cur, force);
     hipLaunchKernelGGL(cell_fill_kernel<real>, gm, b, 0, stream_, C, cur, force);
     hipLaunchKernelGGL(cell_rows_kernel<real>, gr, b, 0, stream_, dsys_, C, cur, force);
+    auto hb_grid = [&](int nacc) { return dim3((unsigned)std::max(1LL, std::min(((long long)nacc * AWSEM_ROW + 255) / 256, 16384LL)), nrep_); };
+    for (int t = 0; t < dsys_.n_beta; t++)
+        hipLaunchKernelGGL((cell_hb_rows_kernel<real, BetaD<real>>), hb_grid(dsys_.beta[t].nacc), b, 0, stream_, dsys_.beta[t], C, cell_hb_beta_[t], pos_, cell_hb_rc2_beta_[t], cur, force);
+    for (int t = 0; t < dsys_.n_pap; t++)
+        hipLaunchKernelGGL((cell_hb_rows_kernel<real, PapD<real>>), hb_grid(dsys_.pap[t].nacc), b, 0, stream_, dsys_.pap[t], C, cell_hb_pap_[t], pos_, cell_hb_rc2_pap_[t], cur, force);
     HIP_TRY(hipGetLastError());
     cell_stale_ = false;
 }
@@ -1032,6 +1056,18 @@ template <class real> void Engine<real>::cell_forces_pass(bool energy, unsigned 
             else hipLaunchKernelGGL((cell_pairs_kernel<false, real>), g, b, 0, stream_, S, C, pos_);
         }
         hipLaunchKernelGGL(cell_chain_kernel<real>, g, b, 0, stream_, S, C, pos_);
+    }
+    for (int t = 0; t < S.n_beta; t++) {
+        if (!((mask >> S.beta[t].group) & 1u)) continue;
+        const dim3 g(row_blocks(S.beta[t].nacc), nrep_);
+        if (energy) hipLaunchKernelGGL((cell_hb_eval_kernel<true, real, BetaD<real>>), g, b, 0, stream_, S.beta[t], C, cell_hb_beta_[t], pos_);
+        else hipLaunchKernelGGL((cell_hb_eval_kernel<false, real, BetaD<real>>), g, b, 0, stream_, S.beta[t], C, cell_hb_beta_[t], pos_);
+    }
+    for (int t = 0; t < S.n_pap; t++) {
+        if (!((mask >> S.pap[t].group) & 1u)) continue;
+        const dim3 g(row_blocks(S.pap[t].nacc), nrep_);
+        if (energy) hipLaunchKernelGGL((cell_hb_eval_kernel<true, real, PapD<real>>), g, b, 0, stream_, S.pap[t], C, cell_hb_pap_[t], pos_);
+        else hipLaunchKernelGGL((cell_hb_eval_kernel<false, real, PapD<real>>), g, b, 0, stream_, S.pap[t], C, cell_hb_pap_[t], pos_);
     }
     HIP_TRY(hipGetLastError());
 }
@@ -1092,6 +1128,14 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
                 HIP_TRY(hipMemcpy(cnt.data(), cell_.bin[0].row_count, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
                 for (int c : cnt) fullest = std::max(fullest, c);
             }
+            auto hb_fullest = [&](const HbRows& Hb, int nacc) {
+                std::vector<int> cnt((size_t)nacc * nrep_);
+                if (cnt.empty()) return;
+                HIP_TRY(hipMemcpy(cnt.data(), Hb.row_count, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+                for (int c : cnt) fullest = std::max(fullest, c);
+            };
+            for (int t = 0; t < dsys_.n_beta && !(st & 2); t++) hb_fullest(cell_hb_beta_[t], dsys_.beta[t].nacc);
+            for (int t = 0; t < dsys_.n_pap && !(st & 2); t++) hb_fullest(cell_hb_pap_[t], dsys_.pap[t].nacc);
             if (!(st & 2) && 2 * fullest <= cell_.bin[0].stride) break;
             HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
             if (attempt >= 6) throw std::string("cell-list path: neighbour rows keep overflowing");
@@ -1109,7 +1153,7 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
         // the rows are rebuilt unconditionally (a host-side decision baked into the launch) right after the coordinates were set
         if (use_graph && !cell_stale_ && nsteps - s >= AWSEM_CELL_CHUNK) {
             CellGraph& G = cell_graph_[cell_cur_];   // the flag parity is baked into the captured launches
-            if (!G.exec || G.dt != dt || G.friction != friction || G.seed != seed || G.rows0 != cell_.bin[0].rows || G.rows1 != cell_.bin[1].rows) {
+            if (!G.exec || G.dt != dt || G.friction != friction || G.seed != seed || G.gen != cell_rows_gen_) {
                 if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
                 const int cur0 = cell_cur_;
                 hipGraph_t graph = nullptr;
@@ -1119,7 +1163,7 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
                 HIP_TRY(hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0));
                 HIP_TRY(hipGraphDestroy(graph));
                 cell_cur_ = cur0;   // capturing ran nothing; AWSEM_CELL_CHUNK is even, so a replay ends on the parity it started on
-                G.dt = dt; G.friction = friction; G.seed = seed; G.rows0 = cell_.bin[0].rows; G.rows1 = cell_.bin[1].rows;
+                G.dt = dt; G.friction = friction; G.seed = seed; G.gen = cell_rows_gen_;
             }
             set_base((long long)(step0 + s));
             HIP_TRY(hipGraphLaunch(G.exec, stream_));
@@ -1135,14 +1179,25 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
     end_async();
 }
 template <class real> int Engine<real>::cell_neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) {
-    if (index != 0 || (kind != AWSEM_LIST_EXCL && kind != AWSEM_LIST_CONTACT)) throw std::string("neighbors (cell-list path): kind must be AWSEM_LIST_EXCL or AWSEM_LIST_CONTACT, index 0");
-    if ((kind == AWSEM_LIST_EXCL && !dsys_.n_excl) || (kind == AWSEM_LIST_CONTACT && !dsys_.n_contact)) throw std::string("neighbors: no such term");
+    const bool hb = kind == AWSEM_LIST_BETA || kind == AWSEM_LIST_PAP;
+    if (!hb && (index != 0 || (kind != AWSEM_LIST_EXCL && kind != AWSEM_LIST_CONTACT))) throw std::string("neighbors (cell-list path): kind must be AWSEM_LIST_EXCL / _CONTACT (index 0), _BETA or _PAP");
+    if ((kind == AWSEM_LIST_EXCL && !dsys_.n_excl) || (kind == AWSEM_LIST_CONTACT && !dsys_.n_contact) || index < 0 ||
+        (kind == AWSEM_LIST_BETA && index >= dsys_.n_beta) || (kind == AWSEM_LIST_PAP && index >= dsys_.n_pap)) throw std::string("neighbors: no such term");
     const int b = kind == AWSEM_LIST_EXCL ? 1 : 0;
-    const double cutoff = b ? cell_rc_excl_ : cell_rc_contact_, r = cutoff + skin;
+    // the list as the caller defines it: screening distance + skin (the rows of a run use their own margins)
+    real* hb_rc2 = kind == AWSEM_LIST_BETA ? &cell_hb_rc2_beta_[index] : &cell_hb_rc2_pap_[index];
+    const real hb_saved = hb ? *hb_rc2 : (real)0;
+    double r = (b ? cell_rc_excl_ : cell_rc_contact_) + skin;
+    if (hb) {
+        r = (kind == AWSEM_LIST_BETA ? std::sqrt((double)dsys_.beta[index].screen2) : host_->pap[index].cutoff) + skin;
+        *hb_rc2 = (real)(r * r);
+    }
     for (int attempt = 0;; attempt++) {
         CellSys<real> C = cell_;
-        C.bin[b].edge_min = (real)std::max((double)C.bin[b].edge_min, r);
-        C.bin[b].rc2 = (real)(r * r);
+        if (!hb) {
+            C.bin[b].edge_min = (real)std::max((double)C.bin[b].edge_min, r);
+            C.bin[b].rc2 = (real)(r * r);
+        }
         cell_pre(false);
         cell_stale_ = true;
         cell_refresh(C);
@@ -1152,24 +1207,38 @@ template <class real> int Engine<real>::cell_neighbors(int rep, int kind, int in
         HIP_TRY(hipMemcpy(&st, dstatus_, sizeof st, hipMemcpyDeviceToHost));
         if (!(st & 2)) break;
         HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
-        if (attempt >= 5) throw std::string("cell-list path: neighbour rows keep overflowing");
+        if (attempt >= 5) { if (hb) *hb_rc2 = hb_saved; throw std::string("cell-list path: neighbour rows keep overflowing"); }
         cell_per_site_ *= 2;
         cell_alloc_lists();
     }
-    const CellBin<real>& B = cell_.bin[b];
-    std::vector<int> cnt(B.n);
-    std::vector<unsigned> rows((size_t)B.n * B.stride);
-    if (B.n) {
-        HIP_TRY(hipMemcpy(cnt.data(), B.row_count + (size_t)rep * B.n, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(rows.data(), B.rows + (size_t)rep * B.n * B.stride, rows.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-    }
     std::vector<std::pair<int, int>> out;
-    for (int i = 0; i < B.n; i++)
-        for (int s = 0; s < cnt[i]; s++) {
-            const int j = (int)(rows[(size_t)i * B.stride + s] & 0xffffffu);
-            if (b == 0) { if (i < j) out.push_back({i, j}); }   // every pair sits in both rows: keep the one of the lower site
-            else { const int a = excl_sorted_atom_[i], c = excl_sorted_atom_[j]; if (a < c) out.push_back({a, c}); }
+    if (hb) {
+        *hb_rc2 = hb_saved;
+        const HbRows& Hb = kind == AWSEM_LIST_BETA ? cell_hb_beta_[index] : cell_hb_pap_[index];
+        const int nacc = kind == AWSEM_LIST_BETA ? dsys_.beta[index].nacc : dsys_.pap[index].nacc;
+        std::vector<int> cnt(nacc);
+        std::vector<unsigned> rows((size_t)nacc * Hb.stride);
+        if (nacc) {
+            HIP_TRY(hipMemcpy(cnt.data(), Hb.row_count + (size_t)rep * nacc, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(rows.data(), Hb.rows + (size_t)rep * nacc * Hb.stride, rows.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
         }
+        for (int i = 0; i < nacc; i++)
+            for (int s = 0; s < cnt[i]; s++) out.push_back({i, (int)rows[(size_t)i * Hb.stride + s]});   // (acceptor index, donor index)
+    } else {
+        const CellBin<real>& B = cell_.bin[b];
+        std::vector<int> cnt(B.n);
+        std::vector<unsigned> rows((size_t)B.n * B.stride);
+        if (B.n) {
+            HIP_TRY(hipMemcpy(cnt.data(), B.row_count + (size_t)rep * B.n, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(rows.data(), B.rows + (size_t)rep * B.n * B.stride, rows.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        }
+        for (int i = 0; i < B.n; i++)
+            for (int s = 0; s < cnt[i]; s++) {
+                const int j = (int)(rows[(size_t)i * B.stride + s] & 0xffffffu);
+                if (b == 0) { if (i < j) out.push_back({i, j}); }   // every pair sits in both rows: keep the one of the lower site
+                else { const int a = excl_sorted_atom_[i], c = excl_sorted_atom_[j]; if (a < c) out.push_back({a, c}); }
+            }
+    }
     std::sort(out.begin(), out.end());
     const int n = (int)out.size();
     for (int k = 0; k < n && k < capacity; k++) { pairs[2 * k] = out[k].first; pairs[2 * k + 1] = out[k].second; }

@@ -830,8 +830,38 @@ template <class V, class Desc> __device__ void build_hbond(const Desc& d, const 
     __syncthreads();
 }
 
-template <bool ENERGY, class V> __device__ void eval_beta(const BetaD<typename V::real_t>& d, const V& L) {
+// one (acceptor, donor) pair of a beta term; shared by the pair-list walk below and the cell-list rows (awsem_cell.h)
+template <bool ENERGY, class V> __device__ __forceinline__ void beta_pair(const BetaD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e) {
     typedef typename V::real_t real;
+    const R3<real> po = L.pos(A.x), a = po - L.pos(D.x);
+    const real r1s = dist2(a);
+    if (!(r1s < d.screen2)) return;
+    const R3<real> b = po - L.pos(D.y);
+    const real r2s = dist2(b);
+    const real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
+    const real da = r1s * i1 - d.r_ON, db = r2s * i2 - d.r_OH;
+    const real ex1 = (real)0.5 * (da * da * d.inv_sNO2 + db * db * d.inv_sHO2);
+    if (ex1 > d.max_expo) return;
+    const real c = d.lambda[(size_t)D.w * d.nres + A.w];   // -k * lambda[don_res][acc_res]
+    const real th1 = M<real>::exp(-ex1), g1 = -th1 * da * d.inv_sNO2, g2 = -th1 * db * d.inv_sHO2;
+    if (!d.two_theta) {
+        if (ENERGY) e += (double)(c * th1);
+        L.pair_force(A.x, D.x, a.x, a.y, a.z, -c * g1 * i1);
+        L.pair_force(A.x, D.y, b.x, b.y, b.z, -c * g2 * i2);
+    } else {
+        const R3<real> pp = L.pos(D.z), cc = pp - L.pos(A.y), ee = pp - L.pos(A.z);
+        const real r3s = dist2(cc), r4s = dist2(ee);
+        const real i3 = M<real>::rsqrt(r3s), i4 = M<real>::rsqrt(r4s);
+        real h1, h2;
+        const real th2 = hb_theta(r3s * i3, r4s * i4, d.r_ON, d.r_OH, d.inv_sNO2, d.inv_sHO2, h1, h2);
+        if (ENERGY) e += (double)(c * th1 * th2);
+        L.pair_force(A.x, D.x, a.x, a.y, a.z, -c * g1 * th2 * i1);
+        L.pair_force(A.x, D.y, b.x, b.y, b.z, -c * g2 * th2 * i2);
+        L.pair_force(D.z, A.y, cc.x, cc.y, cc.z, -c * th1 * h1 * i3);
+        L.pair_force(D.z, A.z, ee.x, ee.y, ee.z, -c * th1 * h2 * i4);
+    }
+}
+template <bool ENERGY, class V> __device__ void eval_beta(const BetaD<typename V::real_t>& d, const V& L) {
     AWSEM_WAVE_VARS;
     Energy e;
     const ListView lv = list_view(L, d.ls);
@@ -839,67 +869,42 @@ template <bool ENERGY, class V> __device__ void eval_beta(const BetaD<typename V
         const int idx = c0 + lane;
         if (idx >= lv.count) continue;
         const unsigned ent = lv.e[idx];
-        const Int4 A = d.acc[ent >> 16], D = d.don[ent & 0xffff];
-        const R3<real> po = L.pos(A.x), a = po - L.pos(D.x);
-        const real r1s = dist2(a);
-        if (!(r1s < d.screen2)) continue;
-        const R3<real> b = po - L.pos(D.y);
-        const real r2s = dist2(b);
-        const real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
-        const real da = r1s * i1 - d.r_ON, db = r2s * i2 - d.r_OH;
-        const real ex1 = (real)0.5 * (da * da * d.inv_sNO2 + db * db * d.inv_sHO2);
-        if (ex1 > d.max_expo) continue;
-        const real c = d.lambda[(size_t)D.w * d.nres + A.w];   // -k * lambda[don_res][acc_res]
-        const real th1 = M<real>::exp(-ex1), g1 = -th1 * da * d.inv_sNO2, g2 = -th1 * db * d.inv_sHO2;
-        if (!d.two_theta) {
-            if (ENERGY) e += (double)(c * th1);
-            L.pair_force(A.x, D.x, a.x, a.y, a.z, -c * g1 * i1);
-            L.pair_force(A.x, D.y, b.x, b.y, b.z, -c * g2 * i2);
-        } else {
-            const R3<real> pp = L.pos(D.z), cc = pp - L.pos(A.y), ee = pp - L.pos(A.z);
-            const real r3s = dist2(cc), r4s = dist2(ee);
-            const real i3 = M<real>::rsqrt(r3s), i4 = M<real>::rsqrt(r4s);
-            real h1, h2;
-            const real th2 = hb_theta(r3s * i3, r4s * i4, d.r_ON, d.r_OH, d.inv_sNO2, d.inv_sHO2, h1, h2);
-            if (ENERGY) e += (double)(c * th1 * th2);
-            L.pair_force(A.x, D.x, a.x, a.y, a.z, -c * g1 * th2 * i1);
-            L.pair_force(A.x, D.y, b.x, b.y, b.z, -c * g2 * th2 * i2);
-            L.pair_force(D.z, A.y, cc.x, cc.y, cc.z, -c * th1 * h1 * i3);
-            L.pair_force(D.z, A.z, ee.x, ee.y, ee.z, -c * th1 * h2 * i4);
-        }
+        beta_pair<ENERGY>(d, L, d.acc[ent >> 16], d.don[ent & 0xffff], e);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-template <bool ENERGY, class V> __device__ void eval_pap(const PapD<typename V::real_t>& d, const V& L) {
+template <bool ENERGY, class V> __device__ __forceinline__ void pap_pair(const PapD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e) {
     typedef typename V::real_t real;
+    const real one = (real)1;
+    const R3<real> a1 = L.pos(A.x), a = a1 - L.pos(D.x);
+    const real r1s = dist2(a);
+    if (!(r1s < d.cutoff2)) return;
+    const R3<real> a2 = L.pos(A.y), ee = a1 - a2;
+    const real r3s = dist2(ee), i3 = M<real>::rsqrt(r3s);
+    const real arg3 = d.eta2 * (r3s * i3 - d.d_i4);
+    if (arg3 < d.min_arg) return;
+    const R3<real> b = a2 - L.pos(D.y);
+    const real r2s = dist2(b);
+    const real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
+    const real arg2 = d.eta2 * (d.r0 - r2s * i2);
+    if (arg2 < d.min_arg) return;
+    const real c = d.gamma[(size_t)D.z * d.nres + A.z];   // -k * gamma[don_res][acc_res]
+    const real s1 = sigmoid(d.eta2 * (d.r0 - r1s * i1)), s2 = sigmoid(arg2), s3 = sigmoid(arg3);
+    if (ENERGY) e += (double)(c * s1 * s2 * s3);
+    L.pair_force(A.x, D.x, a.x, a.y, a.z, c * d.eta2 * s1 * (one - s1) * s2 * s3 * i1);
+    L.pair_force(A.y, D.y, b.x, b.y, b.z, c * s1 * d.eta2 * s2 * (one - s2) * s3 * i2);
+    L.pair_force(A.x, A.y, ee.x, ee.y, ee.z, -c * s1 * s2 * d.eta2 * s3 * (one - s3) * i3);
+}
+template <bool ENERGY, class V> __device__ void eval_pap(const PapD<typename V::real_t>& d, const V& L) {
     AWSEM_WAVE_VARS;
     Energy e;
-    const real one = (real)1;
     const ListView lv = list_view(L, d.ls);
     AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id) {
         const int idx = c0 + lane;
         if (idx >= lv.count) continue;
         const unsigned ent = lv.e[idx];
-        const Int4 A = d.acc[ent >> 16], D = d.don[ent & 0xffff];
-        const R3<real> a1 = L.pos(A.x), a = a1 - L.pos(D.x);
-        const real r1s = dist2(a);
-        if (!(r1s < d.cutoff2)) continue;
-        const R3<real> a2 = L.pos(A.y), ee = a1 - a2;
-        const real r3s = dist2(ee), i3 = M<real>::rsqrt(r3s);
-        const real arg3 = d.eta2 * (r3s * i3 - d.d_i4);
-        if (arg3 < d.min_arg) continue;
-        const R3<real> b = a2 - L.pos(D.y);
-        const real r2s = dist2(b);
-        const real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
-        const real arg2 = d.eta2 * (d.r0 - r2s * i2);
-        if (arg2 < d.min_arg) continue;
-        const real c = d.gamma[(size_t)D.z * d.nres + A.z];   // -k * gamma[don_res][acc_res]
-        const real s1 = sigmoid(d.eta2 * (d.r0 - r1s * i1)), s2 = sigmoid(arg2), s3 = sigmoid(arg3);
-        if (ENERGY) e += (double)(c * s1 * s2 * s3);
-        L.pair_force(A.x, D.x, a.x, a.y, a.z, c * d.eta2 * s1 * (one - s1) * s2 * s3 * i1);
-        L.pair_force(A.y, D.y, b.x, b.y, b.z, c * s1 * d.eta2 * s2 * (one - s2) * s3 * i2);
-        L.pair_force(A.x, A.y, ee.x, ee.y, ee.z, -c * s1 * s2 * d.eta2 * s3 * (one - s3) * i3);
+        pap_pair<ENERGY>(d, L, d.acc[ent >> 16], d.don[ent & 0xffff], e);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }

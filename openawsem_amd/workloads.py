@@ -107,12 +107,13 @@ def build_2xov(quiet=True):
     return oa
 
 
-def build_synthetic(n_chains=122, seed=2026, spacing_nm=5.5, quiet=True):
+def build_synthetic(n_chains=122, seed=2026, spacing_nm=5.5, quiet=True, hbonds=False):
     """Synthetic multi-chain system of BASELINE.json configs[4]: `n_chains` copies of the 164-residue 2lzm chain
     (tests/golden/2lzm-openmmawsem.pdb: one of the reference's own test structures) on a jittered cubic lattice with
     random rigid rotations (seeded), 122 chains = 20008 residues / 118k atoms.  Terms: con, chain, chi, excl, rama,
     rama_proline, contact (with burial) -- the hydrogen-bond and fragment-memory terms are left out, as the config
-    says (contact/burial cell-list scaling)."""
+    says (contact/burial cell-list scaling); `hbonds=True` adds beta 1-3, P-AP 1-2 and the helical term (dense
+    nres x nres tables: meant for a few thousand residues)."""
     import numpy as np
     src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "2lzm-openmmawsem.pdb")
     atoms = [ln for ln in open(src) if ln.startswith("ATOM")]
@@ -145,6 +146,11 @@ def build_synthetic(n_chains=122, seed=2026, spacing_nm=5.5, quiet=True):
         oa.addForcesWithDefaultForceGroup([
             basicTerms.con_term(oa), basicTerms.chain_term(oa), basicTerms.chi_term(oa), basicTerms.excl_term(oa, periodic=False),
             basicTerms.rama_term(oa), basicTerms.rama_proline_term(oa), contactTerms.contact_term(oa)])
+        if hbonds:
+            from .functionTerms import hydrogenBondTerms as hb
+            oa.addForcesWithDefaultForceGroup([
+                hb.beta_term_1(oa), hb.beta_term_2(oa), hb.beta_term_3(oa), hb.helical_term(oa),
+                hb.pap_term_1(oa, ssweightFileName="__no_such_ssweight_file__"), hb.pap_term_2(oa, ssweightFileName="__no_such_ssweight_file__")])
     os.remove(path)
     return oa
 

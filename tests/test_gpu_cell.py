@@ -21,14 +21,13 @@ from tests.common import golden_system
 
 pytestmark = pytest.mark.gpu
 
-CELL_KINDS = ("harmonic", "chi", "rama", "excl", "contact", "fragment_memory", "debye_huckel", "helical", "membrane")
-
-
-def _without_hbonds(oa):
+def _full_system(oa):
+    """All 16 terms of the reference test (con, chain, chi, excl, rama x3, contact, beta x3, pap x2, helical, fragment memory, DH)."""
     s = System(oa.system.masses.copy())
     s.virtual_sites = dict(oa.system.virtual_sites)
-    s.forces = [f for f in oa.system.forces if f.kind in CELL_KINDS]
-    assert any(f.kind == "contact" for f in s.forces) and any(f.kind == "excl" for f in s.forces)
+    s.forces = list(oa.system.forces)
+    kinds = {f.kind for f in s.forces}
+    assert {"contact", "excl", "beta", "pap"} <= kinds, kinds
     return s
 
 
@@ -46,7 +45,7 @@ def _ctx(system, R, precision, cell, monkeypatch):
 @pytest.mark.parametrize("protein", ["1brs", "2lzm"])
 def test_cell_path_equals_resident_path(protein, precision, monkeypatch):
     oa, traj, _ = golden_system(protein)
-    system = _without_hbonds(oa)
+    system = _full_system(oa)
     frames = [0, 6, 11]
     a = _ctx(system, len(frames), precision, False, monkeypatch)
     b = _ctx(system, len(frames), precision, True, monkeypatch)
@@ -81,7 +80,7 @@ def test_cell_path_equals_resident_path(protein, precision, monkeypatch):
 @pytest.mark.parametrize("precision", [0, 1])
 def test_cell_neighbour_lists_equal_brute_force(precision, monkeypatch):
     oa, traj, _ = golden_system("1brs")
-    system = _without_hbonds(oa)
+    system = _full_system(oa)
     gpu = _ctx(system, 2, precision, True, monkeypatch)
     cpu = _capi.Context(awsem_oracle.load(), oa.natoms, 2, precision=precision)
     system.upload(cpu)
@@ -93,6 +92,11 @@ def test_cell_neighbour_lists_equal_brute_force(precision, monkeypatch):
             for skin in (0.0, 0.15, 0.4):
                 a, b = gpu.neighbors(kind, 0, replica, skin), cpu.neighbors(kind, 0, replica, skin)
                 assert len(b) > 20 and np.array_equal(a, b), f"kind {kind} replica {replica} skin {skin}: {len(a)} vs {len(b)}"
+    for kind, count in ((_capi.LIST_BETA, 3), (_capi.LIST_PAP, 2)):      # (acceptor, donor) pairs with a non-zero table entry
+        for index in range(count):
+            for skin in (0.0, 0.2):
+                a, b = gpu.neighbors(kind, index, 1, skin), cpu.neighbors(kind, index, 1, skin)
+                assert len(b) > 20 and np.array_equal(a, b), f"kind {kind} index {index} skin {skin}: {len(a)} vs {len(b)}"
     # an evaluation after a neighbour query rebuilds the lists with the standard cutoff
     e = gpu.energy_by_group()
     assert np.isfinite(e).all()
@@ -100,33 +104,50 @@ def test_cell_neighbour_lists_equal_brute_force(precision, monkeypatch):
 
 def test_cell_dynamics_tracks_resident_path(monkeypatch):
     oa, traj, _ = golden_system("1ubq")
-    system = _without_hbonds(oa)
+    system = _full_system(oa)
     T = np.array([300.0, 700.0])
     out = []
     for cell in (False, True):
         ctx = _ctx(system, 2, 1, cell, monkeypatch)     # fp64: differences are summation-order noise only
         ctx.set_positions(traj[2], replica=-1)
         ctx.set_velocities_to_temperature(T, 4)
-        for chunk in (30, 70):
+        for chunk in (30, 270):      # long enough for several list rebuilds at 700 K
             ctx.step(chunk, T, 0.002, 1.0, 21)
         ctx.synchronize()
         out.append((np.stack([ctx.get_positions(r) for r in range(2)]), np.stack([ctx.get_velocities(r) for r in range(2)])))
     assert np.abs(out[0][0][1] - traj[2]).max() > 0.05
-    assert np.abs(out[0][0] - out[1][0]).max() < 1e-9 and np.abs(out[0][1] - out[1][1]).max() < 1e-7
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-8 and np.abs(out[0][1] - out[1][1]).max() < 1e-6
 
 
-def test_hydrogen_bond_terms_are_refused_on_the_cell_path(monkeypatch):
+def test_hydrogen_bond_terms_need_the_excluded_volume_term_on_the_cell_path(monkeypatch):
+    """The rebuild test of the cell path watches the members of the contact / excluded-volume lists (CA, CB, O)."""
     oa, _, _ = golden_system("1ubq")
+    s = System(oa.system.masses.copy())
+    s.virtual_sites = dict(oa.system.virtual_sites)
+    s.forces = [f for f in oa.system.forces if f.kind != "excl"]
     monkeypatch.setenv("AWSEM_FORCE_CELL", "1")
     ctx = _capi.Context(_capi.load_hip_library(), oa.natoms, 1)
-    with pytest.raises(_capi.AwsemError, match="hydrogen-bond terms"):
-        oa.system.upload(ctx)
+    with pytest.raises(_capi.AwsemError, match="excluded-volume term"):
+        s.upload(ctx)
+
+
+@pytest.mark.parametrize("protein", ["1ubq", "1brs"])
+def test_cell_path_reproduces_the_golden_energies_with_all_terms(protein, monkeypatch):
+    """The reference's own fixture (tests/data/<p>_energies.csv) through the cell-list path in fp64 mode."""
+    from tests.common import COLUMNS, FORCE_GROUP
+    oa, traj, golden = golden_system(protein)
+    ctx = _ctx(_full_system(oa), len(traj), 1, True, monkeypatch)
+    for r in range(len(traj)):
+        ctx.set_positions(traj[r], replica=r)
+    e = ctx.energy_by_group()
+    for c in COLUMNS:
+        assert np.abs(e[:, FORCE_GROUP[c]] - golden[c]).max() <= 1e-5, c
 
 
 def test_synthetic_multichain_system_takes_the_cell_path():
-    """~2600 residues (16 chains): too large for LDS, small enough for the O(N^2) oracle in seconds."""
+    """~2600 residues (16 chains) with the hydrogen-bond terms: too large for LDS, small enough for the O(N^2) oracle in seconds."""
     with contextlib.redirect_stdout(io.StringIO()):
-        oa = workloads.build_synthetic(n_chains=16, seed=3)
+        oa = workloads.build_synthetic(n_chains=16, seed=3, hbonds=True)
     assert oa.nres == 16 * 164
     gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, 1, precision=0)
     oa.system.upload(gpu)
@@ -138,7 +159,11 @@ def test_synthetic_multichain_system_takes_the_cell_path():
     for kind in (_capi.LIST_EXCL, _capi.LIST_CONTACT):
         a, b = gpu.neighbors(kind, 0, 0, 0.15), cpu.neighbors(kind, 0, 0, 0.15)
         assert len(b) > 1000 and np.array_equal(a, b)
+    for kind, index in ((_capi.LIST_BETA, 1), (_capi.LIST_PAP, 0)):
+        a, b = gpu.neighbors(kind, index, 0, 0.2), cpu.neighbors(kind, index, 0, 0.2)
+        assert len(b) > 1000 and np.array_equal(a, b)
     eg, ec = gpu.energy_by_group(), cpu.energy_by_group()
+    assert abs(ec[0, 27]) > 100 and abs(ec[0, 28]) > 10      # beta and P-AP are at work
     assert (np.abs(eg - ec) / np.maximum(np.abs(ec), 1.0)).max() <= 1e-4
     fg, fc = gpu.forces(), cpu.forces()
     assert np.linalg.norm(fg - fc) <= 1e-3 * np.linalg.norm(fc)
