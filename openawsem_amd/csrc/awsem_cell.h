@@ -527,10 +527,11 @@ template <class real> __device__ inline CellView<real> cell_view_plain(const Cel
 template <bool ENERGY, class V> __device__ __forceinline__ void hb_pair(const BetaD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e) { beta_pair<ENERGY>(d, L, A, D, e); }
 template <bool ENERGY, class V> __device__ __forceinline__ void hb_pair(const PapD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e) { pap_pair<ENERGY>(d, L, A, D, e); }
 
-// grid (blocks, R)
-template <class real, class Desc> __global__ void cell_hb_rows_kernel(Desc d, CellSys<real> C, HbRows H, const real* __restrict__ pos, real rc2, int cur, int force) {
-    const int rep = blockIdx.y;
-    if (!cell_rebuild(C, rep, cur, force)) return;
+// All hydrogen-bond terms of a system go through ONE launch of each kernel (grid (blocks, R, terms)): their descriptors,
+// rows and list radii sit in device memory and are fetched with scalar loads (blockIdx.z is uniform).
+template <class real> struct HbTerms { const BetaD<real>* beta; const PapD<real>* pap; const HbRows* rows; const real* rc2; int n_beta, n_pap; };
+
+template <class real, class Desc> __device__ __forceinline__ void hb_rows_body(const Desc& d, const CellSys<real>& C, const HbRows& H, const real* __restrict__ pos, real rc2, int rep) {
     const size_t n = C.natoms;
     const real* p = pos + (size_t)rep * 3 * n;
     const int sub = threadIdx.x & (AWSEM_ROW - 1), row_in_wave = (threadIdx.x & 63) / AWSEM_ROW;
@@ -561,9 +562,16 @@ template <class real, class Desc> __global__ void cell_hb_rows_kernel(Desc d, Ce
         if (vi && sub == 0) H.row_count[(size_t)rep * d.nacc + k] = min(cnt, H.stride);
     }
 }
+template <class real> __global__ void cell_hb_rows_kernel(HbTerms<real> T, CellSys<real> C, const real* __restrict__ pos, int cur, int force) {
+    const int rep = blockIdx.y, t = blockIdx.z;
+    if (!cell_rebuild(C, rep, cur, force)) return;
+    const HbRows H = T.rows[t];
+    const real rc2 = T.rc2[t];
+    if (t < T.n_beta) { const BetaD<real> d = T.beta[t]; hb_rows_body(d, C, H, pos, rc2, rep); }
+    else { const PapD<real> d = T.pap[t - T.n_beta]; hb_rows_body(d, C, H, pos, rc2, rep); }
+}
 
-template <bool ENERGY, class real, class Desc> __global__ void cell_hb_eval_kernel(Desc d, CellSys<real> C, HbRows H, const real* __restrict__ pos) {
-    const int rep = blockIdx.y;
+template <bool ENERGY, class real, class Desc> __device__ __forceinline__ void hb_eval_body(const Desc& d, const CellSys<real>& C, const HbRows& H, const real* __restrict__ pos, int rep) {
     const CellView<real> L = cell_view_plain(C, pos, rep);
     const int sub = threadIdx.x & (AWSEM_ROW - 1);
     const unsigned* rows = H.rows + (size_t)rep * d.nacc * H.stride;
@@ -576,6 +584,12 @@ template <bool ENERGY, class real, class Desc> __global__ void cell_hb_eval_kern
         for (int s = sub; s < cnt; s += AWSEM_ROW) hb_pair<ENERGY>(d, L, A, d.don[rows[(size_t)k * H.stride + s]], e);
     }
     flush_energy<ENERGY>(L, d.group, e);
+}
+template <bool ENERGY, class real> __global__ void cell_hb_eval_kernel(HbTerms<real> T, CellSys<real> C, const real* __restrict__ pos, unsigned mask) {
+    const int rep = blockIdx.y, t = blockIdx.z;
+    const HbRows H = T.rows[t];
+    if (t < T.n_beta) { const BetaD<real> d = T.beta[t]; if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, rep); }
+    else { const PapD<real> d = T.pap[t - T.n_beta]; if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, rep); }
 }
 
 // Bonded terms: one workgroup per 256 items of one term (job table built at finalize).

@@ -367,6 +367,9 @@ private:
     long long cell_rows_gen_ = 0;          // bumped whenever the neighbour rows are re-allocated (captured graphs hold their addresses)
     HbRows cell_hb_beta_[AWSEM_MAX_BETA] = {}, cell_hb_pap_[AWSEM_MAX_PAP] = {};   // donor rows of the hydrogen-bond terms
     real cell_hb_rc2_beta_[AWSEM_MAX_BETA] = {}, cell_hb_rc2_pap_[AWSEM_MAX_PAP] = {};
+    HbTerms<real> cell_hb_ = {};           // device-resident descriptor / rows / radius tables of all hydrogen-bond terms
+    int cell_hb_maxacc_ = 0;
+    void cell_hb_sync();                   // re-uploads the rows and radius tables after a change on the host
     int dsys_beta_n_ = 0, dsys_pap_n_ = 0, cell_nacc_beta_[AWSEM_MAX_BETA] = {}, cell_nacc_pap_[AWSEM_MAX_PAP] = {};   // known before dsys_ is set
     CellGraph cell_graph_[2];
     long long* cell_step_base_ = nullptr;
@@ -908,6 +911,13 @@ template <class real> void Engine<real>::cell_setup(DevSys<real>& S, const HostS
     for (int t = 0; t < S.n_beta; t++) { const double r = std::sqrt((double)S.beta[t].screen2) + 1.2 * skin_; cell_hb_rc2_beta_[t] = (real)(r * r); }
     for (int t = 0; t < S.n_pap; t++) { const double r = H.pap[t].cutoff + 1.2 * skin_; cell_hb_rc2_pap_[t] = (real)(r * r); }
     dsys_beta_n_ = S.n_beta; dsys_pap_n_ = S.n_pap;
+    cell_hb_ = HbTerms<real>{};
+    cell_hb_.n_beta = S.n_beta; cell_hb_.n_pap = S.n_pap;
+    if (S.n_beta) cell_hb_.beta = upload(std::vector<BetaD<real>>(S.beta, S.beta + S.n_beta));
+    if (S.n_pap) cell_hb_.pap = upload(std::vector<PapD<real>>(S.pap, S.pap + S.n_pap));
+    cell_hb_maxacc_ = 0;
+    for (int t = 0; t < S.n_beta; t++) cell_hb_maxacc_ = std::max(cell_hb_maxacc_, S.beta[t].nacc);
+    for (int t = 0; t < S.n_pap; t++) cell_hb_maxacc_ = std::max(cell_hb_maxacc_, S.pap[t].nacc);
     for (int t = 0; t < S.n_beta; t++) cell_nacc_beta_[t] = S.beta[t].nacc;
     for (int t = 0; t < S.n_pap; t++) cell_nacc_pap_[t] = S.pap[t].nacc;
     if (S.n_contact > 1 || S.n_excl > 1) throw std::string("cell-list path: at most one contact and one excluded-volume term");
@@ -980,6 +990,18 @@ template <class real> void Engine<real>::cell_setup(DevSys<real>& S, const HostS
     cell_jobs_ = upload(jobs);
     S.lists = nullptr; S.list_stride = 0; S.n_lists = 0; S.skin_half2 = C.skin_half2;
 }
+template <class real> void Engine<real>::cell_hb_sync() {
+    const int nb = dsys_beta_n_, np = dsys_pap_n_, n = nb + np;
+    if (!n) return;
+    std::vector<HbRows> rows(n);
+    std::vector<real> rc2(n);
+    for (int t = 0; t < nb; t++) { rows[t] = cell_hb_beta_[t]; rc2[t] = cell_hb_rc2_beta_[t]; }
+    for (int t = 0; t < np; t++) { rows[nb + t] = cell_hb_pap_[t]; rc2[nb + t] = cell_hb_rc2_pap_[t]; }
+    if (!cell_hb_.rows) { cell_hb_.rows = dalloc<HbRows>(n); cell_hb_.rc2 = dalloc<real>(n); }
+    HIP_TRY(hipStreamSynchronize(stream_));   // nothing in flight reads the tables while they change
+    HIP_TRY(hipMemcpy(const_cast<HbRows*>(cell_hb_.rows), rows.data(), n * sizeof(HbRows), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(const_cast<real*>(cell_hb_.rc2), rc2.data(), n * sizeof(real), hipMemcpyHostToDevice));
+}
 // neighbour rows: `cell_per_site_` entries per contact site, a quarter of that (at least 16) per excluded-volume atom
 template <class real> void Engine<real>::cell_alloc_lists() {
     CellSys<real>& C = cell_;
@@ -999,6 +1021,7 @@ template <class real> void Engine<real>::cell_alloc_lists() {
     };
     for (int t = 0; t < dsys_beta_n_; t++) hb_alloc(cell_hb_beta_[t], cell_nacc_beta_[t]);
     for (int t = 0; t < dsys_pap_n_; t++) hb_alloc(cell_hb_pap_[t], cell_nacc_pap_[t]);
+    cell_hb_sync();
     cell_rows_gen_++;
     cell_stale_ = true;
 }
@@ -1021,11 +1044,10 @@ template <class real> void Engine<real>::cell_refresh(const CellSys<real>& C) {
     hipLaunchKernelGGL(cell_scan_kernel<real>, dim3(AWSEM_CELL_MAXCELLS / 1024, 2 * nrep_), dim3(1024), 0, stream_, C, cur, force);
     hipLaunchKernelGGL(cell_fill_kernel<real>, gm, b, 0, stream_, C, cur, force);
     hipLaunchKernelGGL(cell_rows_kernel<real>, gr, b, 0, stream_, dsys_, C, cur, force);
-    auto hb_grid = [&](int nacc) { return dim3((unsigned)std::max(1LL, std::min(((long long)nacc * AWSEM_ROW + 255) / 256, 16384LL)), nrep_); };
-    for (int t = 0; t < dsys_.n_beta; t++)
-        hipLaunchKernelGGL((cell_hb_rows_kernel<real, BetaD<real>>), hb_grid(dsys_.beta[t].nacc), b, 0, stream_, dsys_.beta[t], C, cell_hb_beta_[t], pos_, cell_hb_rc2_beta_[t], cur, force);
-    for (int t = 0; t < dsys_.n_pap; t++)
-        hipLaunchKernelGGL((cell_hb_rows_kernel<real, PapD<real>>), hb_grid(dsys_.pap[t].nacc), b, 0, stream_, dsys_.pap[t], C, cell_hb_pap_[t], pos_, cell_hb_rc2_pap_[t], cur, force);
+    if (cell_hb_.n_beta + cell_hb_.n_pap) {
+        const dim3 gh((unsigned)std::max(1LL, std::min(((long long)cell_hb_maxacc_ * AWSEM_ROW + 255) / 256, 16384LL)), nrep_, cell_hb_.n_beta + cell_hb_.n_pap);
+        hipLaunchKernelGGL(cell_hb_rows_kernel<real>, gh, b, 0, stream_, cell_hb_, C, pos_, cur, force);
+    }
     HIP_TRY(hipGetLastError());
     cell_stale_ = false;
 }
@@ -1057,17 +1079,10 @@ template <class real> void Engine<real>::cell_forces_pass(bool energy, unsigned 
         }
         hipLaunchKernelGGL(cell_chain_kernel<real>, g, b, 0, stream_, S, C, pos_);
     }
-    for (int t = 0; t < S.n_beta; t++) {
-        if (!((mask >> S.beta[t].group) & 1u)) continue;
-        const dim3 g(row_blocks(S.beta[t].nacc), nrep_);
-        if (energy) hipLaunchKernelGGL((cell_hb_eval_kernel<true, real, BetaD<real>>), g, b, 0, stream_, S.beta[t], C, cell_hb_beta_[t], pos_);
-        else hipLaunchKernelGGL((cell_hb_eval_kernel<false, real, BetaD<real>>), g, b, 0, stream_, S.beta[t], C, cell_hb_beta_[t], pos_);
-    }
-    for (int t = 0; t < S.n_pap; t++) {
-        if (!((mask >> S.pap[t].group) & 1u)) continue;
-        const dim3 g(row_blocks(S.pap[t].nacc), nrep_);
-        if (energy) hipLaunchKernelGGL((cell_hb_eval_kernel<true, real, PapD<real>>), g, b, 0, stream_, S.pap[t], C, cell_hb_pap_[t], pos_);
-        else hipLaunchKernelGGL((cell_hb_eval_kernel<false, real, PapD<real>>), g, b, 0, stream_, S.pap[t], C, cell_hb_pap_[t], pos_);
+    if (cell_hb_.n_beta + cell_hb_.n_pap) {
+        const dim3 g(row_blocks(cell_hb_maxacc_), nrep_, cell_hb_.n_beta + cell_hb_.n_pap);
+        if (energy) hipLaunchKernelGGL((cell_hb_eval_kernel<true, real>), g, b, 0, stream_, cell_hb_, C, pos_, mask);
+        else hipLaunchKernelGGL((cell_hb_eval_kernel<false, real>), g, b, 0, stream_, cell_hb_, C, pos_, mask);
     }
     HIP_TRY(hipGetLastError());
 }
@@ -1191,6 +1206,7 @@ template <class real> int Engine<real>::cell_neighbors(int rep, int kind, int in
     if (hb) {
         r = (kind == AWSEM_LIST_BETA ? std::sqrt((double)dsys_.beta[index].screen2) : host_->pap[index].cutoff) + skin;
         *hb_rc2 = (real)(r * r);
+        cell_hb_sync();
     }
     for (int attempt = 0;; attempt++) {
         CellSys<real> C = cell_;
@@ -1207,13 +1223,14 @@ template <class real> int Engine<real>::cell_neighbors(int rep, int kind, int in
         HIP_TRY(hipMemcpy(&st, dstatus_, sizeof st, hipMemcpyDeviceToHost));
         if (!(st & 2)) break;
         HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
-        if (attempt >= 5) { if (hb) *hb_rc2 = hb_saved; throw std::string("cell-list path: neighbour rows keep overflowing"); }
+        if (attempt >= 5) { if (hb) { *hb_rc2 = hb_saved; cell_hb_sync(); } throw std::string("cell-list path: neighbour rows keep overflowing"); }
         cell_per_site_ *= 2;
         cell_alloc_lists();
     }
     std::vector<std::pair<int, int>> out;
     if (hb) {
         *hb_rc2 = hb_saved;
+        cell_hb_sync();
         const HbRows& Hb = kind == AWSEM_LIST_BETA ? cell_hb_beta_[index] : cell_hb_pap_[index];
         const int nacc = kind == AWSEM_LIST_BETA ? dsys_.beta[index].nacc : dsys_.pap[index].nacc;
         std::vector<int> cnt(nacc);
