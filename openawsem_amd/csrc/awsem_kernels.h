@@ -109,15 +109,18 @@ template <class real> struct ViewCommon {
 template <class real> struct Lds;
 
 // fp32 force accumulator: Q19.12 fixed point, x and y packed in one 64-bit word (x * 2^32 + sign-extended y; the
-// packed sums stay exact because integer addition commutes: y = low word, x = (sum - y) >> 32).
+// packed sums stay exact because integer addition commutes: y = low word, x = (sum - y) >> 32).  The xy words and the z
+// words live in two planes: an atomic of 64 lanes on consecutive atoms then touches consecutive banks (an array of
+// 16-byte {xy, z, pad} records put lanes l and l+8 of the 64-bit atomic, and l, l+8, l+16, l+24 of the 32-bit one, on
+// the same banks).
 #define AWSEM_F32_FORCE_SCALE 4096.0f
-struct alignas(16) FAcc32 { long long xy; int z; int pad; };
 __device__ __forceinline__ long long pack_xy(int X, int Y) { return ((long long)X << 32) + (long long)Y; }
 
 template <> struct Lds<float> : ViewCommon<float> {
     typedef float real_t;
     float4* p;       // positions (w unused)
-    FAcc32* f;       // force accumulators
+    long long* fxy;  // force accumulators: packed x, y  [natoms]
+    int* fz;         //                     z           [natoms] (directly behind fxy; 16 bytes per atom are reserved in all)
     float4* v;       // velocities (step kernel only)
     float4* ref;     // positions at the last pair-list build (step kernel only)
     __device__ __forceinline__ R3<float> pos(int a) const { const float4 q = p[a]; return R3<float>{q.x, q.y, q.z}; }
@@ -126,28 +129,28 @@ template <> struct Lds<float> : ViewCommon<float> {
     __device__ __forceinline__ void set_vel(int a, const R3<float>& r) const { v[a] = make_float4(r.x, r.y, r.z, 0.0f); }
     __device__ __forceinline__ R3<float> refpos(int a) const { const float4 q = ref[a]; return R3<float>{q.x, q.y, q.z}; }
     __device__ __forceinline__ void set_ref(int a, const R3<float>& r) const { ref[a] = make_float4(r.x, r.y, r.z, 0.0f); }
-    __device__ __forceinline__ void zero_force(int a) const { *(int4*)&f[a] = make_int4(0, 0, 0, 0); }
+    __device__ __forceinline__ void zero_force(int a) const { fxy[a] = 0; fz[a] = 0; }
     // the accumulators are all zero while the pair lists are (re)built: 16 bytes per atom of scratch for the builders
-    __device__ __forceinline__ unsigned* scratch() const { return (unsigned*)f; }
+    __device__ __forceinline__ unsigned* scratch() const { return (unsigned*)fxy; }
     __device__ __forceinline__ R3<float> force(int a) const {
-        const int4 q = *(const int4*)&f[a];   // {xy.lo, xy.hi, z, pad}
+        const int2 q = *(const int2*)&fxy[a];   // {xy.lo, xy.hi}
         const int y = q.x, x = q.y + (int)((unsigned)y >> 31);   // undo the borrow of a negative y
         const float s = 1.0f / AWSEM_F32_FORCE_SCALE;
-        return R3<float>{(float)x * s, (float)y * s, (float)q.z * s};
+        return R3<float>{(float)x * s, (float)y * s, (float)fz[a] * s};
     }
     __device__ __forceinline__ void add_force(int a, float x, float y, float z) const {
         const float s = AWSEM_F32_FORCE_SCALE;
-        fixed_add((u64*)&f[a].xy, (u64)pack_xy(__float2int_rn(x * s), __float2int_rn(y * s)));
-        fixed_add(&f[a].z, __float2int_rn(z * s));
+        fixed_add((u64*)&fxy[a], (u64)pack_xy(__float2int_rn(x * s), __float2int_rn(y * s)));
+        fixed_add(&fz[a], __float2int_rn(z * s));
     }
-    __device__ __forceinline__ void add_fz(int a, float z) const { fixed_add(&f[a].z, __float2int_rn(z * AWSEM_F32_FORCE_SCALE)); }
+    __device__ __forceinline__ void add_fz(int a, float z) const { fixed_add(&fz[a], __float2int_rn(z * AWSEM_F32_FORCE_SCALE)); }
     // force of a pair potential: d = x_i - x_j, s = -dE/dr / r; +F on i, the bit-identical -F on j
     __device__ __forceinline__ void pair_force(int i, int j, float dx, float dy, float dz, float s) const {
         const float t = s * AWSEM_F32_FORCE_SCALE;
         const int Z = __float2int_rn(t * dz);
         const u64 XY = (u64)pack_xy(__float2int_rn(t * dx), __float2int_rn(t * dy));
-        fixed_add((u64*)&f[i].xy, XY); fixed_add(&f[i].z, Z);
-        fixed_sub((u64*)&f[j].xy, XY); fixed_sub(&f[j].z, Z);
+        fixed_add((u64*)&fxy[i], XY); fixed_add(&fz[i], Z);
+        fixed_sub((u64*)&fxy[j], XY); fixed_sub(&fz[j], Z);
     }
 };
 
@@ -1032,7 +1035,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void evaluate_terms(c
 
 // ------------------------------------------------------------------ LDS carve-up
 template <class real> struct LdsLayout;
-template <> struct LdsLayout<float> { static constexpr int pos = 16, force = 16, vel = 16, ref = 16; };      // float4, FAcc32, float4, float4
+template <> struct LdsLayout<float> { static constexpr int pos = 16, force = 16, vel = 16, ref = 16; };      // float4, {xy plane, z plane, pad}, float4, float4
 template <> struct LdsLayout<double> { static constexpr int pos = 24, force = 24, vel = 24, ref = 24; };     // three 8-byte planes each
 // what sizes the LDS image of a replica: velocities exist for the massive particles only (indexed by their position in
 // DevSys::massive), the gamma staging holds one environment (1200) or both (2400, z-dependent contact)
@@ -1073,7 +1076,7 @@ __device__ inline Lds<float> carve_lds(float, unsigned char* base, const LdsShap
     const int natoms = sh.natoms;
     unsigned char* q = base;
     L.p = (float4*)q; q += (size_t)16 * natoms;
-    L.f = (FAcc32*)q; q += (size_t)16 * natoms;
+    L.fxy = (long long*)q; L.fz = (int*)(q + (size_t)8 * natoms); q += (size_t)16 * natoms;
     L.v = nullptr; L.ref = nullptr;
     if (with_vel) { L.v = (float4*)q; q += (size_t)16 * sh.nmassive; L.ref = (float4*)q; q += (size_t)16 * natoms; }
     carve_common<float>(L, q, sh);
