@@ -67,6 +67,7 @@ class ReplicaExchange:
         velocity scale factors sqrt(T_new/T_old) of the local replicas."""
         U = all_gather_energies(np.asarray(local_energies, dtype=np.float64), self.world, self.device)
         assert len(U) == self.n
+        self.last_energies = U             # every replica's potential energy at this exchange (replicated on every rank)
         beta = 1.0 / (KB * self.T)
         holder = np.argsort(self.slot)         # ladder index -> replica
         old_T = self.T[self.slot].copy()

@@ -150,3 +150,34 @@ def test_awsem_run_anneals_an_ensemble_and_writes_the_reference_files(tmp_path, 
     sim2 = mm_run.main(["1r69", "--to", str(tmp_path / "run1"), "-s", "400", "-m", "0", "--tempStart", "300", "--replicas", "8",
                         "--fromCheckPoint", str(out / "checkpnt.chk"), "-f", os.path.join(os.path.dirname(mm_run.__file__), "forces_setup.py")])
     assert sim2.currentStep == 2000 + 400
+
+
+def test_awsem_remd_runs_a_ladder_and_restarts(tmp_path, monkeypatch):
+    """mm_remd.py of the reference delegates to openmmtools (absent here; its output.nc is not reproduced): outputs are
+    checked for shape, label bookkeeping and restart ("parity unpinned"; the Metropolis rule itself is tested in test_ensemble.py)."""
+    from openawsem_amd.scripts import mm_remd, mm_run
+    src = data_path.data / "1r69"
+    d = tmp_path / "1r69"
+    shutil.copytree(src, d, ignore=shutil.ignore_patterns("fraglib", "frags.mem"))
+    shutil.copy(d / "1r69.fasta", d / "crystal_structure.fasta")
+    seq = "".join(ln.strip() for ln in open(d / "1r69.fasta") if not ln.startswith(">"))
+    (d / "charge.txt").write_text("".join(f"{i} {1.0 if a in 'RK' else (-1.0 if a in 'DE' else 0.0)}\n" for i, a in enumerate(seq)))
+    forces = os.path.join(os.path.dirname(mm_run.__file__), "forces_setup.py")
+    monkeypatch.chdir(d)
+    out = tmp_path / "remd0"
+    remd = mm_remd.main(["1r69", "--to", str(out), "--replicas", "8", "--tempStart", "300", "--tempEnd", "500", "-x", "100",
+                         "--iterations", "12", "--timeStep", "2", "--reportFrequency", "4", "-f", forces])
+    with np.load(out / "output.npz") as z:
+        assert z["energies"].shape == (12, 8) and np.isfinite(z["energies"]).all()
+        assert np.allclose(z["temperatures"], np.linspace(300, 500, 8))
+        assert all(sorted(row) == list(range(8)) for row in z["ladder_index"])      # a permutation of the ladder after every sweep
+        assert z["attempted"].sum() == 12 * 4 - 6 and 0 < z["accepted"].sum() <= z["attempted"].sum()   # 4 even pairs, 3 odd pairs
+    with np.load(out / "replicas_rank0.npz") as z:
+        assert z["frames"].shape == (3, 8, 368, 3) and z["positions"].shape == (8, 368, 3)
+        assert int(z["iteration"]) == 12 and int(z["step_count"]) == 1200
+        # hotter replicas move further from the common start
+        assert np.abs(z["positions"][0] - z["positions"][1]).max() > 1e-3
+    monkeypatch.chdir(d)
+    remd2 = mm_remd.main(["1r69", "--to", str(tmp_path / "remd1"), "--replicas", "8", "--tempStart", "300", "--tempEnd", "500", "-x", "100",
+                          "--iterations", "4", "--timeStep", "2", "--fromCheckPoint", str(out), "-f", forces])
+    assert remd2.iteration == 16 and remd2.attempted.sum() > remd.attempted.sum() - 1
