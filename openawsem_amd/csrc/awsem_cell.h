@@ -706,7 +706,7 @@ __global__ void cell_integrate_kernel(DevSys<real> S, CellSys<real> C, real* __r
             F.x += gi.w[q] * fv.x; F.y += gi.w[q] * fv.y; F.z += gi.w[q] * fv.z;
         }
         real g[3];
-        gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step, i, g);
+        gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step, mi.id, g);
         const real im = fs * mi.inv_mass, sq = ns * mi.sqrt_inv_mass;
         const real vx = a * v[i] + im * F.x + sq * g[0];
         const real vy = a * v[n + i] + im * F.y + sq * g[1];

@@ -38,7 +38,7 @@ template <class real> struct HelicalItem { int o, n, h; real coef; };
 template <class real> struct DhItem { int i, j; real qq, pad; };
 template <class real> struct GaussItem { int i, j; real r0, a, c; };   // a = 1/(2 sigma^2), c = k gamma (bond value g = -c exp(-a (r-r0)^2), or c r^2)
 template <class real> struct MembItem { int atom; real scale; };
-template <class real> struct alignas(16) MassiveItem { int atom; real inv_mass, sqrt_inv_mass, pad; };
+template <class real> struct alignas(16) MassiveItem { int atom; real inv_mass, sqrt_inv_mass; int id; };   // id: the caller's index of the atom (random streams are keyed by it)
 // the virtual sites a massive particle parents (-1 padded) and its weight in each: the step kernel gathers their forces
 #define AWSEM_MAX_GATHER 8
 template <class real> struct alignas(16) GatherItem { int vs[AWSEM_MAX_GATHER]; real w[AWSEM_MAX_GATHER]; };
@@ -124,6 +124,7 @@ template <class real> struct DevSys {
     int nmassive;
     int nfixed;                           // massless particles that are not virtual sites (they never move)
     const int* fixed;
+    const int* orig;                      // internal atom index -> the caller's (null: identical); see Engine::finalize
     int n_harm, n_chi, n_rama, n_excl, n_contact, n_beta, n_pap, n_helical, n_fm, n_memb, n_dh, n_gauss;
     HarmD<real> harm[AWSEM_MAX_HARM]; ChiD<real> chi[AWSEM_MAX_CHI]; RamaD<real> rama[AWSEM_MAX_RAMA];
     ExclD<real> excl[AWSEM_MAX_EXCL]; ContactD<real> contact[AWSEM_MAX_CONTACT]; BetaD<real> beta[AWSEM_MAX_BETA];

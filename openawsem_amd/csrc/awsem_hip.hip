@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -223,7 +224,7 @@ public:
             const double* src = pass ? v : xyz;
             if (!src) continue;
             for (int r = 0; r < nrep_; r++) for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++)
-                t[r * n3 + (size_t)k * natoms_ + i] = (real)src[r * n3 + 3 * (size_t)i + k];
+                t[r * n3 + (size_t)k * natoms_ + in_(i)] = (real)src[r * n3 + 3 * (size_t)i + k];
             HIP_TRY(hipMemcpy(pass ? vel_ : pos_, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
             if (!pass) cell_stale_ = true;
         }
@@ -238,7 +239,7 @@ public:
             if (!dst) continue;
             HIP_TRY(hipMemcpy(t.data(), pass ? vel_ : pos_, t.size() * sizeof(real), hipMemcpyDeviceToHost));
             for (int r = 0; r < nrep_; r++) for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++)
-                dst[r * n3 + 3 * (size_t)i + k] = (double)t[r * n3 + (size_t)k * natoms_ + i];
+                dst[r * n3 + 3 * (size_t)i + k] = (double)t[r * n3 + (size_t)k * natoms_ + in_(i)];
         }
     }
     void synchronize() override {
@@ -314,7 +315,7 @@ private:
     void set_state(real* dst, int rep, const double* src) {
         HIP_TRY(hipSetDevice(device_));
         std::vector<real> t((size_t)3 * natoms_);
-        for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++) t[(size_t)k * natoms_ + i] = (real)src[3 * i + k];
+        for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++) t[(size_t)k * natoms_ + in_(i)] = (real)src[3 * i + k];
         HIP_TRY(hipStreamSynchronize(stream_));
         int r0 = rep < 0 ? 0 : rep, r1 = rep < 0 ? nrep_ : rep + 1;
         for (int r = r0; r < r1; r++)
@@ -325,7 +326,7 @@ private:
         HIP_TRY(hipStreamSynchronize(stream_));
         std::vector<real> t((size_t)3 * natoms_);
         HIP_TRY(hipMemcpy(t.data(), src + (size_t)rep * 3 * natoms_, t.size() * sizeof(real), hipMemcpyDeviceToHost));
-        for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++) dst[3 * i + k] = (double)t[(size_t)k * natoms_ + i];
+        for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++) dst[3 * i + k] = (double)t[(size_t)k * natoms_ + in_(i)];
     }
 
     int natoms_, nrep_, device_;
@@ -344,7 +345,10 @@ private:
     DevSys<real> dsys_;
     real *pos_ = nullptr, *vel_ = nullptr;
     double *dT_ = nullptr, *dE_ = nullptr, *dF_ = nullptr;
-    const HostSystem* host_ = nullptr;   // owned by the handle, outlives the engine
+    const HostSystem* host_ = nullptr;   // the system as the kernels see it: the handle's, or hint_ when the atoms are renumbered
+    HostSystem hint_;                    // the handle's system in the internal atom order (replica-resident path)
+    std::vector<int> to_int_, to_orig_;  // caller's atom index <-> internal (empty: identical)
+    int in_(int i) const { return to_int_.empty() ? i : to_int_[i]; }
     int* dstatus_ = nullptr;
     int* dmin_it_ = nullptr;
     double* dmin_rms_ = nullptr;
@@ -445,9 +449,55 @@ static std::vector<unsigned> nonzero_mask(const std::vector<double>& t, int nres
     return m;
 }
 
-template <class real> void Engine<real>::finalize(const HostSystem& H) {
+// Internal atom order of the replica-resident path.  A factory numbers atoms residue by residue (N, H, CA, C, O, CB: a
+// stride of ~6), so the 64 lanes of an instruction that touches "the CB of 64 consecutive residues" hit only a quarter of
+// the LDS banks with the 16-byte position records (and the pair lists are built exactly so that their lanes do walk
+// consecutive sites).  Internally the atoms are therefore grouped by ROLE -- excluded-volume class, and for virtual sites
+// the weight triple that places them -- and kept in the caller's order within a role: CA block, CB block, O block, N, H,
+// C blocks.  Consecutive residues are then consecutive LDS records.  The caller never sees this order: positions,
+// velocities, forces and neighbour queries are mapped at the API boundary, and the random streams are keyed by the
+// caller's atom index.
+static std::vector<int> role_order(const HostSystem& H) {
+    const int n = H.natoms;
+    std::vector<long long> key(n, 0);
+    if (!H.excl.empty()) for (size_t i = 0; i < H.excl[0].atom.size(); i++) key[H.excl[0].atom[i]] = 1 + H.excl[0].cls[i];
+    std::vector<std::array<long long, 3>> seen;   // distinct weight triples, in order of first appearance
+    for (size_t v = 0; v < H.vs_site.size(); v++) {
+        std::array<long long, 3> w = {llround(H.vs_w[3 * v] * 1e6), llround(H.vs_w[3 * v + 1] * 1e6), llround(H.vs_w[3 * v + 2] * 1e6)};
+        size_t id = 0;
+        while (id < seen.size() && seen[id] != w) id++;
+        if (id == seen.size()) seen.push_back(w);
+        key[H.vs_site[v]] = 1000 + (long long)id;
+    }
+    std::vector<int> order(n), to(n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+    for (int k = 0; k < n; k++) to[order[k]] = k;
+    return to;
+}
+static HostSystem renumbered(const HostSystem& H, const std::vector<int>& to) {
+    HostSystem R = H;
+    auto m = [&](std::vector<int>& v) { for (int& a : v) if (a >= 0) a = to[a]; };
+    for (int i = 0; i < H.natoms; i++) R.mass[to[i]] = H.mass[i];
+    m(R.vs_site); m(R.vs_par);
+    for (auto& t : R.harm) m(t.pairs);
+    for (auto& t : R.chi) m(t.atoms);
+    for (auto& t : R.rama) m(t.atoms);
+    for (auto& t : R.excl) { m(t.atom); m(t.excl); }
+    for (auto& t : R.contact) m(t.atom);
+    for (auto& t : R.beta) { m(t.acc_atoms); m(t.don_atoms); }
+    for (auto& t : R.pap) { m(t.acc_atoms); m(t.don_atoms); }
+    for (auto& t : R.helical) m(t.atoms);
+    for (auto& t : R.fm) m(t.pairs);
+    for (auto& t : R.memb) m(t.atoms);
+    for (auto& t : R.dh) m(t.pairs);
+    for (auto& t : R.gauss) m(t.pairs);
+    return R;
+}
+
+template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     HIP_TRY(hipSetDevice(device_));
-    host_ = &H;
+    host_ = &H0;
     DevSys<real> S;
     memset(&S, 0, sizeof S);
     S.natoms = natoms_;
@@ -458,12 +508,27 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         if (prop.maxSharedMemoryPerMultiProcessor > lds_max) lds_max = prop.maxSharedMemoryPerMultiProcessor;
         lds_max_ = lds_max;
         int max_sites = 0;
-        for (auto& h : H.contact) max_sites = std::max(max_sites, (int)h.atom.size());
+        for (auto& h : H0.contact) max_sites = std::max(max_sites, (int)h.atom.size());
         const char* force = getenv("AWSEM_FORCE_CELL");
         bool zdep = false;
-        for (auto& h : H.contact) zdep = zdep || (h.flags & AWSEM_CONTACT_ZDEP);
-        cell_mode_ = lds_bytes<real>(LdsShape{natoms_, max_sites, (int)H.contact.size(), 0, zdep ? 2400 : 1200, 0}, false) > lds_max || (force && atoi(force) != 0);
+        for (auto& h : H0.contact) zdep = zdep || (h.flags & AWSEM_CONTACT_ZDEP);
+        cell_mode_ = lds_bytes<real>(LdsShape{natoms_, max_sites, (int)H0.contact.size(), 0, zdep ? 2400 : 1200, 0}, false) > lds_max || (force && atoi(force) != 0);
     }
+    to_int_.clear(); to_orig_.clear();
+    if (!cell_mode_ && !(getenv("AWSEM_NO_REORDER") && atoi(getenv("AWSEM_NO_REORDER")) != 0)) {   // the cell path's windows want the chain order
+        to_int_ = role_order(H0);
+        bool identity = true;
+        for (int i = 0; i < natoms_; i++) identity = identity && to_int_[i] == i;
+        if (identity) to_int_.clear();
+        else {
+            to_orig_.assign(natoms_, 0);
+            for (int i = 0; i < natoms_; i++) to_orig_[to_int_[i]] = i;
+            hint_ = renumbered(H0, to_int_);
+            host_ = &hint_;
+            S.orig = upload(to_orig_);
+        }
+    }
+    const HostSystem& H = *host_;
     // Item order of the static lists.  Replica-resident path: conflict-aware (spread_order).  Cell-list path: by window of
     // AWSEM_WIN atoms (the window kernel accumulates a window's items in LDS); items spanning more than a window's LDS
     // span go last and take the direct path.
@@ -497,7 +562,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H) {
         S.inv_mass = upload(im);
         S.sqrt_inv_mass = upload(sim);
         std::vector<MassiveItem<real>> mv;
-        for (int i = 0; i < natoms_; i++) if (H.mass[i] > 0) mv.push_back(MassiveItem<real>{i, im[i], sim[i], (real)0});
+        for (int i = 0; i < natoms_; i++) if (H.mass[i] > 0) mv.push_back(MassiveItem<real>{i, im[i], sim[i], to_orig_.empty() ? i : to_orig_[i]});
         S.massive = upload(mv);
         S.nmassive = (int)mv.size();
         S.nvs = (int)H.vs_site.size();
@@ -896,6 +961,7 @@ template <class real> int Engine<real>::neighbors(int rep, int kind, int index, 
     for (unsigned k = 0; k < n; k++) {
         if (kind == AWSEM_LIST_CONTACT) out[k] = {(int)(e[k] & 0x3ff), (int)((e[k] >> 10) & 0x3ff)};
         else out[k] = {(int)(e[k] >> 16), (int)(e[k] & 0xffff)};
+        if (kind == AWSEM_LIST_EXCL && !to_orig_.empty()) out[k] = {to_orig_[out[k].first], to_orig_[out[k].second]};
         if (kind == AWSEM_LIST_EXCL && out[k].first > out[k].second) std::swap(out[k].first, out[k].second);
     }
     std::sort(out.begin(), out.end());

@@ -1127,7 +1127,8 @@ __global__ void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__
         double* f = f_out + (size_t)rep * 3 * natoms;
         for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
             const R3<real> F = L.force(i);
-            f[3 * i] = (double)F.x; f[3 * i + 1] = (double)F.y; f[3 * i + 2] = (double)F.z;
+            const int o = S.orig ? S.orig[i] : i;
+            f[3 * o] = (double)F.x; f[3 * o + 1] = (double)F.y; f[3 * o + 2] = (double)F.z;
         }
     }
     if (ENERGY && e_out && threadIdx.x < AWSEM_NGROUPS) e_out[(size_t)rep * AWSEM_NGROUPS + threadIdx.x] = fixed_to_double(L.eg[threadIdx.x]);
@@ -1186,7 +1187,7 @@ __global__ void awsem_maxwell_kernel(const DevSys<real> S, real* __restrict__ ve
     for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
         real g[3] = {0, 0, 0}, s = 0;
         if (S.inv_mass[i] != (real)0) {
-            gauss3<real>(seed, AWSEM_STREAM_VEL, rep, 0, i, g);
+            gauss3<real>(seed, AWSEM_STREAM_VEL, rep, 0, S.orig ? S.orig[i] : i, g);
             s = (real)::sqrt(AWSEM_KB * T[rep]) * S.sqrt_inv_mass[i];
         }
         v[i] = s * g[0]; v[natoms + i] = s * g[1]; v[2 * natoms + i] = s * g[2];
@@ -1302,7 +1303,7 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
                     F.x += gi.w[q] * fv.x; F.y += gi.w[q] * fv.y; F.z += gi.w[q] * fv.z;
                 }
                 real g[3];
-                gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, i, g);
+                gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, mi.id, g);
                 const real im = fs * mi.inv_mass, sq = ns * mi.sqrt_inv_mass;
                 R3<real> v = L.vel(k), x = L.pos(i);
                 v.x = a * v.x + im * F.x + sq * g[0];
