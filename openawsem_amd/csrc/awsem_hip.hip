@@ -256,6 +256,11 @@ private:
         allocs_.push_back(p);
         return (T*)p;
     }
+    void dfree(const void* p) {   // for buffers that are re-allocated during a run (neighbour rows); the stream must be idle
+        if (!p) return;
+        auto it = std::find(allocs_.begin(), allocs_.end(), (void*)p);
+        if (it != allocs_.end()) { allocs_.erase(it); (void)hipFree((void*)p); }
+    }
     template <class T> const T* upload(const std::vector<T>& v) {
         T* p = dalloc<T>(v.size());
         if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -1076,12 +1081,14 @@ template <class real> void Engine<real>::cell_alloc_lists() {
     for (int b = 0; b < 2; b++) {
         const size_t n = (size_t)std::max(1, C.bin[b].n) * C.bin[b].stride;
         if (n > 0x7fffffffULL) throw std::string("cell-list path: neighbour rows exceed 2^31 entries per replica");
+        if (C.bin[b].rows) { HIP_TRY(hipStreamSynchronize(stream_)); dfree(C.bin[b].rows); }
         C.bin[b].rows = dalloc<unsigned>(n * nrep_);
     }
     auto hb_alloc = [&](HbRows& Hb, int nacc) {
         Hb.stride = C.bin[0].stride;
         const size_t n = (size_t)std::max(1, nacc) * Hb.stride;
         if (n > 0x7fffffffULL) throw std::string("cell-list path: hydrogen-bond rows exceed 2^31 entries per replica");
+        if (Hb.rows) { HIP_TRY(hipStreamSynchronize(stream_)); dfree(Hb.rows); }
         Hb.rows = dalloc<unsigned>(n * nrep_);
         if (!Hb.row_count) { Hb.row_count = dalloc<int>((size_t)std::max(1, nacc) * nrep_); HIP_TRY(hipMemset(Hb.row_count, 0, (size_t)std::max(1, nacc) * nrep_ * sizeof(int))); }
     };
