@@ -103,7 +103,15 @@ template <class real> struct PapD {
 template <class real> struct HelicalD { int group, n; const HelicalItem<real>* items; real r_ON, r_OH, inv_sNO2, inv_sHO2; };
 // table2[b][i] = (t[b][i], t[b][i+1]) for i < ntab-1: the two interpolation nodes of a bin in one aligned load
 // pairs[b] = atom_i | atom_j << 16 on the replica-resident path (atoms < 65536); pairs2 = (atom_i, atom_j) for the cell path
-template <class real> struct FmD { int group, n, ntab; const unsigned* pairs; const int* pairs2; const real2_t<real>* table2; real k, dr, inv_dr; };
+// Replica-resident path: the bonds are grouped into BUNDLES of up to AWSEM_FM_BUNDLE bonds that share one atom (the
+// "owner": the lower-numbered end); one lane takes a bundle, keeps the owner's force in integer registers and adds it once.
+// bundles[k] = (owner | count << 16, first bond); partners[u * nb_pad + k] = the other end of the bundle's bond u.
+#define AWSEM_FM_BUNDLE 7
+struct FmBundle { unsigned head, first; };
+template <class real> struct FmD {
+    int group, n, ntab; const unsigned* pairs; const int* pairs2; const real2_t<real>* table2; real k, dr, inv_dr;
+    const FmBundle* bundles; const unsigned* partners; int nbundles, nb_pad;
+};
 template <class real> struct MembD { int group, n; const MembItem<real>* items; real k, k_m2, z_m, center; };
 template <class real> struct DhD { int group, n; const DhItem<real>* items; real k, inv_lam; };
 // A sum of bond values S = sum_b g_b(r_b) and an energy E = f(S):

@@ -782,7 +782,34 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         std::vector<FmD<real>> D;
         for (auto& h : H.fm) {
             const int nb = (int)(h.pairs.size() / 2);
-            const std::vector<int> perm = item_order(nb, 2, h.pairs.data());
+            std::vector<int> perm;
+            std::vector<FmBundle> bundles;
+            std::vector<unsigned> partners;
+            int nb_pad = 0;
+            if (!cell_mode_ && natoms_ <= 65535 && !(getenv("AWSEM_FM_BUNDLES") && atoi(getenv("AWSEM_FM_BUNDLES")) == 0)) {
+                // bundles: the bonds of an atom towards higher-numbered partners, cut into chunks of AWSEM_FM_BUNDLE; all first
+                // chunks come before all second chunks, so that neighbouring lanes own neighbouring atoms
+                std::vector<std::vector<std::pair<int, int>>> of(natoms_);   // owner -> (partner, bond)
+                for (int b = 0; b < nb; b++) {
+                    const int i = h.pairs[2 * b], j = h.pairs[2 * b + 1];
+                    of[std::min(i, j)].push_back({std::max(i, j), b});
+                }
+                size_t maxdeg = 0;
+                for (auto& v : of) { std::sort(v.begin(), v.end()); maxdeg = std::max(maxdeg, v.size()); }
+                struct Chunk { int owner, lo, hi; };
+                std::vector<Chunk> chunks;
+                for (size_t c = 0; c * AWSEM_FM_BUNDLE < maxdeg; c++)
+                    for (int a = 0; a < natoms_; a++)
+                        if (of[a].size() > c * AWSEM_FM_BUNDLE) chunks.push_back(Chunk{a, (int)(c * AWSEM_FM_BUNDLE), (int)std::min(of[a].size(), (c + 1) * AWSEM_FM_BUNDLE)});
+                nb_pad = ((int)chunks.size() + 63) & ~63;
+                partners.assign((size_t)AWSEM_FM_BUNDLE * std::max(nb_pad, 1), 0u);
+                for (size_t k = 0; k < chunks.size(); k++) {
+                    const Chunk& c = chunks[k];
+                    bundles.push_back(FmBundle{(unsigned)c.owner | ((unsigned)(c.hi - c.lo) << 16), (unsigned)perm.size()});
+                    for (int u = 0; u < AWSEM_FM_BUNDLE; u++) partners[(size_t)u * nb_pad + k] = (unsigned)of[c.owner][c.lo + (c.lo + u < c.hi ? u : 0)].first;
+                    for (int q = c.lo; q < c.hi; q++) perm.push_back(of[c.owner][q].second);
+                }
+            } else perm = item_order(nb, 2, h.pairs.data());
             std::vector<real2_t<real>> t2((size_t)nb * (h.ntab - 1));
             for (int b = 0; b < nb; b++) for (int i = 0; i + 1 < h.ntab; i++)
                 t2[(size_t)b * (h.ntab - 1) + i] = real2_t<real>{(real)h.table[(size_t)perm[b] * h.ntab + i], (real)h.table[(size_t)perm[b] * h.ntab + i + 1]};
@@ -790,7 +817,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
             std::vector<unsigned> packed(nb, 0u);
             if (natoms_ <= 65535) for (int b = 0; b < nb; b++) packed[b] = (unsigned)pp[2 * b] | ((unsigned)pp[2 * b + 1] << 16);
             if ((size_t)nb * (h.ntab - 1) >= (1ull << 31)) throw std::string("fragment memory: table too large (nbonds x ntab must stay below 2^31)");
-            D.push_back(FmD<real>{h.group, nb, h.ntab, upload(packed), upload(pp), upload(t2), (real)h.k, (real)h.dr, (real)(1.0 / h.dr)});
+            D.push_back(FmD<real>{h.group, nb, h.ntab, upload(packed), upload(pp), upload(t2), (real)h.k, (real)h.dr, (real)(1.0 / h.dr),
+                                  bundles.empty() ? nullptr : upload(bundles), partners.empty() ? nullptr : upload(partners), (int)bundles.size(), nb_pad});
         }
         if (D.size() > AWSEM_MAX_FM) throw std::string("too many fm terms: at most " + std::to_string(AWSEM_MAX_FM) + " per system");
         S.n_fm = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.fm[t] = D[t];

@@ -152,6 +152,18 @@ template <> struct Lds<float> : ViewCommon<float> {
         fixed_add((u64*)&fxy[i], XY); fixed_add(&fz[i], Z);
         fixed_sub((u64*)&fxy[j], XY); fixed_sub(&fz[j], Z);
     }
+    // the same with the +F of atom i collected in integer registers (exactly what the atomics would have summed) and
+    // added once by add_acc: for a lane that walks several bonds of one atom
+    struct acc_t { u64 xy; int z; };
+    static __device__ __forceinline__ acc_t acc_zero() { return acc_t{0, 0}; }
+    __device__ __forceinline__ void pair_force_owner(acc_t& A, int j, float dx, float dy, float dz, float s) const {
+        const float t = s * AWSEM_F32_FORCE_SCALE;
+        const int Z = __float2int_rn(t * dz);
+        const u64 XY = (u64)pack_xy(__float2int_rn(t * dx), __float2int_rn(t * dy));
+        A.xy += XY; A.z += Z;
+        fixed_sub((u64*)&fxy[j], XY); fixed_sub(&fz[j], Z);
+    }
+    __device__ __forceinline__ void add_acc(int i, const acc_t& A) const { fixed_add((u64*)&fxy[i], A.xy); fixed_add(&fz[i], A.z); }
 };
 
 // SoA coordinates and three Q31.32 accumulators per atom: the fp64 check mode (in LDS) and the cell-list path (in HBM)
@@ -172,6 +184,15 @@ template <class real> struct SoaOps {
         fixed_add(&fx[i], X); fixed_add(&fy[i], Y); fixed_add(&fz[i], Z);
         fixed_sub(&fx[j], X); fixed_sub(&fy[j], Y); fixed_sub(&fz[j], Z);
     }
+    struct acc_t { u64 x, y, z; };
+    static __device__ __forceinline__ acc_t acc_zero() { return acc_t{0, 0, 0}; }
+    __device__ __forceinline__ void pair_force_owner(acc_t& A, int j, real dx, real dy, real dz, real s) const {
+        const real t = s * (real)AWSEM_FIXED_SCALE;
+        const u64 X = to_fixed_scaled(t * dx), Y = to_fixed_scaled(t * dy), Z = to_fixed_scaled(t * dz);
+        A.x += X; A.y += Y; A.z += Z;
+        fixed_sub(&fx[j], X); fixed_sub(&fy[j], Y); fixed_sub(&fz[j], Z);
+    }
+    __device__ __forceinline__ void add_acc(int i, const acc_t& A) const { fixed_add(&fx[i], A.x); fixed_add(&fy[i], A.y); fixed_add(&fz[i], A.z); }
 };
 template <> struct Lds<double> : ViewCommon<double>, SoaOps<double> {
     typedef double real_t;
@@ -389,6 +410,46 @@ template <bool ENERGY, bool PACKED = true, class V> __device__ void term_fm(cons
     constexpr int U = 6;
     const unsigned stride = blockDim.x, n = (unsigned)d.n;
     for (unsigned b = (unsigned)rot_tid(rot); b < n; b += U * stride) fm_body<ENERGY, U, PACKED>(d, L, b, stride, e);
+    flush_energy<ENERGY>(L, d.group, e);
+}
+
+// Bundled walk (replica-resident path): one lane per bundle of <= AWSEM_FM_BUNDLE bonds around one owner atom.  The owner's
+// position is read once, its force is summed in integer registers (bit-identical to the atomics it replaces) and added once:
+// a third fewer LDS reads and atomics than bond-by-bond, all table gathers of the bundle in flight together.
+template <bool ENERGY, class V> __device__ void term_fm_bundled(const FmD<typename V::real_t>& d, const V& L, int rot = 0) {
+    typedef typename V::real_t real;
+    constexpr int K = AWSEM_FM_BUNDLE;
+    Energy e;
+    const unsigned nrow = (unsigned)d.ntab - 1u;
+    for (int k = rot_tid(rot); k < d.nbundles; k += blockDim.x) {
+        const FmBundle h = d.bundles[k];
+        const unsigned o = h.head & 0xffffu, cnt = h.head >> 16;
+        unsigned pj[K], i1[K];
+        real r[K], ir[K];
+        real2_t<real> v[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) pj[u] = d.partners[(unsigned)u * (unsigned)d.nb_pad + (unsigned)k];   // slots past the count repeat the first partner
+        const R3<real> po = L.pos(o);
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const R3<real> dd = po - L.pos(pj[u]);
+            const real r2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z;
+            ir[u] = M<real>::rsqrt(r2); r[u] = r2 * ir[u];
+            const unsigned bin = (unsigned)(int)(r[u] * d.inv_dr);   // r >= 0: truncation is floor
+            i1[u] = bin < nrow - 1u ? bin : nrow - 1u;
+            v[u] = d.table2[(h.first + ((unsigned)u < cnt ? (unsigned)u : 0u)) * nrow + i1[u]];   // (t[i], t[i+1]) in one load
+        }
+        typename V::acc_t A = V::acc_zero();
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            if ((unsigned)u >= cnt) continue;
+            const real slope = (v[u].y - v[u].x) * d.inv_dr;
+            if (ENERGY) e += (double)(-d.k * (v[u].x + slope * (r[u] - d.dr * (real)i1[u])));
+            const R3<real> dd = po - L.pos(pj[u]);   // read again rather than kept in registers across the gather
+            L.pair_force_owner(A, pj[u], dd.x, dd.y, dd.z, d.k * slope * ir[u]);
+        }
+        L.add_acc(o, A);
+    }
     flush_energy<ENERGY>(L, d.group, e);
 }
 
@@ -981,7 +1042,10 @@ template <bool ENERGY, class V> __device__ __forceinline__ void evaluate_terms(c
     Rotor rotor;
     // phase A
     if (c0) contact_density(*c0, L, satom0);
-    for (int u = 0; u < S.n_fm; u++) if (AWSEM_ON(S.fm[u])) term_fm<ENERGY>(S.fm[u], L, rotor.next(S.fm[u].n));
+    for (int u = 0; u < S.n_fm; u++) if (AWSEM_ON(S.fm[u])) {
+        if (S.fm[u].nbundles) term_fm_bundled<ENERGY>(S.fm[u], L, rotor.next(S.fm[u].nbundles));
+        else term_fm<ENERGY>(S.fm[u], L, rotor.next(S.fm[u].n));
+    }
     for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
     for (int u = 0; u < S.n_chi; u++) if (AWSEM_ON(S.chi[u])) term_chi<ENERGY>(S.chi[u], L, rotor.next(S.chi[u].n));
     for (int u = 0; u < S.n_gauss; u++) { const GaussD<real> d = S.gauss[u]; if (d.cv && AWSEM_ON(d)) cv_sum(d, L, rotor.next(d.n)); }
