@@ -181,3 +181,34 @@ def test_awsem_remd_runs_a_ladder_and_restarts(tmp_path, monkeypatch):
     remd2 = mm_remd.main(["1r69", "--to", str(tmp_path / "remd1"), "--replicas", "8", "--tempStart", "300", "--tempEnd", "500", "-x", "100",
                           "--iterations", "4", "--timeStep", "2", "--fromCheckPoint", str(out), "-f", forces])
     assert remd2.iteration == 16 and remd2.attempted.sum() > remd.attempted.sum() - 1
+
+
+def test_awsem_run_on_the_cell_list_path(tmp_path, monkeypatch):
+    """The same driver with the system forced onto the cell-list path (what a protein of more than ~390 residues takes by
+    itself): host-driven minimiser fallback, reporters, checkpoint -- and the same physics: with identical seeds the short
+    fp64 trajectories of the two paths agree."""
+    from openawsem_amd.scripts import mm_run
+    src = data_path.data / "1r69"
+    d = tmp_path / "1r69"
+    shutil.copytree(src, d, ignore=shutil.ignore_patterns("fraglib", "frags.mem"))
+    shutil.copy(d / "1r69.fasta", d / "crystal_structure.fasta")
+    seq = "".join(ln.strip() for ln in open(d / "1r69.fasta") if not ln.startswith(">"))
+    (d / "charge.txt").write_text("".join(f"{i} {1.0 if a in 'RK' else (-1.0 if a in 'DE' else 0.0)}\n" for i, a in enumerate(seq)))
+    forces = os.path.join(os.path.dirname(mm_run.__file__), "forces_setup.py")
+    finals = {}
+    for cell in ("1", "0"):
+        monkeypatch.setenv("AWSEM_FORCE_CELL", cell)
+        monkeypatch.chdir(d)
+        out = tmp_path / f"run_cell{cell}"
+        mm_run.main(["1r69", "--to", str(out), "-s", "400", "--tempStart", "500", "--tempEnd", "400", "--replicas", "2", "--seed", "5",
+                     "-p", "Reference", "--noMinimize", "-f", forces])
+        log = np.loadtxt(out / "output.log", delimiter=",", skiprows=1)
+        assert log.shape == (400, 3) and np.isfinite(log).all()
+        with np.load(out / "ensemble_final.npz") as z:
+            finals[cell] = z["positions"].copy()
+    assert np.abs(finals["1"] - finals["0"]).max() < 1e-6
+    # and the minimiser fallback of the cell path reaches the tolerance too
+    monkeypatch.setenv("AWSEM_FORCE_CELL", "1")
+    monkeypatch.chdir(d)
+    sim = mm_run.main(["1r69", "--to", str(tmp_path / "run_min"), "-s", "400", "-m", "0", "--tempStart", "300", "--seed", "5", "-f", forces])
+    assert np.isfinite(sim.context.energies()).all()
