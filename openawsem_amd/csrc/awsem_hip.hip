@@ -950,7 +950,14 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_minimize_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_list_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
-    block_ = natoms_ > 1024 ? 512 : 256;
+    // Workgroup size: the waves a CU can hold at this kernel's register budget (16) divided among the replicas whose LDS
+    // images fit one CU -- four small replicas share a CU with 4 waves each (more waves per replica were measured slower
+    // there: 1r69, 320 / 384 threads), a replica that has the CU to itself (2xov: 104 KB) takes all 16 (measured +45 %
+    // over 512 threads).
+    {
+        const size_t per_cu = std::max<size_t>(1, lds_max / std::max<size_t>(1, step_ok_ ? lds_step_ : lds_eval_));
+        block_ = (int)std::min<size_t>(1024, std::max<size_t>(256, (1024 / per_cu) / 64 * 64));
+    }
     if (const char* env = getenv("AWSEM_BLOCK")) {
         int b = atoi(env);
         if (b >= 64 && b <= 1024 && b % 64 == 0) block_ = b;
