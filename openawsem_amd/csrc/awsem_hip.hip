@@ -360,7 +360,7 @@ private:
     unsigned* dcounts_ = nullptr;
     std::vector<GaussD<real>> hgauss_;   // host copy of the bond-sum descriptors (DevSys::gauss points to device memory)
     double skin_ = 0.2;    // nm; AWSEM_SKIN overrides (0.15-0.3 measured: 0.2 and above rebuild rarely enough on the hot, extended stage of an annealing run)
-    size_t lds_list_ = 0, lds_max_ = 0;
+    size_t lds_list_ = 0, lds_max_ = 0, n_cu_ = 256;
     bool step_ok_ = false;
 
     // ---- cell-list path (awsem_cell.h): systems that do not fit one CU's LDS
@@ -512,6 +512,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         size_t lds_max = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
         if (prop.maxSharedMemoryPerMultiProcessor > lds_max) lds_max = prop.maxSharedMemoryPerMultiProcessor;
         lds_max_ = lds_max;
+        n_cu_ = std::max(1, prop.multiProcessorCount);
         int max_sites = 0;
         for (auto& h : H0.contact) max_sites = std::max(max_sites, (int)h.atom.size());
         const char* force = getenv("AWSEM_FORCE_CELL");
@@ -955,8 +956,9 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     // there: 1r69, 320 / 384 threads), a replica that has the CU to itself (2xov: 104 KB) takes all 16 (measured +45 %
     // over 512 threads).
     {
-        const size_t per_cu = std::max<size_t>(1, lds_max / std::max<size_t>(1, step_ok_ ? lds_step_ : lds_eval_));
-        block_ = (int)std::min<size_t>(1024, std::max<size_t>(256, (1024 / per_cu) / 64 * 64));
+        size_t per_cu = std::max<size_t>(1, lds_max / std::max<size_t>(1, step_ok_ ? lds_step_ : lds_eval_));
+        per_cu = std::min(per_cu, std::max<size_t>(1, ((size_t)nrep_ + n_cu_ - 1) / n_cu_));   // fewer replicas than slots: a CU holds fewer (1r69, <= 256 replicas: 14.3 -> 12.1 us per step)
+        block_ = per_cu >= 4 ? 256 : per_cu >= 2 && per_cu * 512 <= 1024 ? 512 : per_cu == 1 ? 1024 : 256;   // powers of two only: 320 threads (three replicas per CU) were measured 70 % slower than 256
     }
     if (const char* env = getenv("AWSEM_BLOCK")) {
         int b = atoi(env);
