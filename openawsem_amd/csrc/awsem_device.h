@@ -140,6 +140,8 @@ template <class real> struct DevSys {
     MembD<real> memb[AWSEM_MAX_MEMB]; DhD<real> dh[AWSEM_MAX_DH];
     const GaussD<real>* gauss;            // n_gauss descriptors in device memory (read with scalar loads): bond sums come in any number,
                                           // and run-time indexing of a large array inside the by-value block sends it to scratch
+    int fuse_vs;                          // the first force phase (density, fragment memory, collective-variable sums) touches massive particles only:
+                                          // the step kernel places the virtual sites in that phase instead of a phase of their own
     int n_cv;                             // Gaussian-bond terms with cv != 0 (each owns one LDS accumulator)
     int max_contact_sites;                // LDS scratch sizing
     int any_zdep;

@@ -892,31 +892,45 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
             if (off > 0x7fffffffLL) throw std::string("pair lists of one replica exceed 2^31 entries");
             return ls;
         };
-        auto rc2 = [&](double cutoff) { double r = cutoff + skin_; return (real)(r * r); };
+        // A list is rebuilt when a MASSIVE particle has moved further than skin/2.  A virtual site then has moved at most
+        // sum|w| times that, so a list screened on atoms a and b is cut at cutoff + (amp(a) + amp(b)) / 2 * skin, amp = 1 for a
+        // massive particle and sum|w| for a site (N of the AWSEM backbone: 1.373 -> beta and P-AP lists: 1.19 skin).
+        std::vector<double> amp(natoms_, 1.0);
+        for (size_t v = 0; v < H.vs_site.size(); v++) amp[H.vs_site[v]] = std::fabs(H.vs_w[3 * v]) + std::fabs(H.vs_w[3 * v + 1]) + std::fabs(H.vs_w[3 * v + 2]);
+        auto amp_max = [&](const std::vector<int>& atoms, int stride) { double m = 0; for (size_t i = 0; i < atoms.size(); i += stride) if (atoms[i] >= 0) m = std::max(m, amp[atoms[i]]); return atoms.empty() ? 1.0 : m; };
+        auto rc2 = [&](double cutoff, double margin) { double r = cutoff + margin * skin_; return (real)(r * r); };
         for (int t = 0; t < S.n_contact; t++) {
             ContactD<real>& d = S.contact[t];
             if (d.nsites > 1023) throw std::string("contact term: at most 1023 sites on the replica-resident path");
             d.ls = slot((long long)d.nsites * (d.nsites - 1) / 2);
-            d.list_rc2 = rc2((H.contact[t].flags & AWSEM_CONTACT_NOCUTOFF) ? 1e15 : H.contact[t].p[AWSEM_CP_CUTOFF]);
+            d.list_rc2 = rc2((H.contact[t].flags & AWSEM_CONTACT_NOCUTOFF) ? 1e15 : H.contact[t].p[AWSEM_CP_CUTOFF], amp_max(H.contact[t].atom, 1));
         }
         for (int t = 0; t < S.n_excl; t++) {
             ExclD<real>& d = S.excl[t];
             long long cap = 0;
             for (int c = 0; c < d.nclass; c++) { long long n = d.class_start[c + 1] - d.class_start[c]; cap += n * (n - 1) / 2; }
             d.ls = slot(cap);
-            d.list_rc2 = rc2(H.excl[t].r0);
+            d.list_rc2 = rc2(H.excl[t].r0, amp_max(H.excl[t].atom, 1));
         }
         for (int t = 0; t < S.n_beta; t++) {
             BetaD<real>& d = S.beta[t];
             if (d.nacc > 65535 || d.ndon > 65535) throw std::string("hydrogen-bond term: at most 65535 acceptors / donors");
             d.ls = slot((long long)d.nacc * d.ndon);
-            d.list_rc2 = rc2(std::sqrt((double)d.screen2));
+            d.list_rc2 = rc2(std::sqrt((double)d.screen2), 0.5 * (amp_max(H.beta[t].acc_atoms, 3) + amp_max(H.beta[t].don_atoms, 3)));
         }
         for (int t = 0; t < S.n_pap; t++) {
             PapD<real>& d = S.pap[t];
             if (d.nacc > 65535 || d.ndon > 65535) throw std::string("hydrogen-bond term: at most 65535 acceptors / donors");
             d.ls = slot((long long)d.nacc * d.ndon);
-            d.list_rc2 = rc2(H.pap[t].cutoff);
+            d.list_rc2 = rc2(H.pap[t].cutoff, 0.5 * (amp_max(H.pap[t].acc_atoms, 2) + amp_max(H.pap[t].don_atoms, 2)));
+        }
+        {   // may the step kernel place the virtual sites inside the first force phase?  Only if that phase reads massive particles only
+            bool ok = true;
+            auto massive = [&](const std::vector<int>& atoms) { for (int a : atoms) if (a >= 0 && !(H.mass[a] > 0)) ok = false; };
+            for (auto& h : H.contact) massive(h.atom);
+            for (auto& h : H.fm) massive(h.pairs);
+            for (auto& h : H.gauss) if (h.cv) massive(h.pairs);
+            S.fuse_vs = ok && !(getenv("AWSEM_FUSE_VS") && atoi(getenv("AWSEM_FUSE_VS")) == 0) ? 1 : 0;
         }
         S.n_lists = id;
         S.list_stride = off ? off : 64;

@@ -239,7 +239,7 @@ struct Rotor {   // hands out starting waves: each job continues where the previ
 };
 
 // ------------------------------------------------------------------ bonded terms
-template <bool ENERGY, class V> __device__ void term_harmonic(const HarmD<typename V::real_t>& d, const V& L, int rot = 0) {
+template <bool ENERGY, class V> __device__ __forceinline__ void term_harmonic(const HarmD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
@@ -252,7 +252,7 @@ template <bool ENERGY, class V> __device__ void term_harmonic(const HarmD<typena
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-template <bool ENERGY, class V> __device__ void term_chi(const ChiD<typename V::real_t>& d, const V& L, int rot = 0) {
+template <bool ENERGY, class V> __device__ __forceinline__ void term_chi(const ChiD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
@@ -300,7 +300,7 @@ template <class real> __device__ __forceinline__ void dihedral(const R3<real>& q
     }
 }
 
-template <bool ENERGY, class V> __device__ void term_rama(const RamaD<typename V::real_t>& d, const V& L, int rot = 0) {
+template <bool ENERGY, class V> __device__ __forceinline__ void term_rama(const RamaD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
@@ -342,7 +342,7 @@ template <class real> __device__ __forceinline__ real hb_theta(real r1, real r2,
     return th;
 }
 
-template <bool ENERGY, class V> __device__ void term_helical(const HelicalD<typename V::real_t>& d, const V& L, int rot = 0) {
+template <bool ENERGY, class V> __device__ __forceinline__ void term_helical(const HelicalD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
@@ -405,7 +405,7 @@ template <bool ENERGY, int U, bool PACKED, class V> __device__ __forceinline__ v
 #endif
     }
 }
-template <bool ENERGY, bool PACKED = true, class V> __device__ void term_fm(const FmD<typename V::real_t>& d, const V& L, int rot = 0) {
+template <bool ENERGY, bool PACKED = true, class V> __device__ __forceinline__ void term_fm(const FmD<typename V::real_t>& d, const V& L, int rot = 0) {
     Energy e;
     constexpr int U = 6;
     const unsigned stride = blockDim.x, n = (unsigned)d.n;
@@ -416,7 +416,7 @@ template <bool ENERGY, bool PACKED = true, class V> __device__ void term_fm(cons
 // Bundled walk (replica-resident path): one lane per bundle of <= AWSEM_FM_BUNDLE bonds around one owner atom.  The owner's
 // position is read once, its force is summed in integer registers (bit-identical to the atomics it replaces) and added once:
 // a third fewer LDS reads and atomics than bond-by-bond, all table gathers of the bundle in flight together.
-template <bool ENERGY, class V> __device__ void term_fm_bundled(const FmD<typename V::real_t>& d, const V& L, int rot = 0) {
+template <bool ENERGY, class V> __device__ __forceinline__ void term_fm_bundled(const FmD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     constexpr int K = AWSEM_FM_BUNDLE;
     Energy e;
@@ -453,7 +453,7 @@ template <bool ENERGY, class V> __device__ void term_fm_bundled(const FmD<typena
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-template <bool ENERGY, class V> __device__ void term_memb(const MembD<typename V::real_t>& d, const V& L, int rot = 0) {
+template <bool ENERGY, class V> __device__ __forceinline__ void term_memb(const MembD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
@@ -468,7 +468,7 @@ template <bool ENERGY, class V> __device__ void term_memb(const MembD<typename V
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-template <bool ENERGY, class V> __device__ void term_dh(const DhD<typename V::real_t>& d, const V& L, int rot = 0) {
+template <bool ENERGY, class V> __device__ __forceinline__ void term_dh(const DhD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
@@ -585,7 +585,7 @@ template <class V> __device__ __forceinline__ ListView list_view(const V& L, con
 // a table is staged into the force accumulators' memory, which is all zero and unused while lists are built
 // (build_lists clears it again afterwards).  A global load per candidate would put ~1 us of latency into every
 // iteration of these loops.
-template <class V> __device__ void build_excl(const ExclD<typename V::real_t>& d, const V& L, int* status) {
+template <class V> __device__ __forceinline__ void build_excl(const ExclD<typename V::real_t>& d, const V& L, int* status) {
     typedef typename V::real_t real;
     AWSEM_WAVE_VARS;
     unsigned* e = L.lists + d.ls.list_off;
@@ -635,7 +635,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void excl_body(const 
         L.pair_force(a, b, dd.x, dd.y, dd.z, (real)-2 * d.k * dr * ir);
     }
 }
-template <bool ENERGY, class V> __device__ void eval_excl(const ExclD<typename V::real_t>& d, const V& L) {
+template <bool ENERGY, class V> __device__ __forceinline__ void eval_excl(const ExclD<typename V::real_t>& d, const V& L) {
     AWSEM_WAVE_VARS;
     Energy e;
     const ListView lv = list_view(L, d.ls);
@@ -649,7 +649,7 @@ template <bool ENERGY, class V> __device__ void eval_excl(const ExclD<typename V
 }
 
 // ---- contact: site pairs with |resid_i - resid_j| >= 2 (the density's own exclusion; the pair energy needs more)
-template <class V> __device__ void build_contact(const ContactD<typename V::real_t>& d, const V& L, const int* satom, int* status) {
+template <class V> __device__ __forceinline__ void build_contact(const ContactD<typename V::real_t>& d, const V& L, const int* satom, int* status) {
     typedef typename V::real_t real;
     AWSEM_WAVE_VARS;
     unsigned* e = L.lists + d.ls.list_off;
@@ -703,7 +703,7 @@ template <class V> __device__ __forceinline__ void density_body(const ContactD<t
         fixed_add(&L.rho[j], t);
     }
 }
-template <class V> __device__ void contact_density(const ContactD<typename V::real_t>& d, const V& L, const int* satom) {
+template <class V> __device__ __forceinline__ void contact_density(const ContactD<typename V::real_t>& d, const V& L, const int* satom) {
     AWSEM_WAVE_VARS;
     const ListView lv = list_view(L, d.ls);
     AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id) {
@@ -740,7 +740,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void single_body(cons
         L.dalpha[i] = d.eta_sw2 * (su * ((real)1 - su) - sv * ((real)1 - sv));
     }
 }
-template <bool ENERGY, class V> __device__ void contact_single(const ContactD<typename V::real_t>& d, const V& L, const int* satom, int rot = 0) {
+template <bool ENERGY, class V> __device__ __forceinline__ void contact_single(const ContactD<typename V::real_t>& d, const V& L, const int* satom, int rot = 0) {
     Energy e;
     for (int i = rot_tid(rot); i < d.nsites; i += blockDim.x) single_body<ENERGY>(d, L, i, satom[i], e);
     flush_energy<ENERGY>(L, d.group, e);
@@ -800,7 +800,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void pairs_body(const
         }
     }
 }
-template <bool ENERGY, class V> __device__ void contact_pairs(const ContactD<typename V::real_t>& d, const V& L, const int* satom) {
+template <bool ENERGY, class V> __device__ __forceinline__ void contact_pairs(const ContactD<typename V::real_t>& d, const V& L, const int* satom) {
     AWSEM_WAVE_VARS;
     Energy e;
     const ListView lv = list_view(L, d.ls);
@@ -825,7 +825,7 @@ template <class V> __device__ __forceinline__ void chain_body(const ContactD<typ
     const real g = fixed_to_real(L.drho[i] + L.drho[j], (real)0);
     if (pass) L.pair_force(a, b, dd.x, dd.y, dd.z, -g * d.eta2 * s1 * s2 * (s2 - s1) * ir);
 }
-template <class V> __device__ void contact_chain_rule(const ContactD<typename V::real_t>& d, const V& L, const int* satom) {
+template <class V> __device__ __forceinline__ void contact_chain_rule(const ContactD<typename V::real_t>& d, const V& L, const int* satom) {
     AWSEM_WAVE_VARS;
     const ListView lv = list_view(L, d.ls);
     AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id + 2) {
@@ -840,7 +840,7 @@ template <class V> __device__ void contact_chain_rule(const ContactD<typename V:
 // ---- acceptor x donor terms (CustomHbondForce shape)
 // In fp32 the lists use a conservative pre-screen (Gaussian factors below e^-30 of their maximum are skipped, far
 // under fp32 resolution); the fp64 check mode applies only the reference's cutoff.
-template <class V, class Desc> __device__ void build_hbond(const Desc& d, const V& L, int* status) {
+template <class V, class Desc> __device__ __forceinline__ void build_hbond(const Desc& d, const V& L, int* status) {
     typedef typename V::real_t real;
     AWSEM_WAVE_VARS;
     unsigned* e = L.lists + d.ls.list_off;
@@ -925,7 +925,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void beta_pair(const 
         L.pair_force(D.z, A.z, ee.x, ee.y, ee.z, -c * th1 * h2 * i4);
     }
 }
-template <bool ENERGY, class V> __device__ void eval_beta(const BetaD<typename V::real_t>& d, const V& L) {
+template <bool ENERGY, class V> __device__ __forceinline__ void eval_beta(const BetaD<typename V::real_t>& d, const V& L) {
     AWSEM_WAVE_VARS;
     Energy e;
     const ListView lv = list_view(L, d.ls);
@@ -960,7 +960,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void pap_pair(const P
     L.pair_force(A.y, D.y, b.x, b.y, b.z, c * s1 * d.eta2 * s2 * (one - s2) * s3 * i2);
     L.pair_force(A.x, A.y, ee.x, ee.y, ee.z, -c * s1 * s2 * d.eta2 * s3 * (one - s3) * i3);
 }
-template <bool ENERGY, class V> __device__ void eval_pap(const PapD<typename V::real_t>& d, const V& L) {
+template <bool ENERGY, class V> __device__ __forceinline__ void eval_pap(const PapD<typename V::real_t>& d, const V& L) {
     AWSEM_WAVE_VARS;
     Energy e;
     const ListView lv = list_view(L, d.ls);
@@ -985,6 +985,19 @@ template <class V> __device__ __forceinline__ void compute_virtual_sites(const D
 }
 // fold the force on each virtual site onto its three parents (ThreeParticleAverageSite chain rule); evaluation API
 // only -- the step kernel gathers instead (every massive atom collects from the sites it parents, no atomics)
+// step kernel: virtual sites from their (new) parents, their force accumulators -- already gathered by the integrator --
+// cleared, as are those of massless particles that are no virtual sites
+template <class V> __device__ __forceinline__ void update_virtual_sites(const DevSys<typename V::real_t>& S, const V& L) {
+    typedef typename V::real_t real;
+    for (int i = threadIdx.x; i < S.nvs; i += blockDim.x) {
+        const Int4 v = S.vs[i];
+        const real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
+        const R3<real> pa = L.pos(v.y), pb = L.pos(v.z), pc = L.pos(v.w);
+        L.set_pos(v.x, R3<real>{w0 * pa.x + w1 * pb.x + w2 * pc.x, w0 * pa.y + w1 * pb.y + w2 * pc.y, w0 * pa.z + w1 * pb.z + w2 * pc.z});
+        L.zero_force(v.x);
+    }
+    for (int i = threadIdx.x; i < S.nfixed; i += blockDim.x) L.zero_force(S.fixed[i]);
+}
 template <class V> __device__ __forceinline__ void redistribute_forces(const DevSys<typename V::real_t>& S, const V& L) {
     typedef typename V::real_t real;
     for (int i = threadIdx.x; i < S.nvs; i += blockDim.x) {
@@ -999,7 +1012,7 @@ template <class V> __device__ __forceinline__ void redistribute_forces(const Dev
 }
 
 // Once per launch: contact site -> atom tables and (when the system has a single contact term) its gamma tables.
-template <class V> __device__ void stage_contact_gamma(const ContactD<typename V::real_t>& d, const V& L) {
+template <class V> __device__ __forceinline__ void stage_contact_gamma(const ContactD<typename V::real_t>& d, const V& L) {
     typedef typename V::real_t real;
     if (d.flags & 2) return;
     const int ng = (d.flags & 1) ? 2400 : 1200;
@@ -1030,7 +1043,10 @@ template <class V> __device__ __forceinline__ void build_lists(const DevSys<type
 // address, and the compiler then copies the whole by-value kernarg block to scratch (2.7 KB per lane, half the speed).
 // The contact passes need workgroup barriers between them, which cuts the evaluation into four phases; every other
 // term is issued in one of the phases so that each phase keeps all waves busy.
-template <bool ENERGY, class V> __device__ __forceinline__ void evaluate_terms(const DevSys<typename V::real_t>& S, const V& L, unsigned mask AWSEM_STAMP_ARG) {
+// STEP (the Langevin kernel): the Ramachandran and chirality terms move from the first phase to the second, and with
+// `fused_vs` the first phase also places the virtual sites -- its other work (density, fragment memory) reads massive
+// particles only (DevSys::fuse_vs), so the sites need no phase and no barrier of their own.
+template <bool ENERGY, bool STEP = false, class V> __device__ __forceinline__ void evaluate_terms(const DevSys<typename V::real_t>& S, const V& L, unsigned mask, bool fused_vs AWSEM_STAMP_ARG) {
     typedef typename V::real_t real;
     int first = -1;   // the contact term whose passes define the phases
     for (int t = S.n_contact - 1; t >= 0; t--) if (AWSEM_ON(S.contact[t])) first = t;
@@ -1041,15 +1057,18 @@ template <bool ENERGY, class V> __device__ __forceinline__ void evaluate_terms(c
     if (c0 && multi) { stage_contact_gamma(*c0, L); __syncthreads(); }
     Rotor rotor;
     // phase A
+    if (STEP && fused_vs) update_virtual_sites(S, L);
     if (c0) contact_density(*c0, L, satom0);
     for (int u = 0; u < S.n_fm; u++) if (AWSEM_ON(S.fm[u])) {
         if (S.fm[u].nbundles) term_fm_bundled<ENERGY>(S.fm[u], L, rotor.next(S.fm[u].nbundles));
         else term_fm<ENERGY>(S.fm[u], L, rotor.next(S.fm[u].n));
     }
-    for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
-    for (int u = 0; u < S.n_chi; u++) if (AWSEM_ON(S.chi[u])) term_chi<ENERGY>(S.chi[u], L, rotor.next(S.chi[u].n));
+    if (!STEP) {
+        for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
+        for (int u = 0; u < S.n_chi; u++) if (AWSEM_ON(S.chi[u])) term_chi<ENERGY>(S.chi[u], L, rotor.next(S.chi[u].n));
+    }
     for (int u = 0; u < S.n_gauss; u++) { const GaussD<real> d = S.gauss[u]; if (d.cv && AWSEM_ON(d)) cv_sum(d, L, rotor.next(d.n)); }
-    if (bar) __syncthreads();
+    if (bar || STEP) __syncthreads();
     AWSEM_STAMP(S, 4);
     // phase B
     rotor.acc = 0;
@@ -1064,6 +1083,10 @@ template <bool ENERGY, class V> __device__ __forceinline__ void evaluate_terms(c
     }
     for (int u = 0; u < S.n_helical; u++) if (AWSEM_ON(S.helical[u])) term_helical<ENERGY>(S.helical[u], L, rotor.next(S.helical[u].n));
     for (int u = 0; u < S.n_memb; u++) if (AWSEM_ON(S.memb[u])) term_memb<ENERGY>(S.memb[u], L, rotor.next(S.memb[u].n));
+    if (STEP) {
+        for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
+        for (int u = 0; u < S.n_chi; u++) if (AWSEM_ON(S.chi[u])) term_chi<ENERGY>(S.chi[u], L, rotor.next(S.chi[u].n));
+    }
     if (bar) __syncthreads();
     AWSEM_STAMP(S, 5);
     // phase C
@@ -1185,7 +1208,7 @@ __global__ void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__
     build_lists(S, L, mask);
     __syncthreads();
     AWSEM_STAMP_INIT;
-    evaluate_terms<ENERGY>(S, L, mask AWSEM_STAMP_PASS);
+    evaluate_terms<ENERGY>(S, L, mask, false AWSEM_STAMP_PASS);
     if (f_out) {
         if (redistribute) { redistribute_forces(S, L); __syncthreads(); }
         double* f = f_out + (size_t)rep * 3 * natoms;
@@ -1337,11 +1360,20 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
     compute_virtual_sites(S, L);
     __syncthreads();
     AWSEM_STAMP_INIT;
+    // The lists are rebuilt when a MASSIVE particle has moved further than skin/2 since the last build; lists screened on a
+    // virtual site carry a correspondingly larger margin (host: list_margin), so the sites need no displacement test.
+    const bool fuse = S.fuse_vs != 0;
     for (int s = 0; s < nsteps; s++) {
         const int cur = s & 1;
-        if (s == 0 || __uint_as_float(L.flag[cur]) > (float)S.skin_half2) {   // uniform across the workgroup
+        const bool rebuild = s == 0 || __uint_as_float(L.flag[cur]) > (float)S.skin_half2;   // uniform across the workgroup
+        if (rebuild || !fuse) {   // the virtual sites in a phase of their own: the hydrogen-bond list builders read them
+            update_virtual_sites(S, L);
+            __syncthreads();
+            AWSEM_STAMP(S, 0);
+        }
+        if (rebuild) {
             if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
-            for (int i = threadIdx.x; i < natoms; i += blockDim.x) L.set_ref(i, L.pos(i));
+            for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) { const int i = S.massive[k].atom; L.set_ref(i, L.pos(i)); }
             __syncthreads();
             build_lists(S, L, 0xffffffffu);
             __syncthreads();
@@ -1350,7 +1382,7 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
             if (threadIdx.x == 0) atomicAdd((unsigned long long*)&S.prof[10], 1ull);   // number of list rebuilds
 #endif
         }
-        evaluate_terms<false>(S, L, 0xffffffffu AWSEM_STAMP_PASS);
+        evaluate_terms<false, true>(S, L, 0xffffffffu, fuse && !rebuild AWSEM_STAMP_PASS);
         if (threadIdx.x == 0) L.flag[cur] = 0;   // read by everyone before the barriers of the evaluation; written again next step
         {
             float m = 0;
@@ -1377,28 +1409,14 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
                 L.set_vel(k, v); L.set_pos(i, x);
                 m = fmaxf(m, (float)dist2(x - L.refpos(i)));
             }
+            for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;   // last read in the per-site pass
             book_displacement(&L.flag[cur ^ 1], m);
         }
         __syncthreads();
         AWSEM_STAMP(S, 9);
-        {
-            float m = 0;
-            for (int i = threadIdx.x; i < S.nvs; i += blockDim.x) {
-                const Int4 v = S.vs[i];
-                const real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
-                const R3<real> pa = L.pos(v.y), pb = L.pos(v.z), pc = L.pos(v.w);
-                const R3<real> x = R3<real>{w0 * pa.x + w1 * pb.x + w2 * pc.x, w0 * pa.y + w1 * pb.y + w2 * pc.y, w0 * pa.z + w1 * pb.z + w2 * pc.z};
-                L.set_pos(v.x, x);
-                L.zero_force(v.x);
-                m = fmaxf(m, (float)dist2(x - L.refpos(v.x)));
-            }
-            for (int i = threadIdx.x; i < S.nfixed; i += blockDim.x) L.zero_force(S.fixed[i]);   // massless particles that are no virtual sites
-            for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
-            book_displacement(&L.flag[cur ^ 1], m);
-        }
-        __syncthreads();
-        AWSEM_STAMP(S, 0);
     }
+    compute_virtual_sites(S, L);   // the sites of the final coordinates (a third inlined copy of update_virtual_sites here tips the
+    __syncthreads();               // compiler into spilling the kernarg block: __graft_entry__.build() checks for that)
     AWSEM_STAMP_FLUSH(S);
     for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
         const R3<real> x = L.pos(i);
@@ -1450,7 +1468,7 @@ __global__ void awsem_minimize_kernel(const DevSys<real> S, real* __restrict__ p
             __syncthreads();
         }
         if (threadIdx.x < 3) L.eg[threadIdx.x] = 0;   // visible before anyone adds: the evaluation has barriers
-        evaluate_terms<false>(S, L, 0xffffffffu AWSEM_STAMP_PASS);
+        evaluate_terms<false>(S, L, 0xffffffffu, false AWSEM_STAMP_PASS);
         if (threadIdx.x == 0) L.flag[cur] = 0;
         {   // pass 1: the sums
             Energy eP, eF, eV;
