@@ -64,8 +64,10 @@ def _measured_traffic(args, oa):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm.json:
     FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE), when one matches this configuration."""
     import glob
+    import re
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json"))):
+    natural = lambda f: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(f))]   # r01_v9 before r01_v11
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), key=natural):
         try:
             with open(f) as fh:
                 rec = json.load(fh)
