@@ -7,8 +7,9 @@
 // plain read-modify-write -- no atomics in any pair pass, at the price of meeting every pair from both sides.
 // One MD step is a short fixed sequence of grid-wide kernels on the handle's stream:
 //   pre (virtual sites, displacement test, bounding box, packed site records)
-//   [grid -> count -> scan -> fill -> neighbour rows: all exit at once unless an atom moved more than skin/2]
+//   [grid -> count -> scan -> fill -> neighbour rows -> hydrogen-bond rows: all exit at once unless an atom moved more than skin/2]
 //   bonded terms -> density + per-site pass + excluded volume -> pair pass -> chain-rule pass ->
+//   hydrogen-bond terms (per-acceptor donor rows, one launch for all beta / P-AP terms; global fixed-point atomics) ->
 //   integrate (gathers the virtual-site forces of each massive particle, Langevin update)
 // The per-pair arithmetic is the same code as on the replica-resident path (awsem_kernels.h); all sums are fixed
 // point, so the result does not depend on the (non-deterministic) order of the list entries.
