@@ -184,6 +184,7 @@ public:
             throw std::string(msg);
         }
         HIP_TRY(hipSetDevice(device_));
+        apply_skin(T);
         begin_async(T);
         hipLaunchKernelGGL(awsem_step_kernel<real>, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, dT_, nsteps, dt, friction,
                            (unsigned long long)seed, (long long)step0);
@@ -359,6 +360,29 @@ private:
     double* dmin_rms_ = nullptr;
     unsigned* dcounts_ = nullptr;
     std::vector<GaussD<real>> hgauss_;   // host copy of the bond-sum descriptors (DevSys::gauss points to device memory)
+    struct ListParam { double cutoff, margin; };
+    std::vector<ListParam> list_params_;   // per pair list, in the order contact, excl, beta, pap
+    bool skin_fixed_ = false;
+    // The best skin depends on how fast the particles move and how many pairs a shell of that width adds: measured optima
+    // for 1r69 are 0.22-0.25 nm at 800 K (extended chains) and 0.10 nm at 300 K (folded: 33.3 M replica-steps/s against
+    // 30.0 M with 0.2).  The lists are rebuilt at the start of every launch anyway, so the skin simply follows the hottest
+    // replica of the launch; AWSEM_SKIN pins it.
+    void apply_skin(const double* T) {
+        if (cell_mode_ || skin_fixed_ || list_params_.empty()) return;
+        double tmax = 0;
+        for (int r = 0; r < nrep_; r++) tmax = std::max(tmax, T[r]);
+        const double skin = std::min(0.25, std::max(0.07, 0.028 + 0.00024 * tmax));
+        if (std::fabs(skin - skin_) < 2e-3) return;
+        skin_ = skin;
+        DevSys<real>& S = dsys_;
+        size_t k = 0;
+        auto rc2 = [&]() { const ListParam& p = list_params_[k++]; const double r = p.cutoff + p.margin * skin_; return (real)(r * r); };
+        for (int t = 0; t < S.n_contact; t++) S.contact[t].list_rc2 = rc2();
+        for (int t = 0; t < S.n_excl; t++) S.excl[t].list_rc2 = rc2();
+        for (int t = 0; t < S.n_beta; t++) S.beta[t].list_rc2 = rc2();
+        for (int t = 0; t < S.n_pap; t++) S.pap[t].list_rc2 = rc2();
+        S.skin_half2 = (real)(0.25 * skin_ * skin_ * 0.999);
+    }
     double skin_ = 0.2;    // nm; AWSEM_SKIN overrides (0.15-0.3 measured: 0.2 and above rebuild rarely enough on the hot, extended stage of an annealing run)
     size_t lds_list_ = 0, lds_max_ = 0, n_cu_ = 256;
     bool step_ok_ = false;
@@ -870,7 +894,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     // pair lists: one slot per pair term, capacity = number of candidate pairs (cannot overflow)
     if (const char* env = getenv("AWSEM_SKIN")) {
         double v = atof(env);
-        if (v >= 0.0 && v <= 1.0) skin_ = v;
+        if (v >= 0.0 && v <= 1.0) { skin_ = v; skin_fixed_ = true; }
     }
     dstatus_ = dalloc<int>(1);
     HIP_TRY(hipMemset(dstatus_, 0, sizeof(int)));
@@ -898,7 +922,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         std::vector<double> amp(natoms_, 1.0);
         for (size_t v = 0; v < H.vs_site.size(); v++) amp[H.vs_site[v]] = std::fabs(H.vs_w[3 * v]) + std::fabs(H.vs_w[3 * v + 1]) + std::fabs(H.vs_w[3 * v + 2]);
         auto amp_max = [&](const std::vector<int>& atoms, int stride) { double m = 0; for (size_t i = 0; i < atoms.size(); i += stride) if (atoms[i] >= 0) m = std::max(m, amp[atoms[i]]); return atoms.empty() ? 1.0 : m; };
-        auto rc2 = [&](double cutoff, double margin) { double r = cutoff + margin * skin_; return (real)(r * r); };
+        list_params_.clear();
+        auto rc2 = [&](double cutoff, double margin) { list_params_.push_back({cutoff, margin}); double r = cutoff + margin * skin_; return (real)(r * r); };   // recorded in the order contact, excl, beta, pap: see apply_skin
         for (int t = 0; t < S.n_contact; t++) {
             ContactD<real>& d = S.contact[t];
             if (d.nsites > 1023) throw std::string("contact term: at most 1023 sites on the replica-resident path");
