@@ -267,3 +267,25 @@ def test_minimizer_follows_the_oracle_restatement():
     assert rg[0] <= 10.0 and rc[0] <= 10.0
     eg, ec = gpu.energy()[0], cpu.energy()[0]
     assert abs(eg - ec) < 0.02 * abs(ec), (eg, ec, ig, ic)
+
+
+@pytest.mark.parametrize("env", [{"AWSEM_FUSE_VS": "0"}, {"AWSEM_NO_REORDER": "1"}, {"AWSEM_FM_BUNDLES": "0"}, {"AWSEM_BLOCK": "256"}])
+def test_alternative_kernel_paths_give_the_same_trajectory(env, monkeypatch):
+    """The step kernel's optional paths -- virtual sites in a phase of their own, the caller's atom order kept, fragment
+    memory bond by bond, four waves instead of sixteen -- change how the work is laid out, not what is summed: in fp64
+    mode 60 steps end within rounding of the default path (fixed-point sums, same random streams)."""
+    oa, traj, _ = golden_system("1ubq")
+    T = np.array([300.0, 600.0])
+    out = []
+    for variant in (None, env):
+        for k in ("AWSEM_FUSE_VS", "AWSEM_NO_REORDER", "AWSEM_FM_BUNDLES", "AWSEM_BLOCK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in (variant or {}).items():
+            monkeypatch.setenv(k, v)
+        gpu = _gpu(oa, 2, FP64)
+        gpu.set_positions(traj[3])
+        gpu.set_velocities_to_temperature(T, 5)
+        gpu.step(60, T, 0.002, 1.0, 6)
+        out.append((gpu.get_state()[0], gpu.energy_by_group(), gpu.forces()))
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-9
+    assert np.abs(out[0][1] - out[1][1]).max() < 1e-6 and np.abs(out[0][2] - out[1][2]).max() < 1e-5
