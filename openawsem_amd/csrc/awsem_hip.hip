@@ -371,7 +371,8 @@ private:
         if (cell_mode_ || skin_fixed_ || list_params_.empty()) return;
         double tmax = 0;
         for (int r = 0; r < nrep_; r++) tmax = std::max(tmax, T[r]);
-        const double skin = std::min(0.25, std::max(0.07, 0.028 + 0.00024 * tmax));
+        static const double sa = getenv("AWSEM_SKIN_A") ? atof(getenv("AWSEM_SKIN_A")) : 0.028, sb = getenv("AWSEM_SKIN_B") ? atof(getenv("AWSEM_SKIN_B")) : 0.00024;   // tuning knobs
+        const double skin = std::min(0.25, std::max(0.07, sa + sb * tmax));
         if (std::fabs(skin - skin_) < 2e-3) return;
         skin_ = skin;
         DevSys<real>& S = dsys_;
