@@ -18,5 +18,5 @@ for d in ("$O/pmc_sq1_$tag", "$O/pmc_sq2_$tag"):
             if "awsem_step_kernel" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k in sorted(acc):
-        print(f"{k:28s} {sum(acc[k]) / len(acc[k]) / (1024 * 50):12.1f}  per replica-step ({len(acc[k])} dispatches)")
+        print(f"{k:28s} {sum(acc[k]) / len(acc[k]) / (1024 * ${PMC_STEPS:-50}):12.1f}  per replica-step ({len(acc[k])} dispatches)")
 PY
