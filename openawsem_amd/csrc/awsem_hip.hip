@@ -299,6 +299,8 @@ private:
                 cell_stale_ = true;
                 throw std::string("neighbour list overflow on the cell-list path during dynamics: raise AWSEM_CELL_NEIGHBORS (partners reserved per contact site, default 96, grown to twice the fullest row when dynamics start)");
             }
+            if (st & 4) throw std::string("a force exceeded the range of the fp32 fixed-point accumulators (2.6e5 kJ/mol/nm): overlapping atoms or an exploding "
+                                          "trajectory -- minimise the structure first (awsem_minimize), reduce the time step, or use the fp64 mode");
             throw std::string("pair list overflow on the device (internal error: list capacity below the candidate pair count)");
         }
     }

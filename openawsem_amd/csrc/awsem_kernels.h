@@ -1398,6 +1398,9 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
                     const R3<real> fv = L.force(gi.vs[q]);
                     F.x += gi.w[q] * fv.x; F.y += gi.w[q] * fv.y; F.z += gi.w[q] * fv.z;
                 }
+                // fp32 accumulators hold +-5.2e5 kJ/mol/nm per component (Q19.12): a force beyond half of that means overlapping
+                // atoms -- flag it (bit 2 of the status word) instead of letting the fixed-point sums wrap silently
+                if (sizeof(real) == 4 && !(fabsf((float)F.x) < 2.6e5f && fabsf((float)F.y) < 2.6e5f && fabsf((float)F.z) < 2.6e5f)) atomicOr(S.status, 4);
                 real g[3];
                 gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, mi.id, g);
                 const real im = fs * mi.inv_mass, sq = ns * mi.sqrt_inv_mass;

@@ -152,3 +152,18 @@ def test_annealing_folds_1r69_towards_its_native_structure():
     q, e = ctx.energy(1 << 1), ctx.energy()
     assert q0 < 0.2 and q.mean() > 0.45 and (q > 0.4).mean() > 0.7, (q0, q.mean())
     assert e.mean() < e0 - 500.0, (e0, e.mean())
+
+
+def test_exploding_forces_are_reported_not_wrapped():
+    """Two bonded atoms placed 40 nm from their rest length: 2e6 kJ/mol/nm, beyond the Q19.12 range of the fp32 accumulators."""
+    system = System(np.array([12.0, 12.0]))
+    f = HarmonicBondForce(group=20)
+    f.addBond(0, 1, 0.38, 50208.0)
+    system.addForce(f)
+    ctx = _capi.Context(_capi.load_hip_library(), 2, n_replicas=1, precision=0)
+    system.upload(ctx)
+    ctx.set_positions(np.array([[0.0, 0.0, 0.0], [40.0, 0.0, 0.0]]))
+    ctx.set_velocities_to_temperature([300.0], 1)
+    with pytest.raises(_capi.AwsemError, match="fixed-point accumulators"):
+        ctx.step(1, [300.0], 0.002, 1.0, 1)
+        ctx.synchronize()
