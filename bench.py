@@ -79,6 +79,23 @@ def _measured_traffic(args, oa):
     return None if best is None else best["hbm_bytes_per_launch"]
 
 
+def _measured_valu(args):
+    """VALU instructions per replica-step of the step kernel from the newest committed SQ counter pass (profiles/*_pmc_sq.txt,
+    collected by tools/pmc_sq.sh on the default workload); None for any other configuration."""
+    import glob
+    import re
+    if args.workload != "1r69" or args.replicas != 1024 or args.md_steps != 50 or args.precision != "fp32" or args.folded:
+        return None
+    natural = lambda f: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(f))]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_sq.txt")), key=natural)
+    if not files:
+        return None
+    for line in open(files[-1]):
+        if line.startswith("SQ_INSTS_VALU "):
+            return float(line.split()[1])
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,6 +228,13 @@ def main():
                                  ("state is LDS-resident across the launch, so the kernel is VALU/LDS-bound, not HBM-bound "
                                   "(see DESIGN.md); the HBM fraction is reported because the metric asks for it")},
         }
+        valu = None if synthetic else _measured_valu(args)
+        if valu is not None:
+            # the view SURVEY section 8(d) asks for next to the HBM fraction: wave64 VALU instruction = 4 cycles on a 16-lane SIMD,
+            # 4 SIMDs per CU, R / 256 replicas per CU, 2.4 GHz
+            cu_cycles_per_step = k_ms * 1e-3 / args.md_steps * 2.4e9
+            out["roofline"]["valu"] = {"insts_per_replica_step": valu, "busy_frac": (R / 256.0) * valu * 4.0 / 4.0 / cu_cycles_per_step,
+                                       "source": "profiles/*_pmc_sq.txt (rocprofv3 --pmc SQ_INSTS_VALU), newest"}
         if remd is not None:
             out["config"]["remd_acceptance"] = [round(float(a), 3) for a in remd.acceptance()[:8]]
         if not args.no_cpu_baseline and world == 1 and args.workload == "1r69":
