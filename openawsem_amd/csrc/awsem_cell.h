@@ -716,3 +716,87 @@ __global__ void cell_integrate_kernel(DevSys<real> S, CellSys<real> C, real* __r
         L.px[i] += dtr * vx; L.py[i] += dtr * vy; L.pz[i] += dtr * vz;
     }
 }
+
+// ------------------------------------------------------------------ energy minimiser on the cell-list path
+// The FIRE iteration of awsem_minimize_kernel (awsem_kernels.h) spread over grid-wide kernels: after a force pass,
+// cell_fire_sums_kernel reduces F.v, F.F, v.v over the massive particles of every replica (fixed point: order-independent),
+// cell_fire_update_kernel takes the per-replica decision -- every thread derives the same one from the sums and the
+// previous state, so no broadcast is needed -- and moves the particles.  State and sums are double buffered by iteration
+// parity, so nobody reads what another workgroup is writing.
+template <class real> struct FireState { real dt, alpha; int npos, done, iters, pad; double rms; };
+
+template <class real> __device__ __forceinline__ R3<real> fire_force(const DevSys<real>& S, const CellView<real>& L, int k, int i) {
+    const GatherItem<real> gi = S.gather[k];
+    R3<real> F = L.force(i);
+#pragma unroll
+    for (int q = 0; q < AWSEM_MAX_GATHER; q++) {
+        if (gi.vs[q] < 0) continue;
+        const R3<real> fv = L.force(gi.vs[q]);
+        F.x += gi.w[q] * fv.x; F.y += gi.w[q] * fv.y; F.z += gi.w[q] * fv.z;
+    }
+    return F;
+}
+#define AWSEM_FIRE_SP (1.0 / 1024.0)
+#define AWSEM_FIRE_SF (1.0 / (1024.0 * 1024.0))
+template <class real> __global__ void cell_fire_sums_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos, const real* __restrict__ vel,
+                                                            u64* __restrict__ sums /* [R][3] of this parity */, const FireState<real>* __restrict__ state) {
+    const int rep = blockIdx.y, n = C.natoms;
+    if (state[rep].done) return;
+    const CellView<real> L = cell_view(S, C, pos, rep);
+    const real* v = vel + (size_t)rep * 3 * n;
+    Energy eP, eF, eV;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S.nmassive; k += gridDim.x * blockDim.x) {
+        const int i = S.massive[k].atom;
+        const R3<real> F = fire_force(S, L, k, i);
+        const real vx = v[i], vy = v[n + i], vz = v[2 * (size_t)n + i];
+        eP += (double)(F.x * vx + F.y * vy + F.z * vz) * AWSEM_FIRE_SP;
+        eF += (double)(F.x * F.x + F.y * F.y + F.z * F.z) * AWSEM_FIRE_SF;
+        eV += (double)(vx * vx + vy * vy + vz * vz);
+    }
+    __shared__ u64 part[3];
+    if (threadIdx.x < 3) part[threadIdx.x] = 0;
+    __syncthreads();
+    u64 s[3] = {eP.v, eF.v, eV.v};
+    for (int q = 0; q < 3; q++) {
+        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off);
+        if ((threadIdx.x & 63) == 0 && s[q] != 0) fixed_add(&part[q], s[q]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && part[threadIdx.x] != 0) fixed_add(&sums[3 * rep + threadIdx.x], part[threadIdx.x]);   // one atomic per workgroup and sum
+}
+template <class real> __global__ void cell_fire_update_kernel(DevSys<real> S, CellSys<real> C, real* __restrict__ pos, real* __restrict__ vel,
+                                                              const u64* __restrict__ sums, u64* __restrict__ sums_next,
+                                                              const FireState<real>* __restrict__ state, FireState<real>* __restrict__ state_next, double tolerance) {
+    const int rep = blockIdx.y, n = C.natoms;
+    const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+    if (blockIdx.x == 0 && threadIdx.x < 3) sums_next[3 * rep + threadIdx.x] = 0;   // the other parity: idle during this kernel
+    FireState<real> st = state[rep];
+    if (st.done) { if (writer) state_next[rep] = st; return; }
+    const double P = fixed_to_double(sums[3 * rep]) / AWSEM_FIRE_SP, FF = fixed_to_double(sums[3 * rep + 1]) / AWSEM_FIRE_SF, VV = fixed_to_double(sums[3 * rep + 2]);
+    st.rms = ::sqrt(FF / (3.0 * (S.nmassive > 0 ? S.nmassive : 1)));
+    if (st.rms <= tolerance) { st.done = 1; if (writer) state_next[rep] = st; return; }   // the coordinates stay as they are
+    const real dt_max = (real)0.01, dmax2 = (real)(0.02 * 0.02);
+    real keep = 0, mix = 0;
+    if (P >= 0) {
+        keep = (real)1 - st.alpha; mix = st.alpha * (real)::sqrt(VV / FF);
+        if (++st.npos > 5) { st.dt = st.dt * (real)1.1 < dt_max ? st.dt * (real)1.1 : dt_max; st.alpha *= (real)0.99; }
+    } else { st.npos = 0; st.dt *= (real)0.5; st.alpha = (real)0.1; }
+    st.iters++;
+    if (writer) state_next[rep] = st;
+    const real dt = st.dt;
+    const CellView<real> L = cell_view(S, C, pos, rep);
+    real* v = vel + (size_t)rep * 3 * n;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S.nmassive; k += gridDim.x * blockDim.x) {
+        const int i = S.massive[k].atom;
+        const R3<real> F = fire_force(S, L, k, i);
+        L.zero_force(i);   // the sites' accumulators are cleared by the next pre kernel
+        const real vx = keep * v[i] + mix * F.x + dt * F.x;
+        const real vy = keep * v[n + i] + mix * F.y + dt * F.y;
+        const real vz = keep * v[2 * (size_t)n + i] + mix * F.z + dt * F.z;
+        v[i] = vx; v[n + i] = vy; v[2 * (size_t)n + i] = vz;
+        real dx = dt * vx, dy = dt * vy, dz = dt * vz;
+        const real d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 > dmax2) { const real sc = M<real>::sqrt(dmax2 / d2); dx *= sc; dy *= sc; dz *= sc; }
+        L.px[i] += dx; L.py[i] += dy; L.pz[i] += dz;
+    }
+}

@@ -192,7 +192,7 @@ public:
         end_async();   // asynchronous: resolved by synchronize() / last_kernel_ms
     }
     void minimize(double tolerance, int max_iterations, int32_t* iterations, double* rms) override {
-        if (cell_mode_) throw std::string("minimize: the device minimiser runs on the replica-resident path only (this system takes the cell-list path)");
+        if (cell_mode_) { cell_minimize(tolerance, max_iterations > 0 ? max_iterations : 100000, iterations, rms); return; }
         if (!step_ok_) throw std::string("minimize: the replica does not fit the LDS of one CU together with its velocities in this precision");
         HIP_TRY(hipSetDevice(device_));
         if (!dmin_it_) { dmin_it_ = dalloc<int>(nrep_); dmin_rms_ = dalloc<double>(nrep_); }
@@ -399,6 +399,7 @@ private:
     void cell_evaluate(bool energy, unsigned mask, int redistribute, double* e, double* f);
     void cell_step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0);
     void cell_one_step(double dt, double friction, uint64_t seed, int offset);
+    void cell_minimize(double tolerance, int max_iterations, int32_t* iterations, double* rms);
     struct CellGraph { hipGraphExec_t exec = nullptr; double dt = 0, friction = 0; uint64_t seed = 0; long long gen = -1; };
     long long cell_rows_gen_ = 0;          // bumped whenever the neighbour rows are re-allocated (captured graphs hold their addresses)
     HbRows cell_hb_beta_[AWSEM_MAX_BETA] = {}, cell_hb_pap_[AWSEM_MAX_PAP] = {};   // donor rows of the hydrogen-bond terms
@@ -1344,6 +1345,61 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
     hipLaunchKernelGGL(cell_vsite_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, pos_);
     HIP_TRY(hipGetLastError());
     end_async();
+}
+// FIRE on the cell-list path: the resident kernel's iteration (awsem_minimize_kernel) as a sequence of grid-wide kernels;
+// the host looks at the per-replica `done` flags every 25 iterations.
+template <class real> void Engine<real>::cell_minimize(double tolerance, int max_iterations, int32_t* iterations, double* rms) {
+    HIP_TRY(hipSetDevice(device_));
+    synchronize();
+    const size_t R = nrep_, nstate = R * 3 * natoms_;
+    real* fv = dalloc<real>(nstate);                               // FIRE velocities (the trajectory's velocities stay untouched)
+    FireState<real>* st = dalloc<FireState<real>>(2 * R);
+    u64* sums = dalloc<u64>(2 * 3 * R);
+    std::vector<FireState<real>> h(2 * R);
+    for (auto& s : h) { s.dt = (real)0.001; s.alpha = (real)0.1; s.npos = 0; s.done = 0; s.iters = 0; s.pad = 0; s.rms = 0; }
+    HIP_TRY(hipMemcpy(st, h.data(), h.size() * sizeof(FireState<real>), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(fv, 0, nstate * sizeof(real), stream_));
+    HIP_TRY(hipMemsetAsync(sums, 0, 2 * 3 * R * sizeof(u64), stream_));
+    HIP_TRY(hipMemsetAsync(cell_.f, 0, nstate * sizeof(u64), stream_));
+    HIP_TRY(hipEventRecord(ev0_, stream_));
+    cell_stale_ = true;
+    const dim3 g = cell_grid(dsys_.nmassive), b(256);
+    int it = 0;
+    bool all_done = false;
+    while (it < max_iterations && !all_done) {
+        const int chunk = std::min(25, max_iterations - it);
+        for (int c = 0; c < chunk; c++, it++) {
+            const int p = it & 1;
+            cell_pre(true);
+            cell_refresh(cell_);
+            cell_forces_pass(false, 0xffffffffu);
+            hipLaunchKernelGGL(cell_fire_sums_kernel<real>, g, b, 0, stream_, dsys_, cell_, pos_, fv, sums + 3 * R * p, st + R * p);
+            hipLaunchKernelGGL(cell_fire_update_kernel<real>, g, b, 0, stream_, dsys_, cell_, pos_, fv, sums + 3 * R * p, sums + 3 * R * (p ^ 1),
+                               st + R * p, st + R * (p ^ 1), tolerance);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream_));
+        int stw = 0;
+        HIP_TRY(hipMemcpy(&stw, dstatus_, sizeof stw, hipMemcpyDeviceToHost));
+        if (stw & 2) {   // a neighbour row overflowed while the structure relaxed: reserve more and carry on (the rows are rebuilt)
+            HIP_TRY(hipMemset(dstatus_, 0, sizeof stw));
+            cell_per_site_ *= 2;
+            if (cell_per_site_ > 8192) throw std::string("cell-list path: neighbour rows keep overflowing during the minimisation");
+            cell_alloc_lists();
+        }
+        HIP_TRY(hipMemcpy(h.data(), st + R * (it & 1), R * sizeof(FireState<real>), hipMemcpyDeviceToHost));
+        all_done = true;
+        for (size_t r = 0; r < R; r++) all_done = all_done && h[r].done;
+    }
+    hipLaunchKernelGGL(cell_vsite_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, pos_);
+    HIP_TRY(hipMemsetAsync(cell_.f, 0, nstate * sizeof(u64), stream_));
+    HIP_TRY(hipEventRecord(ev1_, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    record_ms();
+    HIP_TRY(hipMemcpy(h.data(), st + R * (it & 1), R * sizeof(FireState<real>), hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < R; r++) { if (iterations) iterations[r] = h[r].iters; if (rms) rms[r] = h[r].rms; }
+    dfree(fv); dfree(st); dfree(sums);
+    cell_stale_ = true;
 }
 template <class real> int Engine<real>::cell_neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) {
     const bool hb = kind == AWSEM_LIST_BETA || kind == AWSEM_LIST_PAP;

@@ -279,8 +279,8 @@ class Simulation:
         self.currentStep = 0
 
     def minimizeEnergy(self, tolerance=10.0, maxIterations=0):
-        """All replicas at once on the device (FIRE, awsem_minimize); systems on the cell-list path fall back to the
-        host-driven L-BFGS of `minimize`, one replica at a time."""
+        """All replicas at once on the device (FIRE, awsem_minimize) on either path; should the library report the device
+        minimiser unavailable (AWSEM_ELIMIT), the host-driven L-BFGS of `minimize` takes over, one replica at a time."""
         from ._capi import AwsemError
         tol = _value(tolerance, u.kilojoule_per_mole / u.nanometer)
         try:

@@ -172,3 +172,33 @@ def test_synthetic_multichain_system_takes_the_cell_path():
     gpu.step(200, [300.0], 0.002, 1.0, 1)
     e2 = gpu.energy_by_group()
     assert np.isfinite(e2).all() and not np.array_equal(e2, eg)
+
+
+def test_cell_path_minimiser_follows_the_resident_one(monkeypatch):
+    """awsem_minimize on the cell-list path is the resident kernel's FIRE iteration spread over grid-wide kernels: in fp64 the
+    first 25 iterations agree to summation noise, and a full minimisation reaches the tolerance in a minimum of the same depth."""
+    oa, traj, _ = golden_system("1ubq")
+    system = _full_system(oa)
+    res = {}
+    for cell in (False, True):
+        ctx = _ctx(system, 2, 1, cell, monkeypatch)
+        ctx.set_positions(traj[3], replica=0)
+        ctx.set_positions(traj[9], replica=1)
+        ctx.compute_virtual_sites()
+        ctx.minimize(1e-6, 25)
+        x25 = ctx.get_state(velocities=False)[0]
+        it, rms = ctx.minimize(10.0, 20000)
+        res[cell] = (x25, it, rms, ctx.energy(), ctx.get_state(velocities=False)[0])
+    assert np.abs(res[True][0] - res[False][0]).max() < 1e-7
+    assert np.all(res[True][2] <= 10.0) and np.all(res[True][1] < 20000)
+    assert np.all(np.abs(res[True][3] - res[False][3]) < 0.02 * np.abs(res[False][3])), (res[True][3], res[False][3])
+    # the synthetic multi-chain system is what the path exists for: all replicas relaxed on the device
+    with contextlib.redirect_stdout(io.StringIO()):
+        big = workloads.build_synthetic(n_chains=4, seed=5, hbonds=True)
+    monkeypatch.setenv("AWSEM_FORCE_CELL", "1")
+    ctx = _capi.Context(_capi.load_hip_library(), big.natoms, 2, precision=0)
+    big.system.upload(ctx)
+    ctx.set_positions(big.pdb.positions)
+    e0 = ctx.energy()
+    it, rms = ctx.minimize(10.0, 5000)
+    assert np.all(rms <= 10.0) and np.all(ctx.energy() < e0), (it, rms)
