@@ -226,7 +226,7 @@ int awsem_set_step_count(awsem_handle h, int64_t step);
  * (kJ/mol/nm) or max_iterations force evaluations are spent (0 = no limit); virtual sites follow their parents,
  * velocities are left untouched.  The algorithm is FIRE, not OpenMM's L-BFGS: the reference pins only the contract
  * (a nearby local minimum within the force tolerance).  iterations / rms_force: n_replicas values each, or NULL.
- * Replica-resident path only (AWSEM_ELIMIT on the cell-list path). */
+ * Both paths: one workgroup per replica on the replica-resident path, the same iteration as grid-wide kernels on the cell-list path. */
 int awsem_minimize(awsem_handle h, double tolerance_kj_mol_nm, int max_iterations, int32_t* iterations,
                    double* rms_force);
 
