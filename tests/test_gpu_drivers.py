@@ -185,7 +185,7 @@ def test_awsem_remd_runs_a_ladder_and_restarts(tmp_path, monkeypatch):
 
 def test_awsem_run_on_the_cell_list_path(tmp_path, monkeypatch):
     """The same driver with the system forced onto the cell-list path (what a protein of more than ~390 residues takes by
-    itself): host-driven minimiser fallback, reporters, checkpoint -- and the same physics: with identical seeds the short
+    itself): device minimiser, reporters, checkpoint -- and the same physics: with identical seeds the short
     fp64 trajectories of the two paths agree."""
     from openawsem_amd.scripts import mm_run
     src = data_path.data / "1r69"
@@ -207,7 +207,7 @@ def test_awsem_run_on_the_cell_list_path(tmp_path, monkeypatch):
         with np.load(out / "ensemble_final.npz") as z:
             finals[cell] = z["positions"].copy()
     assert np.abs(finals["1"] - finals["0"]).max() < 1e-6
-    # and the minimiser fallback of the cell path reaches the tolerance too
+    # and with the minimisation switched on (the cell path has its own device minimiser)
     monkeypatch.setenv("AWSEM_FORCE_CELL", "1")
     monkeypatch.chdir(d)
     sim = mm_run.main(["1r69", "--to", str(tmp_path / "run_min"), "-s", "400", "-m", "0", "--tempStart", "300", "--seed", "5", "-f", forces])
