@@ -149,7 +149,7 @@ int awsem_add_gaussian_bonds(awsem_handle h, int group, int n, const int32_t* pa
  *             AWSEM_CV_HARMONIC:     E = cv_k/2 (S-x0)^2   qbias_term biasTerms.py:270-302 ("0.5*k_qbias*(q-q0)^2")
  *             AWSEM_CV_SQRT:         E = cv_k sqrt(S)      rg_term biasTerms.py:461-486 ("unit*rg_square^0.5")
  *             AWSEM_CV_SQRT_SQUARE:  E = cv_k (sqrt(S)-x0)^2   rg_bias_term biasTerms.py:489-528
- * Collective-variable kinds are available on the replica-resident path only. */
+ * Available on both paths. */
 #define AWSEM_BOND_GAUSS 0
 #define AWSEM_BOND_R2 1
 #define AWSEM_CV_SUM 0

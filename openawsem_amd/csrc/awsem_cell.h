@@ -54,6 +54,8 @@ template <class real> struct CellSys {
     // accumulators, per replica
     u64* f;                     // [R][3][natoms]
     u64* eg;                    // [R][32]
+    u64* cv;                    // [R][n_cv] sums of the collective-variable terms (2^-48 fixed point); cleared by the pre kernel
+    int n_cv;
     u64 *rho, *drho;            // [R][nsites]
     real *rhov, *alpha, *dalpha;
     real* ref;                  // [R][3][natoms] positions at the last build
@@ -82,6 +84,7 @@ template <class real> __device__ inline CellView<real> cell_view(const DevSys<re
         L.satom = const_cast<int*>(d.atom);
     } else L.satom = nullptr;
     L.eg = C.eg + (size_t)rep * AWSEM_NGROUPS;
+    L.cv = C.cv ? C.cv + (size_t)rep * C.n_cv : nullptr;
     L.lcount = nullptr; L.flag = nullptr; L.lists = nullptr;
     return L;
 }
@@ -148,6 +151,7 @@ template <bool STEP, class real> __global__ void cell_pre_kernel(DevSys<real> S,
     int* bb = C.bbox + ((size_t)rep * C.nblk_pre + blockIdx.x) * 8;   // read by cell_geom_kernel of this step only
     if (threadIdx.x < 3) { bb[threadIdx.x] = slo[threadIdx.x]; bb[4 + threadIdx.x] = shi[threadIdx.x]; }
     if (blockIdx.x == 0 && threadIdx.x == 0) C.flag[2 * rep + (cur ^ 1)] = 0;   // nobody reads or writes the other flag during this step
+    if (blockIdx.x == 0 && (int)threadIdx.x < C.n_cv) C.cv[(size_t)rep * C.n_cv + threadIdx.x] = 0;
 }
 
 // ------------------------------------------------------------------ rebuild (all kernels exit at once unless flagged)
@@ -520,7 +524,7 @@ template <class real> __device__ inline CellView<real> cell_view_plain(const Cel
     L.px = p; L.py = p + n; L.pz = p + 2 * n;
     u64* f = C.f + (size_t)rep * 3 * n;
     L.fx = f; L.fy = f + n; L.fz = f + 2 * n;
-    L.rho = L.drho = nullptr; L.rhov = L.alpha = L.dalpha = L.gamma = nullptr; L.satom = nullptr;
+    L.rho = L.drho = nullptr; L.rhov = L.alpha = L.dalpha = L.gamma = nullptr; L.satom = nullptr; L.cv = nullptr;
     L.eg = C.eg + (size_t)rep * AWSEM_NGROUPS;
     L.lcount = nullptr; L.flag = nullptr; L.lists = nullptr;
     return L;
@@ -595,7 +599,7 @@ template <bool ENERGY, class real> __global__ void cell_hb_eval_kernel(HbTerms<r
 
 // Bonded terms: one workgroup per 256 items of one term (job table built at finalize).
 struct CellJob { int kind, term, first; };
-enum { CJ_HARM, CJ_CHI, CJ_RAMA, CJ_HELICAL, CJ_FM, CJ_MEMB, CJ_DH, CJ_GAUSS };
+enum { CJ_HARM, CJ_CHI, CJ_RAMA, CJ_HELICAL, CJ_FM, CJ_MEMB, CJ_DH, CJ_GAUSS, CJ_CV_SUM, CJ_CV_APPLY };
 template <bool ENERGY, class real> __global__ void cell_bonded_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos, const CellJob* __restrict__ jobs, unsigned mask) {
     const int rep = blockIdx.y;
     const CellView<real> L = cell_view(S, C, pos, rep);
@@ -610,6 +614,10 @@ template <bool ENERGY, class real> __global__ void cell_bonded_kernel(DevSys<rea
     case CJ_MEMB: { MembD<real> d = S.memb[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f); term_memb<ENERGY>(d, L); } break;
     case CJ_DH: { DhD<real> d = S.dh[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f); term_dh<ENERGY>(d, L); } break;
     case CJ_GAUSS: { GaussD<real> d = S.gauss[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f); term_gauss<ENERGY>(d, L); } break;
+    // collective-variable terms: the sum in a launch of its own (cell_cv_kernel), then energy (first job only) and forces
+    case CJ_CV_SUM: { GaussD<real> d = S.gauss[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f); cv_sum(d, L); } break;
+    case CJ_CV_APPLY: { GaussD<real> d = S.gauss[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f);
+                        if (f == 0) cv_apply<ENERGY>(d, L); else cv_apply<false>(d, L); } break;
     }
 }
 
@@ -630,7 +638,7 @@ template <bool ENERGY, class real> __global__ void cell_window_kernel(DevSys<rea
     WinView<real> L;
     L.px = &sp[0][0] - a0; L.py = &sp[1][0] - a0; L.pz = &sp[2][0] - a0;
     L.fx = &sf[0][0] - a0; L.fy = &sf[1][0] - a0; L.fz = &sf[2][0] - a0;
-    L.rho = L.drho = nullptr; L.rhov = L.alpha = L.dalpha = L.gamma = nullptr; L.satom = nullptr;
+    L.rho = L.drho = nullptr; L.rhov = L.alpha = L.dalpha = L.gamma = nullptr; L.satom = nullptr; L.cv = nullptr;
     L.lcount = nullptr; L.flag = nullptr; L.lists = nullptr;
     L.eg = C.eg + (size_t)rep * AWSEM_NGROUPS;
     __syncthreads();

@@ -421,6 +421,8 @@ private:
     std::vector<int> cell_wstart_, cell_nlocal_;            // per local bonded term (harm, chi, rama, helical, fm, memb order): window starts, local item count
     const int* cell_wstart_dev_ = nullptr;
     int cell_nwin_ = 0, cell_nslots_ = 0;
+    int cell_ncvjobs_ = 0;
+    const CellJob *cell_cv_sum_jobs_ = nullptr, *cell_cv_apply_jobs_ = nullptr;
 };
 
 // Order static items (bonds, dihedrals, virtual sites ...) so that the 64 items one wave handles in one
@@ -887,7 +889,6 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
                 it[b] = GaussItem<real>{h.pairs[2 * o], h.pairs[2 * o + 1], (real)(h.kind ? 0.0 : h.r0[o]),
                                         (real)(h.kind ? 0.0 : 0.5 / (h.sigma[o] * h.sigma[o])), (real)h.kg[o]};
             }
-            if (h.cv && cell_mode_) throw std::string("collective-variable terms (qbias_term, rg_term, ...) are not available on the cell-list path");
             D.push_back(GaussD<real>{h.group, (int)it.size(), upload(it), h.kind, h.cv, h.cv ? ncv++ : 0, 0, (real)h.cv_k, (real)h.cv_x0});
         }
         if (D.size() > AWSEM_MAX_GAUSS) throw std::string("too many bond-sum terms (Gaussian bonds, Q, Rg): at most " + std::to_string(AWSEM_MAX_GAUSS) + " per system");
@@ -1132,7 +1133,16 @@ template <class real> void Engine<real>::cell_setup(DevSys<real>& S, const HostS
     for (int t = 0; t < S.n_fm; t++) add(CJ_FM, t, S.fm[t].n, true);
     for (int t = 0; t < S.n_memb; t++) add(CJ_MEMB, t, S.memb[t].n, true);
     for (int t = 0; t < S.n_dh; t++) add(CJ_DH, t, S.dh[t].n, false);
-    for (int t = 0; t < S.n_gauss; t++) add(CJ_GAUSS, t, hgauss_[t].n, false);
+    std::vector<CellJob> cv_sum_jobs, cv_apply_jobs;   // collective-variable terms: the sums in one launch, energy + forces in the next
+    for (int t = 0; t < S.n_gauss; t++) {
+        if (!hgauss_[t].cv) { add(CJ_GAUSS, t, hgauss_[t].n, false); continue; }
+        for (int f = 0; f < std::max(1, hgauss_[t].n); f += 256) { cv_sum_jobs.push_back(CellJob{CJ_CV_SUM, t, f}); cv_apply_jobs.push_back(CellJob{CJ_CV_APPLY, t, f}); }
+    }
+    cell_ncvjobs_ = (int)cv_sum_jobs.size();
+    cell_cv_sum_jobs_ = upload(cv_sum_jobs); cell_cv_apply_jobs_ = upload(cv_apply_jobs);
+    C.n_cv = S.n_cv;
+    C.cv = dalloc<u64>(R * std::max(1, S.n_cv));
+    HIP_TRY(hipMemset(C.cv, 0, R * std::max(1, S.n_cv) * sizeof(u64)));
     cell_nslots_ = slot;
     cell_nwin_ = (natoms_ + AWSEM_WIN - 1) / AWSEM_WIN;
     if ((size_t)cell_nslots_ * (cell_nwin_ + 1) != cell_wstart_.size()) throw std::string("internal error: window tables out of step with the bonded terms");
@@ -1215,6 +1225,15 @@ template <class real> void Engine<real>::cell_forces_pass(bool energy, unsigned 
     if (cell_njobs_) {
         if (energy) hipLaunchKernelGGL((cell_bonded_kernel<true, real>), dim3(cell_njobs_, nrep_), b, 0, stream_, S, C, pos_, cell_jobs_, mask);
         else hipLaunchKernelGGL((cell_bonded_kernel<false, real>), dim3(cell_njobs_, nrep_), b, 0, stream_, S, C, pos_, cell_jobs_, mask);
+    }
+    if (cell_ncvjobs_) {
+        if (energy) {
+            hipLaunchKernelGGL((cell_bonded_kernel<true, real>), dim3(cell_ncvjobs_, nrep_), b, 0, stream_, S, C, pos_, cell_cv_sum_jobs_, mask);
+            hipLaunchKernelGGL((cell_bonded_kernel<true, real>), dim3(cell_ncvjobs_, nrep_), b, 0, stream_, S, C, pos_, cell_cv_apply_jobs_, mask);
+        } else {
+            hipLaunchKernelGGL((cell_bonded_kernel<false, real>), dim3(cell_ncvjobs_, nrep_), b, 0, stream_, S, C, pos_, cell_cv_sum_jobs_, mask);
+            hipLaunchKernelGGL((cell_bonded_kernel<false, real>), dim3(cell_ncvjobs_, nrep_), b, 0, stream_, S, C, pos_, cell_cv_apply_jobs_, mask);
+        }
     }
     auto row_blocks = [](int n) { return (int)std::max(1LL, std::min(((long long)n * AWSEM_ROW + 255) / 256, 16384LL)); };
     const bool contact_on = S.n_contact && ((mask >> S.contact[0].group) & 1u);
