@@ -84,11 +84,17 @@ int awsem_add_excl(awsem_handle h, int group, int nsites, const int32_t* atom, c
 /* contact_term contactTerms.py:99-375 (CustomGBForce: density rho, direct + mediated pair energy, burial)
  * and burial_term contactTerms.py:1772-1840 (flags & AWSEM_CONTACT_BURIAL_ONLY).
  * Sites are the nres "CB, or CA for glycine" atoms.  gamma is [env 0..1][kind 0=direct,1=protein,2=water][20][20],
- * burial_gamma is [20][3] or NULL (burialPartOn=False).  dparams: see awsem_contact_dparam below. */
+ * burial_gamma is [20][3] ([2][20][3] with AWSEM_CONTACT_MEMBRANE_BURIAL) or NULL (burialPartOn=False).
+ * dparams: see awsem_contact_dparam below. */
 enum {
     AWSEM_CONTACT_ZDEP = 1,         /* z_dependent=True: blend env 0 / env 1 with alphaMembrane(z) */
     AWSEM_CONTACT_BURIAL_ONLY = 2,  /* standalone burial_term: no pair energy */
-    AWSEM_CONTACT_NOCUTOFF = 4      /* burial_term never calls setNonbondedMethod -> NoCutoff */
+    AWSEM_CONTACT_NOCUTOFF = 4,     /* burial_term never calls setNonbondedMethod -> NoCutoff */
+    AWSEM_CONTACT_INDEX_BASED = 16, /* index_based_contact_term contactTerms.py:668-876: gamma is [3][nsites][nsites] and burial_gamma
+                                       [nsites][3], both by site (= residue) index; the pair (i < j) reads gamma[kind][i][j];
+                                       restype is ignored; not combinable with the other flags */
+    AWSEM_CONTACT_MEMBRANE_BURIAL = 8  /* hybrid_contact_term contactTerms.py:1283-1289: burial_gamma is [water, membrane][20][3] and
+                                          the wells of site i are blended with (1 - alpha_i, alpha_i); needs AWSEM_CONTACT_ZDEP */
 };
 enum awsem_contact_dparam {
     AWSEM_CP_K = 0, AWSEM_CP_RMIN, AWSEM_CP_RMAX, AWSEM_CP_RMINII, AWSEM_CP_RMAXII, AWSEM_CP_ETA,

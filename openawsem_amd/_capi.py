@@ -183,7 +183,12 @@ class Context:
         dp = _f64(dparams)
         g = None if gamma is None else _f64(gamma).reshape(-1)
         bg = None if burial_gamma is None else _f64(burial_gamma).reshape(-1)
-        assert len(dp) == 20 and (g is None or len(g) == 2400) and (bg is None or len(bg) == 60)
+        n = len(a)
+        if int(flags) & 16:      # index based: tables by site
+            assert g is not None and len(g) == 3 * n * n and (bg is None or len(bg) == 3 * n)
+        else:
+            assert (g is None or len(g) == 2400) and (bg is None or len(bg) == (120 if int(flags) & 8 else 60))
+        assert len(dp) == 20
         self._call("add_contact", group, len(a), _ip(a), _ip(t), _ip(r), _ip(ch), int(env), int(min_seq_sep), int(flags),
                    _dp(dp), _dp(g), _dp(bg))
 

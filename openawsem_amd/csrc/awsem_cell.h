@@ -454,7 +454,8 @@ template <bool ENERGY, class real> __global__ void cell_pairs_kernel(DevSys<real
             const real sj = L.rhov[j], aj = zdep ? L.alpha[j] : (real)0;
             // the type pair as the lower site sees it (what the half lists of the resident path hold)
             const int ty = i < j ? ti * 20 + tj : tj * 20 + ti;
-            const PairTerms<real> t = contact_pair_math(d, L.gamma, ty, r, si * sj, ai * aj);
+            const PairTerms<real> t = (d.flags & 16) ? contact_pair_math<true>(d, d.gamma, (i < j ? i : j) * d.nsites + (i < j ? j : i), r, si * sj, ai * aj)
+                                                     : contact_pair_math(d, L.gamma, ty, r, si * sj, ai * aj);
             if (ENERGY) en += (double)((real)0.5 * t.E);
             const real c = -t.dEdr * ir * (real)AWSEM_FIXED_SCALE;
             X += to_fixed_scaled(c * dx); Y += to_fixed_scaled(c * dy); Z += to_fixed_scaled(c * dz);

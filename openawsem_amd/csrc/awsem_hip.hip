@@ -1596,13 +1596,26 @@ int awsem_add_contact(awsem_handle h, int group, int nsites, const int32_t* atom
     if (nsites < 0 || !dparams || (nsites && (!atom || !restype || !resid || !chain)) || !atoms_ok(h, atom, nsites) || env < 0 || env > 1)
         return fail(AWSEM_EINVAL, "add_contact: bad arguments");
     if (!(flags & AWSEM_CONTACT_BURIAL_ONLY) && !gamma) return fail(AWSEM_EINVAL, "add_contact: gamma table required");
+    if ((flags & AWSEM_CONTACT_MEMBRANE_BURIAL) && (!(flags & AWSEM_CONTACT_ZDEP) || !bgamma))
+        return fail(AWSEM_EINVAL, "add_contact: membrane burial wells need the z-dependent variant and a [2][20][3] burial table");
+    const bool indexed = flags & AWSEM_CONTACT_INDEX_BASED;
+    if (indexed && (flags & (AWSEM_CONTACT_ZDEP | AWSEM_CONTACT_MEMBRANE_BURIAL | AWSEM_CONTACT_BURIAL_ONLY)))
+        return fail(AWSEM_EINVAL, "add_contact: the index-based variant has one environment and its own burial table");
     for (int i = 0; i < nsites; i++) if (restype[i] < 0 || restype[i] >= 20) return fail(AWSEM_EINVAL, "add_contact: residue type out of range 0..19");
     HContact c;
     c.group = group; c.env = env; c.min_seq_sep = min_seq_sep; c.flags = flags; c.has_burial = bgamma != nullptr;
     c.atom = vec(atom, nsites); c.restype = vec(restype, nsites); c.resid = vec(resid, nsites); c.chain = vec(chain, nsites);
     memcpy(c.p, dparams, sizeof c.p);
-    c.gamma = gamma ? vec(gamma, 2400) : std::vector<double>(2400, 0.0);
-    c.bgamma = bgamma ? vec(bgamma, 60) : std::vector<double>(60, 0.0);
+    if (indexed) {   // tables by site index: [3][nsites][nsites] and [nsites][3]
+        c.gamma = vec(gamma, 3 * (size_t)nsites * nsites);
+        c.bgamma = bgamma ? vec(bgamma, 3 * (size_t)nsites) : std::vector<double>(3 * (size_t)nsites, 0.0);
+        if (c.gamma.empty()) c.gamma.assign(3, 0.0);
+        if (c.bgamma.empty()) c.bgamma.assign(3, 0.0);
+    } else {
+        c.gamma = gamma ? vec(gamma, 2400) : std::vector<double>(2400, 0.0);
+        c.bgamma = bgamma ? vec(bgamma, (flags & AWSEM_CONTACT_MEMBRANE_BURIAL) ? 120 : 60) : std::vector<double>(60, 0.0);
+        c.bgamma.resize(120, 0.0);
+    }
     h->H.contact.push_back(std::move(c));
     return AWSEM_OK;
 }

@@ -720,25 +720,34 @@ template <bool ENERGY, class V> __device__ __forceinline__ void single_body(cons
     typedef typename V::real_t real;
     real rho = fixed_to_real(L.rho[i], (real)0);
     L.rhov[i] = sigmoid(-d.eta_s2 * (rho - d.rho0));
-    real dE = 0;
+    real dE = 0, al = 0, dal = 0;
+    if (d.flags & 1) {
+        real z = L.pos(atom).z - d.zc;
+        real su = sigmoid(d.eta_sw2 * (z + d.z_m)), sv = sigmoid(d.eta_sw2 * (d.z_m - z));
+        al = su + sv - (real)1;
+        dal = d.eta_sw2 * (su * ((real)1 - su) - sv * ((real)1 - sv));
+        L.alpha[i] = al;
+        L.dalpha[i] = dal;
+    }
     if (d.has_burial) {
-        int t = (d.info[i] >> 27) & 31;
+        int t = (d.flags & 16) ? i : (d.info[i] >> 27) & 31;   // index based: wells per site
+        real dz = 0;
 #pragma unroll
         for (int m = 0; m < 3; m++) {
             real gb = d.bgamma[t * 3 + m];
             // tanh(a) + tanh(b) = 2 (sig(2a) + sig(2b) - 1)
             real sa = sigmoid(d.kappa2 * (rho - d.rho_lo[m])), sb = sigmoid(d.kappa2 * (d.rho_hi[m] - rho));
+            if (d.flags & 8) {   // hybrid contact: the wells blend water and membrane depths with the site's own alpha(z)
+                const real gm = d.bgamma[60 + t * 3 + m];
+                dz += -d.kb * (gm - gb) * (sa + sb - (real)1);
+                gb = ((real)1 - al) * gb + al * gm;
+            }
             if (ENERGY) e += (double)(-d.kb * gb * (sa + sb - (real)1));
             dE += -d.kb * gb * d.kappa2 * (sa * ((real)1 - sa) - sb * ((real)1 - sb));
         }
+        if (d.flags & 8) L.add_fz(atom, -dz * dal);
     }
     L.drho[i] = to_fixed(dE);
-    if (d.flags & 1) {
-        real z = L.pos(atom).z - d.zc;
-        real su = sigmoid(d.eta_sw2 * (z + d.z_m)), sv = sigmoid(d.eta_sw2 * (d.z_m - z));
-        L.alpha[i] = su + sv - (real)1;
-        L.dalpha[i] = d.eta_sw2 * (su * ((real)1 - su) - sv * ((real)1 - sv));
-    }
 }
 template <bool ENERGY, class V> __device__ __forceinline__ void contact_single(const ContactD<typename V::real_t>& d, const V& L, const int* satom, int rot = 0) {
     Energy e;
@@ -749,16 +758,18 @@ template <bool ENERGY, class V> __device__ __forceinline__ void contact_single(c
 // contact_pair_math: the arithmetic for one pair at distance r (shared by the list-driven passes of both paths):
 // E, dE/dr, dE/d(sigma_water) and, for the z-dependent variant, M - W (membrane minus water energy).
 template <class real> struct PairTerms { real E, dEdr, dEdsw, MW; };
-template <class real> __device__ __forceinline__ PairTerms<real> contact_pair_math(const ContactD<real>& d, const real* g0, int ty, real r, real sw, real aa) {
+// INDEXED (index_based_contact_term): g0 is the global [3][nsites][nsites] table and ty = site_i * nsites + site_j.
+template <bool INDEXED = false, class real> __device__ __forceinline__ PairTerms<real> contact_pair_math(const ContactD<real>& d, const real* g0, int ty, real r, real sw, real aa) {
     const real* g1 = g0 + 1200;
+    const int plane = INDEXED ? d.nsites * d.nsites : 400;
     const real one = (real)1;
     const real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
     const real s3 = sigmoid(d.eta2 * (r - d.rminII)), s4 = sigmoid(d.eta2 * (d.rmaxII - r));
     const real th1 = s1 * s2, dth1 = d.eta2 * th1 * (s2 - s1);
     const real th2 = s3 * s4, dth2 = d.eta2 * th2 * (s4 - s3);
     PairTerms<real> o;
-    if (!(d.flags & 1)) {
-        const real gd = g0[ty], gp = g0[400 + ty], gw = g0[800 + ty];
+    if (INDEXED || !(d.flags & 1)) {
+        const real gd = g0[ty], gp = g0[plane + ty], gw = g0[2 * plane + ty];
         const real med = sw * gw + (one - sw) * gp;
         o.E = -d.k * (gd * th1 + th2 * med);
         o.dEdr = -d.k * (gd * dth1 + dth2 * med);
@@ -788,7 +799,8 @@ template <bool ENERGY, class V> __device__ __forceinline__ void pairs_body(const
     const real si = L.rhov[i], sj = L.rhov[j];
     real ai = 0, aj = 0;
     if (zdep) { ai = L.alpha[i]; aj = L.alpha[j]; }
-    const PairTerms<real> t = contact_pair_math(d, L.gamma, ty, r, si * sj, ai * aj);
+    const PairTerms<real> t = (d.flags & 16) ? contact_pair_math<true>(d, d.gamma, pass ? i * d.nsites + j : 0, r, si * sj, ai * aj)
+                                             : contact_pair_math(d, L.gamma, ty, r, si * sj, ai * aj);
     if (pass) {
         if (ENERGY) e += (double)t.E;
         L.pair_force(a, b, dd.x, dd.y, dd.z, -t.dEdr * ir);
@@ -1014,7 +1026,7 @@ template <class V> __device__ __forceinline__ void redistribute_forces(const Dev
 // Once per launch: contact site -> atom tables and (when the system has a single contact term) its gamma tables.
 template <class V> __device__ __forceinline__ void stage_contact_gamma(const ContactD<typename V::real_t>& d, const V& L) {
     typedef typename V::real_t real;
-    if (d.flags & 2) return;
+    if (d.flags & (2 | 16)) return;   // burial only: no pair tables; index based: read from global memory
     const int ng = (d.flags & 1) ? 2400 : 1200;
     const real* src = d.gamma + ((d.flags & 1) ? 0 : d.env * 1200);
     for (int i = threadIdx.x; i < ng; i += blockDim.x) L.gamma[i] = src[i];

@@ -113,7 +113,7 @@ class ExclForce(Force):
         return self.r_excl
 
 
-CONTACT_ZDEP, CONTACT_BURIAL_ONLY, CONTACT_NOCUTOFF = 1, 2, 4
+CONTACT_ZDEP, CONTACT_BURIAL_ONLY, CONTACT_NOCUTOFF, CONTACT_MEMBRANE_BURIAL, CONTACT_INDEX_BASED = 1, 2, 4, 8, 16
 
 
 class ContactForce(Force):
@@ -125,7 +125,7 @@ class ContactForce(Force):
         self.env, self.min_seq_sep, self.flags = 0, 10, 0
         self.dparams = np.zeros(20)
         self.gamma = None          # [2][3][20][20]: env x (direct, protein, water)
-        self.burial_gamma = None   # [20][3]
+        self.burial_gamma = None   # [20][3]; [2][20][3] (water, membrane) with CONTACT_MEMBRANE_BURIAL
         self.cutoff = 1.0
 
     def getCutoffDistance(self):

@@ -34,7 +34,8 @@ typedef struct {
     int *atom, *restype, *resid, *chain;
     double p[32];
     double gamma[2 * 3 * 400];
-    double bgamma[60];
+    double bgamma[120];   /* [20][3]; with flag 8 a second [20][3] block for the membrane */
+    double *gamma_idx, *bgamma_idx;   /* flag 16: [3][nsites][nsites] and [nsites][3] by site index */
 } contact_t;
 typedef struct {
     int group, two_theta, nacc, ndon, nres;
@@ -118,7 +119,7 @@ static void free_term(term_t* t) {
     case T_CHI: { chi_t* x = p; free(x->atoms); } break;
     case T_RAMA: { rama_t* x = p; free(x->atoms); free(x->wp); free(x->bw); } break;
     case T_EXCL: { excl_t* x = p; free(x->atom); free(x->cls); free(x->excl); } break;
-    case T_CONTACT: { contact_t* x = p; free(x->atom); free(x->restype); free(x->resid); free(x->chain); } break;
+    case T_CONTACT: { contact_t* x = p; free(x->atom); free(x->restype); free(x->resid); free(x->chain); free(x->gamma_idx); free(x->bgamma_idx); } break;
     case T_BETA: { beta_t* x = p; free(x->acc_atoms); free(x->acc_res); free(x->don_atoms); free(x->don_res); free(x->lambda); } break;
     case T_PAP: { pap_t* x = p; free(x->acc_atoms); free(x->acc_res); free(x->don_atoms); free(x->don_res); free(x->gamma); } break;
     case T_HELICAL: { helical_t* x = p; free(x->atoms); free(x->coef); } break;
@@ -194,9 +195,15 @@ int awsem_oracle_add_contact(ctx_t* c, int group, int nsites, const int* atom, c
     t->atom = dup_mem(atom, nsites * sizeof(int)); t->restype = dup_mem(restype, nsites * sizeof(int));
     t->resid = dup_mem(resid, nsites * sizeof(int)); t->chain = dup_mem(chain, nsites * sizeof(int));
     memcpy(t->p, dparams, 20 * sizeof(double));
-    if (gamma) memcpy(t->gamma, gamma, sizeof t->gamma);
     t->has_burial = bgamma != NULL;
-    if (bgamma) memcpy(t->bgamma, bgamma, sizeof t->bgamma);
+    if (flags & 16) {   /* index_based_contact_term: tables by site index */
+        if (flags & (1 | 2 | 8)) return fail(-1, "add_contact: the index-based variant has one environment and its own burial table");
+        t->gamma_idx = dup_mem(gamma, 3 * (size_t)nsites * nsites * sizeof(double));
+        if (bgamma) t->bgamma_idx = dup_mem(bgamma, 3 * (size_t)nsites * sizeof(double));
+        return add_term(c, T_CONTACT, t);
+    }
+    if (gamma) memcpy(t->gamma, gamma, sizeof t->gamma);
+    if (bgamma) memcpy(t->bgamma, bgamma, ((flags & 8) ? 120 : 60) * sizeof(double));
     return add_term(c, T_CONTACT, t);
 }
 int awsem_oracle_add_hbond_beta(ctx_t* c, int group, int two_theta, int nacc, const int* acc_atoms, const int* acc_res, int ndon,
@@ -513,7 +520,13 @@ static double eval_contact(const contact_t* t, const double* x, double* f) {
         double dsi = -0.5 * eta_s * (1 - ti * ti), dsj = -0.5 * eta_s * (1 - tj * tj);
         int ty = t->restype[i] * 20 + t->restype[j];
         double E = 0, dEdr = 0, dEdsw = 0;
-        if (!zdep) {
+        if (t->flags & 16) {   /* gamma_ijm(0, resId1, resId2) etc., contactTerms.py:853-860 */
+            const size_t n2 = (size_t)n * n, ij = (size_t)i * n + j;
+            double gd = t->gamma_idx[ij], gp = t->gamma_idx[n2 + ij], gw = t->gamma_idx[2 * n2 + ij];
+            E = -kc * (gd * th1 + th2 * (sw * gw + (1 - sw) * gp));
+            dEdr = -kc * (gd * dth1 + dth2 * (sw * gw + (1 - sw) * gp));
+            dEdsw = -kc * th2 * (gw - gp);
+        } else if (!zdep) {
             const double* g = t->gamma + t->env * 1200;
             double gd = g[ty], gp = g[400 + ty], gw = g[800 + ty];
             E = -kc * (gd * th1 + th2 * (sw * gw + (1 - sw) * gp));
@@ -539,8 +552,13 @@ static double eval_contact(const contact_t* t, const double* x, double* f) {
         pair_force(f, t->atom[i], t->atom[j], d, r, dEdr);
     }
     if (t->has_burial) for (int i = 0; i < n; i++) for (int m = 0; m < 3; m++) {   /* contactTerms.py:343-351 */
-        double gb = t->bgamma[t->restype[i] * 3 + m], lo = p[10 + m], hi = p[13 + m];
+        double gb = (t->flags & 16) ? t->bgamma_idx[i * 3 + m] : t->bgamma[t->restype[i] * 3 + m], lo = p[10 + m], hi = p[13 + m];
         double ta = tanh(kappa * (rho[i] - lo)), tb = tanh(kappa * (hi - rho[i]));
+        if (t->flags & 8) {   /* hybrid_contact_term, contactTerms.py:1283-1289: (1-alpha_i) water wells + alpha_i membrane wells */
+            double gm = t->bgamma[60 + t->restype[i] * 3 + m];
+            if (f) f[3 * t->atom[i] + 2] -= -0.5 * kb * (gm - gb) * (ta + tb) * dalpha[i];
+            gb = (1 - alpha[i]) * gb + alpha[i] * gm;
+        }
         e += -0.5 * kb * gb * (ta + tb);
         dEdrho[i] += -0.5 * kb * gb * kappa * ((1 - ta * ta) - (1 - tb * tb));
     }

@@ -1,0 +1,217 @@
+"""Research variants of the contact term: hybrid_contact_term (reference contactTerms.py:1110-1311) and
+index_based_contact_term (668-876).
+
+Parity unpinned by any reference fixture (no golden column, no example output), so: the parameter-file reader is checked
+against a loop-by-loop restatement of the file layout the reference documents by its own reading loops (1163-1184), the
+oracle's forces against finite differences of its energies, the blend against the golden-pinned contact term in the limits
+where the two must coincide, and the HIP kernels (both paths, both precisions) against the oracle."""
+import numpy as np
+import pytest
+
+from openawsem_amd import _capi, unit as u
+from openawsem_amd.forces import System
+from openawsem_amd.functionTerms import contactTerms
+from oracle import awsem_oracle
+from tests.common import golden_system
+from tests.test_oracle_forces import _fd_check
+
+
+def _gamma_file(tmp_path, values):
+    path = tmp_path / "hybrid_contact_gamma.dat"
+    np.savetxt(path, values)
+    return str(path)
+
+
+def _random_file(tmp_path, seed=3):
+    return _gamma_file(tmp_path, np.random.default_rng(seed).normal(0.0, 0.6, 1380))
+
+
+def _system_of(oa, force):
+    system = System(oa.system.masses.copy())
+    system.virtual_sites = dict(oa.system.virtual_sites)
+    system.addForce(force)
+    return system
+
+
+def _centred(x, oa):
+    """Put the membrane midplane through the protein so that alpha(z) takes the whole range over the sites."""
+    return x - np.array([0.0, 0.0, x[oa.ca, 2].mean()])
+
+
+def test_parameter_file_layout(tmp_path, capsys):
+    raw = np.random.default_rng(1).normal(size=1380)
+    gamma, burial = contactTerms.read_hybrid_gamma(_gamma_file(tmp_path, raw))
+    g, c = -raw, 0
+    for env in range(2):
+        for plane in range(3):             # direct, protein mediated, water mediated (contactTerms.py:1167-1175)
+            for i in range(20):
+                for j in range(i, 20):
+                    assert gamma[env, plane, i, j] == g[c] and gamma[env, plane, j, i] == g[c]
+                    c += 1
+    for env in range(2):                   # burial wells: [environment][well][residue type] (1177-1184)
+        for well in range(3):
+            for t in range(20):
+                assert burial[env, t, well] == g[c]
+                c += 1
+    assert c == 1380
+    with pytest.raises(ValueError):
+        contactTerms.read_hybrid_gamma(_gamma_file(tmp_path, raw[:-1]))
+
+
+def test_factory_follows_the_reference(tmp_path, capsys):
+    oa, _, _ = golden_system("1ubq")
+    f = contactTerms.hybrid_contact_term(oa, hybrid_gamma_file=_random_file(tmp_path))
+    assert f.getForceGroup() == 18 and f.getCutoffDistance() == 1.0 and f.min_seq_sep == 10
+    assert not f.gamma[0].any() and f.gamma[1].any()          # res_table(0, ...) is all zero in the reference (1187-1198)
+    assert f.burial_gamma.shape == (2, 20, 3)
+    g = contactTerms.hybrid_contact_term(oa, hybrid_gamma_file=_random_file(tmp_path), water_pair_part=True)
+    assert g.gamma[0].any()
+
+
+def test_oracle_forces_match_finite_differences(tmp_path, oracle_api, capsys):
+    oa, traj, _ = golden_system("1ubq")
+    f = contactTerms.hybrid_contact_term(oa, hybrid_gamma_file=_random_file(tmp_path), water_pair_part=True)
+    ctx = awsem_oracle.make_context(_system_of(oa, f), n_replicas=1)
+    x = _centred(traj[5], oa)
+    sites = np.array(f.atom)
+    atoms = np.random.default_rng(5).choice(sites, size=24, replace=False)
+    got, fd = _fd_check(ctx, x, 1 << 18, atoms)
+    assert np.abs(fd).max() > 1.0
+    assert np.abs(got - fd).max() / max(1.0, np.abs(fd).max()) < 2e-6
+
+
+def test_blend_reduces_to_the_pinned_contact_term(tmp_path, oracle_api, capsys):
+    """Same tables in both environments: the blend (1 - a) X + a X must give the z-independent, golden-pinned contact term."""
+    oa, traj, _ = golden_system("1ubq")
+    plain = contactTerms.contact_term(oa)
+    iu = np.triu_indices(20)
+    block = np.concatenate([plain.gamma[0, p][iu] for p in range(3)])
+    wells = np.asarray(plain.burial_gamma).T.reshape(-1)               # [well][type]
+    path = _gamma_file(tmp_path, -np.concatenate([block, block, wells, wells]))
+    hybrid = contactTerms.hybrid_contact_term(oa, hybrid_gamma_file=path, water_pair_part=True)
+    a = awsem_oracle.make_context(_system_of(oa, plain), n_replicas=1)
+    b = awsem_oracle.make_context(_system_of(oa, hybrid), n_replicas=1)
+    for frame in (0, 7):
+        x = _centred(traj[frame], oa)
+        a.set_positions(x, replica=0)
+        b.set_positions(x, replica=0)
+        ea, eb = a.energy_by_group()[0, 22], b.energy_by_group()[0, 18]
+        assert abs(ea) > 1.0 and abs(ea - eb) < 1e-9 * abs(ea)
+        assert np.abs(a.forces()[0] - b.forces()[0]).max() < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,etol,ftol", [(0, 1e-4, 1e-3), (1, 1e-9, 1e-7)])
+@pytest.mark.parametrize("cell", ["0", "1"])
+@pytest.mark.parametrize("water_pair_part", [False, True])
+def test_gpu_matches_oracle(tmp_path, precision, etol, ftol, cell, water_pair_part, monkeypatch, capsys):
+    monkeypatch.setenv("AWSEM_FORCE_CELL", cell)
+    oa, traj, _ = golden_system("1ubq")
+    f = contactTerms.hybrid_contact_term(oa, hybrid_gamma_file=_random_file(tmp_path), z_m=1.0, water_pair_part=water_pair_part)
+    system = _system_of(oa, f)
+    frames = [_centred(traj[k], oa) for k in (0, 5, 11)]
+    gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=len(frames), precision=precision)
+    system.upload(gpu)
+    cpu = awsem_oracle.make_context(system, n_replicas=len(frames))
+    for r, x in enumerate(frames):
+        gpu.set_positions(x, replica=r)
+        cpu.set_positions(x, replica=r)
+    eg, ec = gpu.energy_by_group()[:, 18], cpu.energy_by_group()[:, 18]
+    assert np.abs(ec).min() > 1.0
+    assert (np.abs(eg - ec) <= etol * np.abs(ec) + 2e-7).all()   # 2e-7: Q31.32 sums of terms of both signs
+    fg, fc = gpu.forces(redistribute=False), cpu.forces(redistribute=False)
+    assert np.abs(fc[:, :, 2]).max() > 1.0
+    assert np.abs(fg - fc).max() <= ftol * np.abs(fc).max() + (5e-3 if precision == 0 and cell == "0" else 1e-7 if precision else 1e-5)
+    gpu.close()
+
+
+# ------------------------------------------------------------------ index_based_contact_term
+def _index_folder(tmp_path, oa, from_types=None, seed=11, membrane=False):
+    """ff_contact/ with nres x nres tables: random symmetric ones, or the type tables of a contact_term spread over the
+    residues (gamma[type_i][type_j]), for which the index-based term must reproduce that contact term."""
+    folder = tmp_path / "ff_contact"
+    folder.mkdir(exist_ok=True)
+    n = oa.nres
+    rng = np.random.default_rng(seed)
+    suffix = "_mem" if membrane else ""
+    if from_types is None:
+        for name in ("direct", "protein", "water"):
+            t = rng.normal(0.0, 0.7, (n, n))
+            np.savetxt(folder / f"{name}{suffix}.dat", (t + t.T) / 2)
+        np.savetxt(folder / "burial.dat", rng.normal(0.0, 0.7, (n, 3)))
+    else:
+        ty = np.asarray(from_types.restype)
+        for plane, name in enumerate(("direct", "protein", "water")):
+            np.savetxt(folder / f"{name}{suffix}.dat", from_types.gamma[0, plane][np.ix_(ty, ty)])
+        np.savetxt(folder / "burial.dat", np.asarray(from_types.burial_gamma)[ty])
+    return str(folder)
+
+
+def test_index_based_factory(tmp_path, capsys):
+    oa, _, _ = golden_system("1ubq")
+    folder = _index_folder(tmp_path, oa)
+    f = contactTerms.index_based_contact_term(oa, gamma_folder=folder)
+    n = oa.nres
+    assert f.getForceGroup() == 22 and f.gamma.shape == (3, n, n) and f.burial_gamma.shape == (n, 3) and f.min_seq_sep == 10
+    assert np.array_equal(f.gamma[2], np.loadtxt(f"{folder}/water.dat")) and np.array_equal(f.gamma[1], np.loadtxt(f"{folder}/protein.dat"))
+    assert contactTerms.index_based_contact_term(oa, gamma_folder=folder, burialPartOn=False, forceGroup=5).burial_gamma is None
+    with pytest.raises(NotImplementedError):
+        contactTerms.index_based_contact_term(oa, gamma_folder=folder, z_dependent=True)
+    with pytest.raises(OSError):
+        contactTerms.index_based_contact_term(oa, gamma_folder=folder, inMembrane=True)       # *_mem.dat are read then (766-773)
+    np.savetxt(f"{folder}/direct.dat", np.zeros((n - 1, n)))
+    with pytest.raises(ValueError):
+        contactTerms.index_based_contact_term(oa, gamma_folder=folder)
+
+
+def test_index_tables_of_type_gammas_give_the_pinned_contact_term(tmp_path, oracle_api, capsys):
+    oa, traj, golden = golden_system("1ubq")
+    plain = contactTerms.contact_term(oa)
+    indexed = contactTerms.index_based_contact_term(oa, gamma_folder=_index_folder(tmp_path, oa, from_types=plain))
+    a = awsem_oracle.make_context(_system_of(oa, plain), n_replicas=1)
+    b = awsem_oracle.make_context(_system_of(oa, indexed), n_replicas=1)
+    for frame in (0, 9):
+        a.set_positions(traj[frame], replica=0)
+        b.set_positions(traj[frame], replica=0)
+        ea, eb = a.energy_by_group()[0, 22], b.energy_by_group()[0, 22]
+        assert abs(ea) > 1.0 and abs(ea - eb) < 1e-9 * abs(ea)
+        assert np.abs(a.forces()[0] - b.forces()[0]).max() < 1e-8
+
+
+def test_index_based_oracle_forces_match_finite_differences(tmp_path, oracle_api, capsys):
+    oa, traj, _ = golden_system("1ubq")
+    f = contactTerms.index_based_contact_term(oa, gamma_folder=_index_folder(tmp_path, oa))
+    ctx = awsem_oracle.make_context(_system_of(oa, f), n_replicas=1)
+    atoms = np.random.default_rng(5).choice(np.array(f.atom), size=24, replace=False)
+    got, fd = _fd_check(ctx, traj[5], 1 << 22, atoms)
+    assert np.abs(fd).max() > 1.0
+    assert np.abs(got - fd).max() / max(1.0, np.abs(fd).max()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,etol,ftol", [(0, 1e-4, 1e-3), (1, 1e-9, 1e-7)])
+@pytest.mark.parametrize("cell", ["0", "1"])
+def test_index_based_gpu_matches_oracle_and_the_golden_contact_column(tmp_path, precision, etol, ftol, cell, monkeypatch, capsys):
+    monkeypatch.setenv("AWSEM_FORCE_CELL", cell)
+    oa, traj, golden = golden_system("1ubq")
+    random_tables = contactTerms.index_based_contact_term(oa, gamma_folder=_index_folder(tmp_path, oa), forceGroup=5)
+    (tmp_path / "typed").mkdir()
+    typed = contactTerms.index_based_contact_term(oa, gamma_folder=_index_folder(tmp_path / "typed", oa, from_types=contactTerms.contact_term(oa)))
+    frames = (0, 5, 11)
+    for force, g in ((random_tables, 5), (typed, 22)):     # one context each: the cell-list path takes one contact term
+        system = _system_of(oa, force)
+        gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=len(frames), precision=precision)
+        system.upload(gpu)
+        cpu = awsem_oracle.make_context(system, n_replicas=len(frames))
+        for r, k in enumerate(frames):
+            gpu.set_positions(traj[k], replica=r)
+            cpu.set_positions(traj[k], replica=r)
+        eg, ec = gpu.energy_by_group()[:, g], cpu.energy_by_group()[:, g]
+        assert np.abs(ec).min() > 1.0
+        assert (np.abs(eg - ec) <= etol * np.abs(ec) + 2e-7).all()   # 2e-7: Q31.32 sums of terms of both signs
+        if g == 22:   # the reference's golden Contact column, through residue-indexed tables
+            want = np.array([golden["Contact"][k] for k in frames])
+            assert np.abs(eg - want).max() <= max(etol, 2e-5) * np.abs(want).max()
+        fg, fc = gpu.forces(redistribute=False), cpu.forces(redistribute=False)
+        assert np.abs(fg - fc).max() <= ftol * np.abs(fc).max() + (5e-3 if precision == 0 and cell == "0" else 1e-7 if precision else 1e-5)
+        gpu.close()
