@@ -154,8 +154,10 @@ def test_annealing_folds_1r69_towards_its_native_structure():
     assert e.mean() < e0 - 500.0, (e0, e.mean())
 
 
-def test_exploding_forces_are_reported_not_wrapped():
-    """Two bonded atoms placed 40 nm from their rest length: 2e6 kJ/mol/nm, beyond the Q19.12 range of the fp32 accumulators."""
+def test_exploding_forces_are_reported_not_wrapped(monkeypatch):
+    """Two bonded atoms placed 40 nm from their rest length: 2e6 kJ/mol/nm, beyond the Q19.12 range of the fp32 accumulators
+    of the replica-resident path (the cell-list path accumulates in Q31.32 and has no such limit)."""
+    monkeypatch.setenv("AWSEM_FORCE_CELL", "0")
     system = System(np.array([12.0, 12.0]))
     f = HarmonicBondForce(group=20)
     f.addBond(0, 1, 0.38, 50208.0)
