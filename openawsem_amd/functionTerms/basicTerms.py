@@ -48,6 +48,35 @@ def chain_term(oa, k_chain=50208, bond_k=[1, 1, 1], bond_lengths=[0.2459108, 0.2
     return chain
 
 
+def chain_no_cb_constraint_term(oa, k_chain=50208, bond_lengths=[0.2459108, 0.2519591, 0.2466597], forceGroup=20):
+    """chain_term without the springs that hold CB: only N-C of the interior residues (reference basicTerms.py:542-574)."""
+    _no_periodic(oa)
+    k_chain *= oa.k_awsem
+    chain = HarmonicBondForce()
+    for i in range(oa.nres):
+        if i not in oa.chain_starts and i not in oa.chain_ends:
+            chain.addBond(oa.n[i], oa.c[i], bond_lengths[2], k_chain)
+    chain.setForceGroup(forceGroup)
+    return chain
+
+
+def con_no_cb_constraint_term(oa, k_con=50208, bond_lengths=[.3816, .240, .276, .153], forceGroup=20):
+    """con_term with the CA-CB spring kept only at the chain ends, where no N / C site holds CB (reference
+    basicTerms.py:577-615)."""
+    _no_periodic(oa)
+    k_con *= oa.k_awsem
+    con = HarmonicBondForce()
+    for i in range(oa.nres):
+        con.addBond(oa.ca[i], oa.o[i], bond_lengths[1], k_con)
+        if ((i in oa.chain_starts) or (i in oa.chain_ends)) and (not oa.res_type[i] == "IGL"):
+            con.addBond(oa.ca[i], oa.cb[i], bond_lengths[3], k_con)
+        if i not in oa.chain_ends:
+            con.addBond(oa.ca[i], oa.ca[i + 1], bond_lengths[0], k_con)
+            con.addBond(oa.o[i], oa.ca[i + 1], bond_lengths[2], k_con)
+    con.setForceGroup(forceGroup)
+    return con
+
+
 def chi_term(oa, k_chi=251.04, chi0=-0.71, forceGroup=20):
     """Chirality of (CA, C, N, CB): E = k (chi - chi0)^2 (reference basicTerms.py:98-138)."""
     _no_periodic(oa)

@@ -24,3 +24,22 @@ def test_lambda_and_gamma_tables_equal_the_scalar_loops(protein):
     g2 = np.array([[hb.get_pap_gamma_P(i, j, chain[i], chain[j], 0.4, ssweight) for j in range(nres)] for i in range(nres)])
     assert np.array_equal(hb._pap_gamma_table(oa, ssweight, parallel=False, block=41), g1)
     assert np.array_equal(hb._pap_gamma_table(oa, ssweight, parallel=True, block=41), g2)
+
+
+def test_backbone_variants_without_cb_springs():
+    """chain_no_cb_constraint_term / con_no_cb_constraint_term (reference basicTerms.py:542-615) are subsets of the chain /
+    con springs: N-C of interior residues only; CA-CB only at chain ends."""
+    from openawsem_amd.functionTerms import basicTerms
+    from tests.common import golden_system
+    oa, _, _ = golden_system("1brs")          # three chains
+    def bonds(f):
+        return {p: (r0, k) for p, r0, k in zip(f.pairs, f.r0, f.k)}
+    chain, chain_no = bonds(basicTerms.chain_term(oa)), bonds(basicTerms.chain_no_cb_constraint_term(oa))
+    con, con_no = bonds(basicTerms.con_term(oa)), bonds(basicTerms.con_no_cb_constraint_term(oa))
+    interior = [i for i in range(oa.nres) if i not in oa.chain_starts and i not in oa.chain_ends]
+    assert set(chain_no) == {(oa.n[i], oa.c[i]) for i in interior}
+    assert all(chain[b] == chain_no[b] for b in chain_no)
+    ends = [i for i in range(oa.nres) if (i in oa.chain_starts or i in oa.chain_ends) and oa.res_type[i] != "IGL"]
+    cb_bonds = {(oa.ca[i], oa.cb[i]) for i in range(oa.nres) if oa.res_type[i] != "IGL"}
+    assert set(con_no) & cb_bonds == {(oa.ca[i], oa.cb[i]) for i in ends}
+    assert set(con) - cb_bonds == set(con_no) - cb_bonds and all(con[b] == con_no[b] for b in con_no)
