@@ -139,6 +139,13 @@ int awsem_add_fragment_memory(awsem_handle h, int group, int nbonds, const int32
 int awsem_add_membrane(awsem_handle h, int group, int n, const int32_t* atoms, const double* scale, double k,
                        double k_m, double z_m, double center);
 
+/* Other CustomExternalForce terms of the reference, one parameter per particle:
+ *   AWSEM_EXT_LINEAR_X/Y/Z  pulling_term biasTerms.py:574-605:                      E = -k param_i x   (or y, z)
+ *   AWSEM_EXT_ABS_Z         membrane_preassigned_side_term membraneTerms.py:177-215: E = k |z - center - param_i| */
+enum { AWSEM_EXT_LINEAR_X = 1, AWSEM_EXT_LINEAR_Y = 2, AWSEM_EXT_LINEAR_Z = 3, AWSEM_EXT_ABS_Z = 4 };
+int awsem_add_external(awsem_handle h, int group, int kind, int n, const int32_t* atoms, const double* param, double k,
+                       double center);
+
 /* debye_huckel_term debyeHuckelTerms.py:10-76 (CustomBondForce): E = k_dh qq / r exp(-r/screening_length). */
 int awsem_add_debye_huckel(awsem_handle h, int group, int n, const int32_t* pairs, const double* qq,
                            double k_dh, double screening_length);

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "add_helical": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double, C.c_double, C.c_double]),
     "add_fragment_memory": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, C.c_int, c_dbl_p, C.c_double, C.c_double]),
     "add_membrane": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "add_external": (C.c_int, ["H", C.c_int, C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double]),
     "add_debye_huckel": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double]),
     "add_gaussian_bonds": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p]),
     "add_bond_sum": (C.c_int, ["H", C.c_int, C.c_int, C.c_int, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p, C.c_int, C.c_double, C.c_double]),
@@ -218,6 +219,11 @@ class Context:
         nb = len(p) // 2
         t = t.reshape(nb, -1) if nb else t.reshape(0, max(2, t.shape[-1] if t.ndim else 2))
         self._call("add_fragment_memory", group, nb, _ip(p), t.shape[1], _dp(t), float(k_fm), float(dr))
+
+    def add_external(self, group, kind, atoms, param, k, center=0.0):
+        a, s = _i32(atoms), _f64(param)
+        assert len(a) == len(s)
+        self._call("add_external", group, int(kind), len(a), _ip(a), _dp(s), float(k), float(center))
 
     def add_membrane(self, group, atoms, scale, k, k_m, z_m, center):
         a, s = _i32(atoms), _f64(scale)

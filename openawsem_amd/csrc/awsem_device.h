@@ -21,7 +21,7 @@
 #define AWSEM_MAX_PAP 4
 #define AWSEM_MAX_HELICAL 2
 #define AWSEM_MAX_FM 2
-#define AWSEM_MAX_MEMB 2
+#define AWSEM_MAX_MEMB 4
 #define AWSEM_MAX_DH 2
 #define AWSEM_MAX_GAUSS 16
 #define AWSEM_FIXED_SCALE 4294967296.0   // 2^32: forces, energies and densities are accumulated as int64 fixed point
@@ -112,7 +112,7 @@ template <class real> struct FmD {
     int group, n, ntab; const unsigned* pairs; const int* pairs2; const real2_t<real>* table2; real k, dr, inv_dr;
     const FmBundle* bundles; const unsigned* partners; int nbundles, nb_pad;
 };
-template <class real> struct MembD { int group, n; const MembItem<real>* items; real k, k_m2, z_m, center; };
+template <class real> struct MembD { int group, n; const MembItem<real>* items; real k, k_m2, z_m, center; int kind, pad; };   // kind 0: slab; AWSEM_EXT_*: awsem_add_external
 template <class real> struct DhD { int group, n; const DhItem<real>* items; real k, inv_lam; };
 // A sum of bond values S = sum_b g_b(r_b) and an energy E = f(S):
 //   kind 0: g = -c exp(-a (r - r0)^2)   kind 1: g = c r^2

@@ -55,7 +55,7 @@ struct HBeta { int group, two_theta, nres; std::vector<int> acc_atoms, acc_res, 
 struct HPap { int group, nres; std::vector<int> acc_atoms, acc_res, don_atoms, don_res; std::vector<double> gamma; double k, eta, r0, d_i4, cutoff; };
 struct HHelical { int group; std::vector<int> atoms; std::vector<double> coef; double r_ON, s_NO, r_OH, s_HO; };
 struct HFm { int group, ntab; std::vector<int> pairs; std::vector<double> table; double k, dr; };
-struct HMemb { int group; std::vector<int> atoms; std::vector<double> scale; double k, k_m, z_m, center; };
+struct HMemb { int group; std::vector<int> atoms; std::vector<double> scale; double k, k_m, z_m, center; int kind = 0; };
 struct HDh { int group; std::vector<int> pairs; std::vector<double> qq; double k, lam; };
 struct HGauss { int group; std::vector<int> pairs; std::vector<double> r0, sigma, kg; int kind = 0, cv = 0; double cv_k = 0, cv_x0 = 0; };
 
@@ -862,7 +862,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
             for (size_t b = 0; b < it.size(); b++) perm[b] = (int)b;
             if (cell_mode_) perm = item_order((int)it.size(), 1, h.atoms.data());
             for (size_t b = 0; b < it.size(); b++) it[b] = MembItem<real>{h.atoms[perm[b]], (real)h.scale[perm[b]]};
-            D.push_back(MembD<real>{h.group, (int)it.size(), upload(it), (real)h.k, (real)(2 * h.k_m), (real)h.z_m, (real)h.center});
+            D.push_back(MembD<real>{h.group, (int)it.size(), upload(it), (real)h.k, (real)(2 * h.k_m), (real)h.z_m, (real)h.center, h.kind, 0});
         }
         if (D.size() > AWSEM_MAX_MEMB) throw std::string("too many memb terms: at most " + std::to_string(AWSEM_MAX_MEMB) + " per system");
         S.n_memb = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.memb[t] = D[t];
@@ -1662,6 +1662,15 @@ int awsem_add_fragment_memory(awsem_handle h, int group, int nb, const int32_t* 
     if (nb < 0 || ntab < 2 || !(dr > 0) || (nb && (!pairs || !table)) || !atoms_ok(h, pairs, 2 * (size_t)nb))
         return fail(AWSEM_EINVAL, "add_fragment_memory: bad arguments");
     h->H.fm.push_back(HFm{group, ntab, vec(pairs, 2 * (size_t)nb), vec(table, (size_t)nb * ntab), k, dr});
+    return AWSEM_OK;
+}
+int awsem_add_external(awsem_handle h, int group, int kind, int n, const int32_t* atoms, const double* param, double k, double center) {
+    NEED_BUILD(h, group);
+    if (kind < AWSEM_EXT_LINEAR_X || kind > AWSEM_EXT_ABS_Z) return fail(AWSEM_EINVAL, "add_external: unknown kind %d", kind);
+    if (n < 0 || (n && (!atoms || !param)) || !atoms_ok(h, atoms, n)) return fail(AWSEM_EINVAL, "add_external: bad arguments");
+    HMemb m{group, vec(atoms, n), vec(param, n), k, 0.0, 0.0, center};
+    m.kind = kind;
+    h->H.memb.push_back(std::move(m));
     return AWSEM_OK;
 }
 int awsem_add_membrane(awsem_handle h, int group, int n, const int32_t* atoms, const double* scale, double k, double k_m, double z_m, double center) {

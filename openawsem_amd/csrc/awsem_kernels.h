@@ -458,6 +458,19 @@ template <bool ENERGY, class V> __device__ __forceinline__ void term_memb(const 
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
         const MembItem<real> it = d.items[b];
+        if (d.kind != 0) {   // uniform: the other external-field terms (awsem_add_external)
+            const R3<real> x = L.pos(it.atom);
+            if (d.kind == 4) {   // k |z - center - z_i|
+                const real u = x.z - d.center - it.scale;
+                if (ENERGY) e += (double)(d.k * (u < 0 ? -u : u));
+                L.add_fz(it.atom, u > 0 ? -d.k : (u < 0 ? d.k : (real)0));
+            } else {             // -k s_i x (or y, z): a constant force k s_i along the axis
+                const real c = d.kind == 1 ? x.x : (d.kind == 2 ? x.y : x.z), fc = d.k * it.scale;
+                if (ENERGY) e += (double)(-fc * c);
+                L.add_force(it.atom, d.kind == 1 ? fc : (real)0, d.kind == 2 ? fc : (real)0, d.kind == 3 ? fc : (real)0);
+            }
+            continue;
+        }
         real z = L.pos(it.atom).z - d.center;
         // 1/2 tanh(u) + 1/2 tanh(v) = sig(2u) + sig(2v) - 1
         real su = sigmoid(d.k_m2 * (z + d.z_m)), sv = sigmoid(d.k_m2 * (d.z_m - z));

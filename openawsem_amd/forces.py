@@ -255,6 +255,30 @@ class MembraneForce(Force):
         ctx.add_membrane(self._group, self.atoms, self.scale, self.k, self.k_m, self.z_m, self.center)
 
 
+EXT_LINEAR_X, EXT_LINEAR_Y, EXT_LINEAR_Z, EXT_ABS_Z = 1, 2, 3, 4
+
+
+class ExternalForce(Force):
+    """One-parameter CustomExternalForce shapes (awsem_add_external): E = -k p_i x|y|z, or k |z - center - p_i|."""
+    kind = "external"
+
+    def __init__(self, shape, k, center=0.0, group=0):
+        super().__init__(group)
+        self.shape, self.k, self.center = int(shape), float(k), float(center)
+        self.atoms, self.param = [], []
+
+    def addParticle(self, atom, params=(1.0,)):
+        self.atoms.append(int(atom))
+        self.param.append(float(params[0]))
+        return len(self.atoms) - 1
+
+    def getNumParticles(self):
+        return len(self.atoms)
+
+    def _upload(self, ctx):
+        ctx.add_external(self._group, self.shape, self.atoms, self.param, self.k, self.center)
+
+
 class DebyeHuckelForce(Force):
     kind = "debye_huckel"
 

@@ -141,3 +141,23 @@ def rg_bias_term(oa, k=1 * _u.kilocalorie_per_mole, rg0=0.0, atomGroup=-1, force
     """k_rg (Rg - rg0)^2 over the CA atoms of the residues in atomGroup (all by default); Rg in nm."""
     group = list(range(oa.nres)) if (isinstance(atomGroup, int) and atomGroup == -1) else list(atomGroup)
     return _rg_square([oa.ca[i] for i in group], "sqrt_square", oa.k_awsem * _kj(k), float(rg0), forceGroup)
+
+
+def pulling_term(oa, k_pulling=4.184, forceDirect="x", appliedToResidue=1, forceGroup=19):
+    """Constant force k_pulling (kJ/mol/nm) along +x, +y or +z on every atom of one residue: E = -k x (reference
+    biasTerms.py:574-605).  `appliedToResidue` is 1-based, or "FIRST" / "LAST"."""
+    from ..forces import EXT_LINEAR_X, ExternalForce
+    axis = {"x": 0, "y": 1, "z": 2}.get(str(forceDirect).strip().lower())
+    if axis is None:
+        raise ValueError(f"forceDirect must be x, y or z, not {forceDirect!r}")
+    k_pulling *= oa.k_awsem
+    if appliedToResidue == "LAST":
+        appliedToResidue = oa.nres
+    if appliedToResidue == "FIRST":
+        appliedToResidue = 1
+    pulling = ExternalForce(EXT_LINEAR_X + axis, k_pulling)
+    for i in range(oa.natoms):
+        if oa.resi[i] == (appliedToResidue - 1):
+            pulling.addParticle(i)
+    pulling.setForceGroup(forceGroup)
+    return pulling

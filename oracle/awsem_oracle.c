@@ -51,7 +51,7 @@ typedef struct {
 } pap_t;
 typedef struct { int group, n; int *atoms; double *coef; double r_ON, s_NO, r_OH, s_HO; } helical_t;
 typedef struct { int group, n, ntab; int *pairs; double *table; double k, dr; } fm_t;
-typedef struct { int group, n; int *atoms; double *scale; double k, k_m, z_m, center; } memb_t;
+typedef struct { int group, n; int *atoms; double *scale; double k, k_m, z_m, center; int kind; } memb_t;   /* kind 0: slab; 1-3: -k s x|y|z; 4: k|z-c-s| */
 typedef struct { int group, n; int *pairs; double *qq; double k, lam; } dh_t;
 typedef struct { int group, n; int *pairs; double *r0, *sigma, *kg; int kind, cv; double cv_k, cv_x0; } gauss_t;
 
@@ -256,6 +256,14 @@ int awsem_oracle_add_fragment_memory(ctx_t* c, int group, int nb, const int* pai
     fm_t* t = calloc(1, sizeof *t); t->group = group; t->n = nb; t->ntab = ntab; t->k = k; t->dr = dr;
     t->pairs = dup_mem(pairs, 2 * nb * sizeof(int)); t->table = dup_mem(table, (size_t)nb * ntab * sizeof(double));
     return add_term(c, T_FM, t);
+}
+int awsem_oracle_add_external(ctx_t* c, int group, int kind, int n, const int* atoms, const double* param, double k, double center) {
+    CHECK_BUILD(c, group);
+    if (kind < 1 || kind > 4) return fail(-1, "add_external: unknown kind");
+    if (n < 0 || (n && (!atoms || !param)) || !check_atoms(c, atoms, n, 0)) return fail(-1, "add_external: bad arguments");
+    memb_t* t = calloc(1, sizeof *t); t->group = group; t->n = n; t->atoms = dup_mem(atoms, n * sizeof(int)); t->scale = dup_mem(param, n * sizeof(double));
+    t->k = k; t->center = center; t->kind = kind;
+    return add_term(c, T_MEMB, t);
 }
 int awsem_oracle_add_membrane(ctx_t* c, int group, int n, const int* atoms, const double* scale, double k, double k_m, double z_m, double center) {
     CHECK_BUILD(c, group);
@@ -661,6 +669,18 @@ static double eval_memb(const memb_t* t, const double* x, double* f) {
     double e = 0;
     for (int b = 0; b < t->n; b++) {
         int a = t->atoms[b];
+        if (t->kind == 4) {            /* membraneTerms.py:202: k |z - center - z_m,i| */
+            double u = x[3 * a + 2] - t->center - t->scale[b];
+            e += t->k * fabs(u);
+            if (f) f[3 * a + 2] -= t->k * (u > 0 ? 1.0 : (u < 0 ? -1.0 : 0.0));
+            continue;
+        }
+        if (t->kind != 0) {            /* biasTerms.py:595: (-k) * x */
+            int ax = t->kind - 1;
+            e += -t->k * t->scale[b] * x[3 * a + ax];
+            if (f) f[3 * a + ax] += t->k * t->scale[b];
+            continue;
+        }
         double z = x[3 * a + 2] - t->center;
         double u = t->k_m * (z + t->z_m), v = t->k_m * (t->z_m - z);
         e += t->k * t->scale[b] * (0.5 * tanh(u) + 0.5 * tanh(v));
