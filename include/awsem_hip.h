@@ -165,6 +165,7 @@ int awsem_add_gaussian_bonds(awsem_handle h, int group, int n, const int32_t* pa
  * Available on both paths. */
 #define AWSEM_BOND_GAUSS 0
 #define AWSEM_BOND_R2 1
+#define AWSEM_BOND_R2_XY 2   /* g = coef ((x1-x2)^2 + (y1-y2)^2): cylindrical_rg_bias_term biasTerms.py:531-571 */
 #define AWSEM_CV_SUM 0
 #define AWSEM_CV_HARMONIC 1
 #define AWSEM_CV_SQRT 2

@@ -1696,7 +1696,7 @@ int awsem_add_gaussian_bonds(awsem_handle h, int group, int n, const int32_t* pa
 int awsem_add_bond_sum(awsem_handle h, int group, int bond_kind, int n, const int32_t* pairs, const double* r0, const double* sigma,
                        const double* coef, int cv_kind, double cv_k, double cv_x0) {
     NEED_BUILD(h, group);
-    if (bond_kind < 0 || bond_kind > 1 || cv_kind < 0 || cv_kind > 3) return fail(AWSEM_EINVAL, "add_bond_sum: unknown bond or collective-variable kind");
+    if (bond_kind < 0 || bond_kind > AWSEM_BOND_R2_XY || cv_kind < 0 || cv_kind > 3) return fail(AWSEM_EINVAL, "add_bond_sum: unknown bond or collective-variable kind");
     if (n < 0 || (n && (!pairs || !coef || (bond_kind == 0 && (!r0 || !sigma)))) || !atoms_ok(h, pairs, 2 * (size_t)n)) return fail(AWSEM_EINVAL, "add_bond_sum: bad arguments");
     for (int b = 0; b < n && bond_kind == 0; b++) if (!(sigma[b] > 0)) return fail(AWSEM_EINVAL, "add_bond_sum: sigma must be positive");
     HGauss g{group, vec(pairs, 2 * (size_t)n), bond_kind == 0 ? vec(r0, n) : std::vector<double>(), bond_kind == 0 ? vec(sigma, n) : std::vector<double>(), vec(coef, n)};

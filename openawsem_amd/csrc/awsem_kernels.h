@@ -500,7 +500,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void term_dh(const Dh
 // bond_value: g and s = -(dg/dr)/r of one bond.
 template <class real> __device__ __forceinline__ void bond_value(const GaussD<real>& d, const GaussItem<real>& it, const R3<real>& dd, real& g, real& s) {
     const real r2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z;
-    if (d.kind == 1) { g = it.c * r2; s = (real)-2 * it.c; return; }
+    if (d.kind != 0) { g = it.c * r2; s = (real)-2 * it.c; return; }   // r^2 kinds (kind 2: the callers have projected dd on the xy plane)
     const real ir = M<real>::rsqrt(r2), dr = r2 * ir - it.r0;
     g = -it.c * M<real>::exp(-it.a * dr * dr);
     s = (real)2 * it.a * dr * g * ir;   // dg/dr = -2 a dr g
@@ -510,7 +510,8 @@ template <bool ENERGY, class V> __device__ __forceinline__ void term_gauss(const
     Energy e;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
         const GaussItem<real> it = d.items[b];
-        const R3<real> dd = L.pos(it.i) - L.pos(it.j);
+        R3<real> dd = L.pos(it.i) - L.pos(it.j);
+        if (d.kind == 2) dd.z = 0;
         real g, s;
         bond_value(d, it, dd, g, s);
         if (ENERGY) e += (double)g;
@@ -528,7 +529,9 @@ template <class V> __device__ __forceinline__ void cv_sum(const GaussD<typename 
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
         const GaussItem<real> it = d.items[b];
         real g, s;
-        bond_value(d, it, L.pos(it.i) - L.pos(it.j), g, s);
+        R3<real> dd = L.pos(it.i) - L.pos(it.j);
+        if (d.kind == 2) dd.z = 0;
+        bond_value(d, it, dd, g, s);
         t += (u64)__double2ll_rn((double)g * AWSEM_CV_SCALE);
     }
     for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
@@ -549,7 +552,8 @@ template <bool ENERGY, class V> __device__ __forceinline__ void cv_apply(const G
     const real fpr = (real)fp;
     for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
         const GaussItem<real> it = d.items[b];
-        const R3<real> dd = L.pos(it.i) - L.pos(it.j);
+        R3<real> dd = L.pos(it.i) - L.pos(it.j);
+        if (d.kind == 2) dd.z = 0;
         real g, s;
         bond_value(d, it, dd, g, s);
         L.pair_force(it.i, it.j, dd.x, dd.y, dd.z, fpr * s);

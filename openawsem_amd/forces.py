@@ -333,7 +333,7 @@ class BondSumForce(Force):
     rg_bias_term 489-528).  bond_kind "gauss": g = coef exp(-(r-r0)^2/(2 sigma^2)); "r2": g = coef r^2.
     cv: "sum" E = S; "harmonic" E = k/2 (S-x0)^2; "sqrt" E = k sqrt(S); "sqrt_square" E = k (sqrt(S)-x0)^2."""
     kind = "bond_sum"
-    BOND = {"gauss": 0, "r2": 1}
+    BOND = {"gauss": 0, "r2": 1, "r2_xy": 2}
     CV = {"sum": 0, "harmonic": 1, "sqrt": 2, "sqrt_square": 3}
 
     def __init__(self, bond_kind="gauss", cv="sum", k=0.0, x0=0.0, group=0):

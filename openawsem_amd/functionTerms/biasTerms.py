@@ -123,8 +123,8 @@ def qbias_term(oa, q0, reference_pdb_file, reference_chain_name, k_qbias=100 * _
     return _q_force(inter, forceGroup, cv="harmonic", k=_kj(k_qbias), x0=float(q0))
 
 
-def _rg_square(ca_atoms, cv, k, x0, group):
-    f = BondSumForce("r2", cv, k, x0, group=group)
+def _rg_square(ca_atoms, cv, k, x0, group, bond="r2"):
+    f = BondSumForce(bond, cv, k, x0, group=group)
     n = len(ca_atoms)
     for a in range(n):
         for b in range(a + 1, n):
@@ -141,6 +141,13 @@ def rg_bias_term(oa, k=1 * _u.kilocalorie_per_mole, rg0=0.0, atomGroup=-1, force
     """k_rg (Rg - rg0)^2 over the CA atoms of the residues in atomGroup (all by default); Rg in nm."""
     group = list(range(oa.nres)) if (isinstance(atomGroup, int) and atomGroup == -1) else list(atomGroup)
     return _rg_square([oa.ca[i] for i in group], "sqrt_square", oa.k_awsem * _kj(k), float(rg0), forceGroup)
+
+
+def cylindrical_rg_bias_term(oa, k=1 * _u.kilocalorie_per_mole, rg0=0.0, atomGroup=-1, forceGroup=27):
+    """rg_bias_term on the xy projection: k_rg (sqrt(sum_{i<j} ((x_i-x_j)^2 + (y_i-y_j)^2) / n^2) - rg0)^2 (reference
+    biasTerms.py:531-571)."""
+    group = list(range(oa.nres)) if (isinstance(atomGroup, int) and atomGroup == -1) else list(atomGroup)
+    return _rg_square([oa.ca[i] for i in group], "sqrt_square", oa.k_awsem * _kj(k), float(rg0), forceGroup, bond="r2_xy")
 
 
 def pulling_term(oa, k_pulling=4.184, forceDirect="x", appliedToResidue=1, forceGroup=19):

@@ -292,7 +292,7 @@ int awsem_oracle_add_gaussian_bonds(ctx_t* c, int group, int n, const int* pairs
 int awsem_oracle_add_bond_sum(ctx_t* c, int group, int bond_kind, int n, const int* pairs, const double* r0, const double* sigma,
                               const double* coef, int cv_kind, double cv_k, double cv_x0) {
     CHECK_BUILD(c, group);
-    if (bond_kind < 0 || bond_kind > 1 || cv_kind < 0 || cv_kind > 3) return fail(-1, "add_bond_sum: unknown bond or collective-variable kind");
+    if (bond_kind < 0 || bond_kind > 2 || cv_kind < 0 || cv_kind > 3) return fail(-1, "add_bond_sum: unknown bond or collective-variable kind");
     if (n < 0 || (n && (!pairs || !coef || (bond_kind == 0 && (!r0 || !sigma)))) || !check_atoms(c, pairs, 2 * n, 0)) return fail(-1, "add_bond_sum: bad arguments");
     for (int b = 0; b < n && bond_kind == 0; b++) if (!(sigma[b] > 0)) return fail(-1, "add_bond_sum: sigma must be positive");
     gauss_t* t = calloc(1, sizeof *t); t->group = group; t->n = n; t->pairs = dup_mem(pairs, 2 * n * sizeof(int));
@@ -704,15 +704,21 @@ static double eval_dh(const dh_t* t, const double* x, double* f) {
 /* er_term templateTerms.py:643-693 and additive_amhgo_term templateTerms.py:600-640 (CustomBondForce):
  * E = -k gamma_ij exp(-(r - r_ijN)^2 / (2 sigma_ij^2)) */
 static double bond_value(const gauss_t* t, int b, double r, double* dgdr) {
-    if (t->kind == 1) { *dgdr = 2 * t->kg[b] * r; return t->kg[b] * r * r; }
+    if (t->kind != 0) { *dgdr = 2 * t->kg[b] * r; return t->kg[b] * r * r; }   /* kind 2: r is the length of the xy projection */
     double dr = r - t->r0[b], s2 = t->sigma[b] * t->sigma[b];
     double g = -t->kg[b] * exp(-dr * dr / (2 * s2));
     *dgdr = -g * dr / s2;
     return g;
 }
+/* separation of a bond; for the cylindrical kind (biasTerms.py:560) its projection on the xy plane */
+static double bond_dist(const gauss_t* t, const double* x, int i, int j, double* d) {
+    double r = dist(x, i, j, d);
+    if (t->kind == 2) { d[2] = 0; r = sqrt(d[0] * d[0] + d[1] * d[1]); }
+    return r;
+}
 static double eval_gauss(const gauss_t* t, const double* x, double* f) {
     double S = 0, d[3], dg;
-    for (int b = 0; b < t->n; b++) S += bond_value(t, b, dist(x, t->pairs[2 * b], t->pairs[2 * b + 1], d), &dg);
+    for (int b = 0; b < t->n; b++) S += bond_value(t, b, bond_dist(t, x, t->pairs[2 * b], t->pairs[2 * b + 1], d), &dg);
     double E = S, fp = 1;   /* E = f(S), fp = f'(S) */
     if (t->cv == 1) { E = 0.5 * t->cv_k * (S - t->cv_x0) * (S - t->cv_x0); fp = t->cv_k * (S - t->cv_x0); }
     else if (t->cv == 2 || t->cv == 3) {
@@ -722,9 +728,9 @@ static double eval_gauss(const gauss_t* t, const double* x, double* f) {
     }
     for (int b = 0; b < t->n; b++) {
         int i = t->pairs[2 * b], j = t->pairs[2 * b + 1];
-        double r = dist(x, i, j, d);
+        double r = bond_dist(t, x, i, j, d);
         bond_value(t, b, r, &dg);
-        pair_force(f, i, j, d, r, fp * dg);
+        if (r > 0) pair_force(f, i, j, d, r, fp * dg);
     }
     return E;
 }

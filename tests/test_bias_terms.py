@@ -1,5 +1,5 @@
 """Order parameters and biases (reference biasTerms.py): q_value 146-188, qc_value 191-223, partial_q_value 226-267,
-qbias_term 270-302, rg_term 461-486, rg_bias_term 489-528.
+qbias_term 270-302, rg_term 461-486, rg_bias_term 489-528, cylindrical_rg_bias_term 531-571.
 
 Parity unpinned by any reference fixture (the golden CSVs carry no Q / Rg column), so: the factories are checked against
 a direct numpy evaluation of the reference's formulas, the oracle's forces against finite differences, and the HIP path
@@ -52,7 +52,8 @@ def _bias_system(oa, backbone=False):
               biasTerms.rg_term(oa),                                                          # group 2
               biasTerms.qc_value(oa, NATIVE),                                                 # group 3
               biasTerms.qbias_term(oa, 0.7, NATIVE, "ALL", forceGroup=4),                     # group 4
-              biasTerms.rg_bias_term(oa, k=5 * u.kilocalorie_per_mole, rg0=0.9, forceGroup=27)]
+              biasTerms.rg_bias_term(oa, k=5 * u.kilocalorie_per_mole, rg0=0.9, forceGroup=27),
+              biasTerms.cylindrical_rg_bias_term(oa, k=3 * u.kilocalorie_per_mole, rg0=0.5, atomGroup=list(range(5, 60)), forceGroup=28)]
     if backbone:
         forces += [basicTerms.con_term(oa), basicTerms.chain_term(oa), basicTerms.chi_term(oa), basicTerms.excl_term(oa),
                    basicTerms.rama_term(oa)]
@@ -81,6 +82,9 @@ def test_factories_and_oracle_match_the_reference_formulas():
         assert abs(e[r, 2] - 10 * Rg) < 1e-10
         assert abs(e[r, 4] - 0.5 * 418.4 * (Q - 0.7) ** 2) < 1e-9
         assert abs(e[r, 27] - 5 * 4.184 * (Rg - 0.9) ** 2) < 1e-9
+        ca = traj[f][oa.ca][5:60]
+        d2 = ((ca[:, None, :2] - ca[None, :, :2]) ** 2).sum(-1)
+        assert abs(e[r, 28] - 3 * 4.184 * (np.sqrt(np.triu(d2, 1).sum() / len(ca) ** 2) - 0.5) ** 2) < 1e-9      # cylindrical: xy only
     # Q of the native CA trace itself is 1: put every CA on its crystal position
     x = traj[0].copy()
     x[oa.ca] = _native_ca()
@@ -121,7 +125,7 @@ def test_oracle_forces_are_the_gradient_of_the_collective_variable_energies():
     cpu.set_positions(x, replica=0)
     rng = np.random.default_rng(5)
     h = 1e-6
-    for group in (1, 2, 3, 4, 27):
+    for group in (1, 2, 3, 4, 27, 28):
         f = cpu.forces(1 << group, redistribute=False)[0]
         assert np.abs(f).max() > 0
         for a in rng.choice(oa.ca, 6, replace=False):
@@ -152,7 +156,7 @@ def test_gpu_matches_oracle(precision, etol, ftol, cell, monkeypatch):
         gpu.set_positions(traj[f], replica=r)
         cpu.set_positions(traj[f], replica=r)
     eg, ec = gpu.energy_by_group(), cpu.energy_by_group()
-    for group in (1, 2, 3, 4, 27):
+    for group in (1, 2, 3, 4, 27, 28):
         # plain sums go through the 2^-32 energy accumulators: ~10^4 nearly equal bonds round coherently (2e-7 on Q = 1)
         tol = max(etol, 5e-7) if group in (1, 3) else etol
         assert np.abs(eg[:, group] - ec[:, group]).max() <= tol * max(1.0, np.abs(ec[:, group]).max()), group
