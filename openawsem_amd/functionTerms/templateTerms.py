@@ -133,8 +133,9 @@ def _nm(x):
     return float(x.value_in_unit(u.nanometer)) if hasattr(x, "value_in_unit") else float(x)
 
 
-def _pdb_ca_cb(pdb_file, chain_name):
-    """Per residue of `chain_name` (first model): (residue name, CA xyz, CB xyz or None), coordinates in Angstrom."""
+def _pdb_ca_cb(pdb_file, chain_name, with_resseq=False):
+    """Per residue of `chain_name` (first model): (residue name, CA xyz, CB xyz or None), coordinates in Angstrom; with
+    `with_resseq` a fourth entry, the residue number of the PDB file."""
     residues, index = [], {}
     with open(pdb_file) as fh:
         for line in fh:
@@ -148,7 +149,7 @@ def _pdb_ca_cb(pdb_file, chain_name):
             key = line[22:27]
             if key not in index:
                 index[key] = len(residues)
-                residues.append([line[17:20].strip(), None, None])
+                residues.append([line[17:20].strip(), None, None] + ([int(line[22:26])] if with_resseq else []))
             xyz = np.array([float(line[30:38]), float(line[38:46]), float(line[46:54])])
             residues[index[key]][1 if name == "CA" else 2] = xyz
     return residues
@@ -182,6 +183,42 @@ def additive_amhgo_term(oa, pdb_file, chain_name, k_amhgo=4.184, amhgo_min_seq_s
     for a, b, params in read_amhgo_structure(oa, pdb_file, chain_name, amhgo_min_seq_sep, amhgo_contact_threshold, amhgo_well_width):
         force.addBond(a, b, params)
     force.setForceGroup(forceGroup)
+    return force
+
+
+def read_memory(oa, pdb_file, chain_name, target_start, fragment_start, length, weight, min_seq_sep, max_seq_sep, am_well_width=0.1):
+    """Bonds of one associative memory (reference templateTerms.py:297-370): the residues of `chain_name` numbered
+    fragment_start .. fragment_start + length - 2 (the reference's `range(fragment_start, fragment_start+length-1)`) are
+    laid on the target residues from `target_start` (1-based); every CA/CB x CA/CB pair of residues with
+    min_seq_sep <= i - j <= max_seq_sep gives [atom_i, atom_j, [weight, gamma = 1, r_memory (nm), well_width |i-j|^0.15]]."""
+    residues = [r for r in _pdb_ca_cb(pdb_file, chain_name, with_resseq=True) if fragment_start <= r[3] < fragment_start + length - 1]
+    out = []
+    for i, (name_i, ca_i, cb_i, _) in enumerate(residues):
+        for j, (name_j, ca_j, cb_j, _) in enumerate(residues):
+            if abs(i - j) > max_seq_sep or i - j < min_seq_sep:
+                continue
+            ti, tj = target_start + i - 1, target_start + j - 1
+            atoms_i, atoms_j = [(ca_i, oa.ca[ti])], [(ca_j, oa.ca[tj])]
+            if name_i != "GLY" and oa.cb[ti] >= 0:
+                atoms_i.append((cb_i, oa.cb[ti]))
+            if name_j != "GLY" and oa.cb[tj] >= 0:
+                atoms_j.append((cb_j, oa.cb[tj]))
+            for xi, ai in atoms_i:
+                for xj, aj in atoms_j:
+                    if xi is None or xj is None:
+                        raise ValueError(f"{pdb_file}: a residue of chain {chain_name} lacks the CA or CB atom the memory needs")
+                    out.append([ai, aj, [weight, 1.0, float(np.linalg.norm(xi - xj)) / 10.0, am_well_width * abs(i - j) ** 0.15]])
+    return out
+
+
+def associative_memory_term(oa, memories, k_am=0.8368, min_seq_sep=3, max_seq_sep=9, am_well_width=0.1):
+    """Associative-memory term over whole structures (reference templateTerms.py:373-411):
+    E = -k_am sum w_m gamma_ij exp(-(r - r_ijm)^2 / (2 sigma_ij^2)); `memories` holds tuples
+    (pdb_file, chain, target_start, fragment_start, length, weight).  Force group 0, as the reference leaves it."""
+    force = GaussianBondForce(k_am * oa.k_awsem)
+    for memory in memories:
+        for a, b, (w_m, gamma_ij, r_ijm, sigma_ij) in read_memory(oa, *memory, min_seq_sep, max_seq_sep, am_well_width=am_well_width):
+            force.addBond(a, b, [w_m * gamma_ij, r_ijm, sigma_ij])
     return force
 
 

@@ -135,3 +135,41 @@ def test_constraint_by_distance_is_a_harmonic_bond():
     assert abs(cpu.energy_by_group()[0, 3] - 0.5 * 2 * 4.184 * (r - 1.2) ** 2) < 1e-10
     with pytest.raises(NotImplementedError):
         constraints.group_constraint_by_position(oa)
+
+
+def test_associative_memory_term_matches_a_direct_evaluation(oracle_api, capsys):
+    """associative_memory_term / read_memory (reference templateTerms.py:297-411): whole-structure memories as Gaussian
+    bonds.  Two overlapping memories cut from the 1ubq crystal structure; the energy is recomputed here from the PDB
+    coordinates with the reference's index conventions (1-based target_start, fragment range short by one residue)."""
+    oa, traj, _ = golden_system("1ubq")
+    pdb = os.path.join(GOLDEN, "1ubq-crystal_structure.pdb")
+    memories = [(pdb, "A", 1, 1, 40, 1.0), (pdb, "A", 21, 21, 30, 0.5)]
+    am = templateTerms.associative_memory_term(oa, memories, k_am=0.8368, min_seq_sep=3, max_seq_sep=9)
+    assert am.getForceGroup() == 0
+    native = {}
+    with open(pdb) as fh:
+        for line in fh:
+            if line.startswith("ATOM") and line[12:16].strip() in ("CA", "CB"):
+                native[(int(line[22:26]), line[12:16].strip())] = np.array([float(line[30:38]), float(line[38:46]), float(line[46:54])]) / 10
+    x = traj[8]
+    want, nbonds = 0.0, 0
+    for _, _, target, start, length, w in memories:
+        resseq = list(range(start, start + length - 1))
+        for i, ri in enumerate(resseq):
+            for j, rj in enumerate(resseq):
+                if not 3 <= i - j <= 9:
+                    continue
+                ti, tj = target + i - 1, target + j - 1
+                for ni, ai in (("CA", oa.ca[ti]), ("CB", oa.cb[ti])):
+                    for nj, aj in (("CA", oa.ca[tj]), ("CB", oa.cb[tj])):
+                        if ai < 0 or aj < 0:
+                            continue
+                        r0, sigma = np.linalg.norm(native[(ri, ni)] - native[(rj, nj)]), 0.1 * (i - j) ** 0.15
+                        want += -0.8368 * w * np.exp(-(np.linalg.norm(x[ai] - x[aj]) - r0) ** 2 / (2 * sigma ** 2))
+                        nbonds += 1
+    assert am.getNumBonds() == nbonds > 1000
+    system = System(oa.system.masses.copy())
+    system.addForce(am)
+    cpu = awsem_oracle.make_context(system, n_replicas=1)
+    cpu.set_positions(x, replica=0)
+    assert abs(cpu.energy_by_group()[0, 0] - want) < 1e-9 and want < -1.0
