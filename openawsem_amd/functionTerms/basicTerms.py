@@ -120,6 +120,41 @@ def excl_term(oa, k_excl=8368, r_excl=0.35, periodic=False, excludeCB=False, for
     return excl
 
 
+def excl_term_v2(oa, k_excl=8368, r_excl=0.35, periodic=False, excludeCB=False, forceGroup=20):
+    """excl_term without createExclusionsFromBonds (reference basicTerms.py:194-263): a pair of the same interaction groups
+    counts iff step(|res1-res2| - 2 + isChainEdge1*isChainEdge2 + isnot_Ca1 + isnot_Ca2) = 1, i.e. CA-CA pairs of
+    neighbouring residue indices and the CA-CB pair of one residue are left out.  isChainEdge is computed as the reference
+    does (the ATOM index is looked up in the lists of chain-end RESIDUE indices, basicTerms.py:237)."""
+    _no_periodic(oa)
+    if excludeCB:
+        raise NotImplementedError("excl_term_v2(excludeCB=True) is not supported by the MI355X AWSEM engine")
+    k_excl *= oa.k_awsem
+    excl = ExclForce(k_excl, r_excl)
+    ca, cb, o = list(oa.ca), [x for x in oa.cb if x > 0], list(oa.o)
+    cls = {a: 0 for a in ca + cb}
+    cls.update({a: 1 for a in o})
+    excl.atom = sorted(cls)
+    excl.cls = [cls[a] for a in excl.atom]
+    edge = set(oa.chain_ends) | set(oa.chain_starts)
+    ca_set = set(ca)
+
+    def counted(a, b):
+        return abs(oa.resi[a] - oa.resi[b]) - 2 + int(a in edge) * int(b in edge) + int(a not in ca_set) + int(b not in ca_set) >= 0
+
+    pairs = set()
+    by_res = {}
+    for a in ca + cb:
+        by_res.setdefault(int(oa.resi[a]), []).append(a)
+    for r, atoms in by_res.items():                       # only |res1 - res2| <= 1 can fail the test
+        for a in atoms:
+            for b in atoms + by_res.get(r + 1, []):
+                if a != b and not counted(a, b):
+                    pairs.add((min(a, b), max(a, b)))
+    excl.excl_pairs = sorted(pairs)
+    excl.setForceGroup(forceGroup)
+    return excl
+
+
 def _rama_bonds(oa, i):
     return [oa.c[i - 1], oa.n[i], oa.ca[i], oa.c[i], oa.n[i + 1]]
 
