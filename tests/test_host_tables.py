@@ -79,3 +79,28 @@ def test_excl_term_v2_pair_rule(oracle_api):
     cpu = awsem_oracle.make_context(system, n_replicas=1)
     cpu.set_positions(x, replica=0)
     assert abs(cpu.energy_by_group()[0, 20] - want) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cell", ["0", "1"])
+def test_excl_term_v2_on_the_gpu(cell, monkeypatch):
+    from openawsem_amd import _capi
+    from openawsem_amd.forces import System
+    from openawsem_amd.functionTerms import basicTerms
+    from oracle import awsem_oracle
+    from tests.common import golden_system
+    monkeypatch.setenv("AWSEM_FORCE_CELL", cell)
+    oa, traj, _ = golden_system("1brs")
+    system = System(oa.system.masses.copy())
+    system.virtual_sites = dict(oa.system.virtual_sites)
+    system.addForce(basicTerms.excl_term_v2(oa))
+    gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=2, precision=1)
+    system.upload(gpu)
+    cpu = awsem_oracle.make_context(system, n_replicas=2)
+    for r, k in enumerate((2, 9)):
+        gpu.set_positions(traj[k], replica=r)
+        cpu.set_positions(traj[k], replica=r)
+    eg, ec = gpu.energy_by_group()[:, 20], cpu.energy_by_group()[:, 20]
+    assert np.abs(ec).min() > 0.01 and np.abs(eg - ec).max() <= 1e-9 * np.abs(ec).max() + 1e-8
+    assert np.abs(gpu.forces(redistribute=False) - cpu.forces(redistribute=False)).max() <= 1e-6
+    gpu.close()
