@@ -1411,6 +1411,17 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
             if (threadIdx.x == 0) atomicAdd((unsigned long long*)&S.prof[10], 1ull);   // number of list rebuilds
 #endif
         }
+        // the step's random numbers depend on nothing but the counter: generated here, ahead of the force phases
+        // (for up to two particles per lane; larger systems draw them in the integrator as before)
+        real g_pre[2][3] = {{0, 0, 0}, {0, 0, 0}};
+        const bool pre = S.nmassive <= 2 * (int)blockDim.x;
+        if (pre) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int k = (int)threadIdx.x + q * (int)blockDim.x;
+                if (k < S.nmassive) gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, S.massive[k].id, g_pre[q]);
+            }
+        }
         evaluate_terms<false, true>(S, L, 0xffffffffu, fuse && !rebuild AWSEM_STAMP_PASS);
         if (threadIdx.x == 0) L.flag[cur] = 0;   // read by everyone before the barriers of the evaluation; written again next step
         {
@@ -1431,7 +1442,8 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
                 // atoms -- flag it (bit 2 of the status word) instead of letting the fixed-point sums wrap silently
                 if (sizeof(real) == 4 && !(fabsf((float)F.x) < 2.6e5f && fabsf((float)F.y) < 2.6e5f && fabsf((float)F.z) < 2.6e5f)) atomicOr(S.status, 4);
                 real g[3];
-                gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, mi.id, g);
+                if (pre) { const bool second = k >= (int)blockDim.x; g[0] = second ? g_pre[1][0] : g_pre[0][0]; g[1] = second ? g_pre[1][1] : g_pre[0][1]; g[2] = second ? g_pre[1][2] : g_pre[0][2]; }
+                else gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, mi.id, g);
                 const real im = fs * mi.inv_mass, sq = ns * mi.sqrt_inv_mass;
                 R3<real> v = L.vel(k), x = L.pos(i);
                 v.x = a * v.x + im * F.x + sq * g[0];
