@@ -1413,13 +1413,20 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
         }
         // the step's random numbers depend on nothing but the counter: generated here, ahead of the force phases
         // (for up to two particles per lane; larger systems draw them in the integrator as before)
-        real g_pre[2][3] = {{0, 0, 0}, {0, 0, 0}};
+        real g_pre[2][3] = {{0, 0, 0}, {0, 0, 0}}, im_pre[2] = {0, 0};
+        int at_pre[2] = {0, 0};
         const bool pre = S.nmassive <= 2 * (int)blockDim.x;
         if (pre) {
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const int k = (int)threadIdx.x + q * (int)blockDim.x;
-                if (k < S.nmassive) gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, S.massive[k].id, g_pre[q]);
+                if (k < S.nmassive) {   // the particle's static record is consumed here too: noise amplitude, force factor, atom
+                    const MassiveItem<real> mi = S.massive[k];
+                    gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, mi.id, g_pre[q]);
+                    const real sq = ns * mi.sqrt_inv_mass;
+                    g_pre[q][0] *= sq; g_pre[q][1] *= sq; g_pre[q][2] *= sq;
+                    im_pre[q] = fs * mi.inv_mass; at_pre[q] = mi.atom;
+                }
             }
         }
         evaluate_terms<false, true>(S, L, 0xffffffffu, fuse && !rebuild AWSEM_STAMP_PASS);
@@ -1427,9 +1434,20 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
         {
             float m = 0;
             for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {   // compact list: no lane idles on a virtual site
-                const MassiveItem<real> mi = S.massive[k];
                 const GatherItem<real> gi = S.gather[k];
-                const int i = mi.atom;
+                const bool second = k >= (int)blockDim.x;
+                real g[3], im;
+                int i;
+                if (pre) {
+                    i = second ? at_pre[1] : at_pre[0]; im = second ? im_pre[1] : im_pre[0];
+                    g[0] = second ? g_pre[1][0] : g_pre[0][0]; g[1] = second ? g_pre[1][1] : g_pre[0][1]; g[2] = second ? g_pre[1][2] : g_pre[0][2];
+                } else {
+                    const MassiveItem<real> mi = S.massive[k];
+                    i = mi.atom; im = fs * mi.inv_mass;
+                    gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, mi.id, g);
+                    const real sq = ns * mi.sqrt_inv_mass;
+                    g[0] *= sq; g[1] *= sq; g[2] *= sq;
+                }
                 R3<real> F = L.force(i);
                 L.zero_force(i);
 #pragma unroll
@@ -1441,14 +1459,10 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
                 // fp32 accumulators hold +-5.2e5 kJ/mol/nm per component (Q19.12): a force beyond half of that means overlapping
                 // atoms -- flag it (bit 2 of the status word) instead of letting the fixed-point sums wrap silently
                 if (sizeof(real) == 4 && !(fabsf((float)F.x) < 2.6e5f && fabsf((float)F.y) < 2.6e5f && fabsf((float)F.z) < 2.6e5f)) atomicOr(S.status, 4);
-                real g[3];
-                if (pre) { const bool second = k >= (int)blockDim.x; g[0] = second ? g_pre[1][0] : g_pre[0][0]; g[1] = second ? g_pre[1][1] : g_pre[0][1]; g[2] = second ? g_pre[1][2] : g_pre[0][2]; }
-                else gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, mi.id, g);
-                const real im = fs * mi.inv_mass, sq = ns * mi.sqrt_inv_mass;
                 R3<real> v = L.vel(k), x = L.pos(i);
-                v.x = a * v.x + im * F.x + sq * g[0];
-                v.y = a * v.y + im * F.y + sq * g[1];
-                v.z = a * v.z + im * F.z + sq * g[2];
+                v.x = a * v.x + im * F.x + g[0];
+                v.y = a * v.y + im * F.y + g[1];
+                v.z = a * v.z + im * F.z + g[2];
                 x.x += dtr * v.x; x.y += dtr * v.y; x.z += dtr * v.z;
                 L.set_vel(k, v); L.set_pos(i, x);
                 m = fmaxf(m, (float)dist2(x - L.refpos(i)));
