@@ -366,7 +366,7 @@ def load_hip_library(path: str | None = None) -> CApi:
     global _hip_api
     if _hip_api is not None and path is None:
         return _hip_api
-    p = path or HIP_LIBRARY_PATH
+    p = path or os.environ.get("AWSEM_HIP_LIBRARY") or HIP_LIBRARY_PATH   # AWSEM_HIP_LIBRARY: an experiment build (tools/try_*.sh)
     if not os.path.exists(p):
         raise ImportError(f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')")
     api = CApi(C.CDLL(p), "awsem_", extra=_HIP_ONLY)

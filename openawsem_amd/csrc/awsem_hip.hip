@@ -548,7 +548,12 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         const char* force = getenv("AWSEM_FORCE_CELL");
         bool zdep = false;
         for (auto& h : H0.contact) zdep = zdep || (h.flags & AWSEM_CONTACT_ZDEP);
-        cell_mode_ = lds_bytes<real>(LdsShape{natoms_, max_sites, (int)H0.contact.size(), 0, zdep ? 2400 : 1200, 0}, false) > lds_max || (force && atoi(force) != 0);
+        // sized by what DYNAMICS needs (velocities of the massive particles and the list reference positions on top of the
+        // evaluation's image): a system that fits for energies only would otherwise be unable to step or minimise
+        int nmassive = 0, ncv = 0;
+        for (double m : H0.mass) nmassive += m > 0 ? 1 : 0;
+        for (auto& h : H0.gauss) ncv += h.cv ? 1 : 0;
+        cell_mode_ = lds_bytes<real>(LdsShape{natoms_, max_sites, (int)H0.contact.size(), nmassive, zdep ? 2400 : 1200, ncv}, true) > lds_max || (force && atoi(force) != 0);
     }
     to_int_.clear(); to_orig_.clear();
     if (!cell_mode_ && !(getenv("AWSEM_NO_REORDER") && atoi(getenv("AWSEM_NO_REORDER")) != 0)) {   // the cell path's windows want the chain order
@@ -1073,13 +1078,18 @@ template <class real> void Engine<real>::cell_setup(DevSys<real>& S, const HostS
     for (int t = 0; t < S.n_beta; t++) cell_nacc_beta_[t] = S.beta[t].nacc;
     for (int t = 0; t < S.n_pap; t++) cell_nacc_pap_[t] = S.pap[t].nacc;
     if (S.n_contact > 1 || S.n_excl > 1) throw std::string("cell-list path: at most one contact and one excluded-volume term");
-    if (S.n_contact && (H.contact[0].flags & AWSEM_CONTACT_NOCUTOFF)) throw std::string("cell-list path: the contact term needs a cutoff");
     if (S.n_contact && S.contact[0].nsites >= (1 << 24)) throw std::string("cell-list path: at most 2^24 contact sites");
     if (const char* env = getenv("AWSEM_CELL_NEIGHBORS")) { int v = atoi(env); if (v >= 16 && v <= 4096) cell_per_site_ = v; }
     CellSys<real>& C = cell_;
     memset(&C, 0, sizeof C);
     C.natoms = natoms_; C.nrep = nrep_; C.nsites = S.n_contact ? S.contact[0].nsites : 0;
     cell_rc_contact_ = S.n_contact ? H.contact[0].p[AWSEM_CP_CUTOFF] : 0.0;
+    // NoCutoff (standalone burial_term): a cell list needs a radius.  The density switch theta_I(r) carries the factor
+    // sig(2 eta (rmax - r)) <= e^-60 = 8.8e-27 beyond rmax + 30 / eta (1.25 nm with the reference's constants): below the
+    // resolution of the Q31.32 density sums (2.3e-10) and of fp64 next to any density that matters, so rows cut there give
+    // the NoCutoff result bit for bit in the accumulators.
+    if (S.n_contact && (H.contact[0].flags & AWSEM_CONTACT_NOCUTOFF))
+        cell_rc_contact_ = H.contact[0].p[AWSEM_CP_RMAX] + 30.0 / H.contact[0].p[AWSEM_CP_ETA];
     cell_rc_excl_ = S.n_excl ? H.excl[0].r0 : 0.0;
     C.skin_half2 = (real)(0.25 * skin_ * skin_ * 0.999);
     C.status = dstatus_;
@@ -1260,6 +1270,7 @@ template <class real> void Engine<real>::cell_forces_pass(bool energy, unsigned 
 }
 template <class real> void Engine<real>::cell_evaluate(bool energy, unsigned mask, int redistribute, double* e, double* f) {
     const size_t R = nrep_;
+    synchronize();   // drains pending awsem_step launches and raises THEIR status (a row overflow during dynamics) before the word is reused here
     for (int attempt = 0;; attempt++) {
         HIP_TRY(hipEventRecord(ev0_, stream_));
         HIP_TRY(hipMemsetAsync(cell_.f, 0, R * 3 * natoms_ * sizeof(u64), stream_));
@@ -1422,6 +1433,7 @@ template <class real> void Engine<real>::cell_minimize(double tolerance, int max
 }
 template <class real> int Engine<real>::cell_neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) {
     const bool hb = kind == AWSEM_LIST_BETA || kind == AWSEM_LIST_PAP;
+    synchronize();   // as in cell_evaluate: a pending launch's status is reported, not mistaken for this call's
     if (!hb && (index != 0 || (kind != AWSEM_LIST_EXCL && kind != AWSEM_LIST_CONTACT))) throw std::string("neighbors (cell-list path): kind must be AWSEM_LIST_EXCL / _CONTACT (index 0), _BETA or _PAP");
     if ((kind == AWSEM_LIST_EXCL && !dsys_.n_excl) || (kind == AWSEM_LIST_CONTACT && !dsys_.n_contact) || index < 0 ||
         (kind == AWSEM_LIST_BETA && index >= dsys_.n_beta) || (kind == AWSEM_LIST_PAP && index >= dsys_.n_pap)) throw std::string("neighbors: no such term");

@@ -1,0 +1,266 @@
+"""Terms of the north-star list that no reference fixture pins: standalone burial_term (reference
+contactTerms.py:1772-1840), membrane_term / membrane_preassigned_term (membraneTerms.py:12-54, 115-156) and
+debye_huckel_term (debyeHuckelTerms.py:10-76).
+
+PARITY UNPINNED by the reference (no golden column, no example output), so the chain of evidence is: (CPU) the oracle
+against a numpy closed form written from the reference's expression strings, and its forces against finite differences
+of its energies; (GPU) the HIP kernels -- both precisions, the replica-resident and the cell-list path -- against the
+oracle, energies <= 1e-4 and forces <= 1e-3 relative in fp32 (BASELINE.json north_star), 1e-9 / 1e-7 in fp64."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import openawsem_amd as oa_pkg
+from openawsem_amd import _capi, unit as u
+from openawsem_amd.forces import System
+from openawsem_amd.functionTerms import contactTerms, debyeHuckelTerms, membraneTerms
+from oracle import awsem_oracle
+from tests.common import GOLDEN, golden_system
+from tests.test_oracle_forces import _fd_check
+
+
+def _system_of(oa, *forces):
+    system = System(oa.system.masses.copy())
+    system.virtual_sites = dict(oa.system.virtual_sites)
+    for f in forces:
+        system.addForce(f)
+    return system
+
+
+def _in_project_dir(tmp_path, monkeypatch, oa, seed=2):
+    """A working directory as the reference's factories expect one: burial_gamma.dat, zim, zimPosition."""
+    shutil.copy(os.path.join(oa_pkg.data_path.parameters, "burial_gamma.dat"), tmp_path / "burial_gamma.dat")
+    rng = np.random.default_rng(seed)
+    np.savetxt(tmp_path / "zim", rng.uniform(-1.0, 1.0, oa.nres))                       # hydrophobicity scale per residue
+    np.savetxt(tmp_path / "zimPosition", rng.integers(1, 4, oa.nres), fmt="%d")         # 1 / 2 / 3; 2 = membrane
+    monkeypatch.chdir(tmp_path)
+
+
+# ------------------------------------------------------------------ numpy closed forms (from the reference's expression strings)
+def _burial_closed_form(oa, x, k=4.184):
+    """contactTerms.py:1809: rho_i = sum_j step(|resId_i-resId_j|-2) 1/4 (1+tanh(50(r-.45)))(1+tanh(50(.65-r))) over ALL site pairs
+    (NoCutoff, no chain test); :1821-1823: E = sum_i sum_m -0.5 k gamma[type_i][m] (tanh(4(rho-rmin_m)) + tanh(4(rmax_m-rho)))."""
+    sites = np.array([cb if cb > 0 else ca for cb, ca in zip(oa.cb, oa.ca)])
+    resid = np.array([oa.resi[a] for a in sites])
+    types = np.array([contactTerms.gamma_se_map_1_letter[oa.seq[r]] for r in resid])
+    gamma = np.loadtxt("burial_gamma.dat")
+    p = x[sites]
+    r = np.linalg.norm(p[:, None, :] - p[None, :, :], axis=-1)
+    with np.errstate(over="ignore"):
+        theta = 0.25 * (1 + np.tanh(50 * (r - .45))) * (1 + np.tanh(50 * (.65 - r)))
+    theta[np.abs(resid[:, None] - resid[None, :]) < 2] = 0.0
+    rho = theta.sum(1)
+    e = 0.0
+    for m, (lo, hi) in enumerate(((0.0, 3.0), (3.0, 6.0), (6.0, 9.0))):
+        e += np.sum(-0.5 * k * gamma[types, m] * (np.tanh(4.0 * (rho - lo)) + np.tanh(4.0 * (hi - rho))))
+    return e, rho, r, resid
+
+
+def _slab(z, k_m=20.0, z_m=1.5, c=0.0):
+    return 0.5 * np.tanh(k_m * ((z - c) + z_m)) + 0.5 * np.tanh(k_m * (z_m - (z - c)))
+
+
+def _centred(x, oa, shift=0.0):
+    """Put the slab edge through the protein: the tanh flanks (width 1/k_m = 0.05 nm) are where the forces are."""
+    return x - np.array([0.0, 0.0, x[oa.ca, 2].mean() + shift])
+
+
+# ------------------------------------------------------------------ CPU: oracle against the closed forms
+@pytest.mark.parametrize("protein,frame", [("1ubq", 5), ("1brs", 11), ("1brs", 0)])
+def test_burial_term_oracle_matches_the_closed_form(protein, frame, tmp_path, monkeypatch, oracle_api):
+    oa, traj, _ = golden_system(protein)
+    _in_project_dir(tmp_path, monkeypatch, oa)
+    f = contactTerms.burial_term(oa)
+    assert f.getForceGroup() == 17 and f.getNonbondedMethod() == 0          # NoCutoff (contactTerms.py:1796-1839: no setNonbondedMethod)
+    assert f.gamma is None and f.burial_gamma.shape == (20, 3) and len(f.atom) == oa.nres
+    ctx = awsem_oracle.make_context(_system_of(oa, f), n_replicas=1)
+    x = traj[frame]
+    ctx.set_positions(x, replica=0)
+    e = ctx.energy_by_group()[0]
+    want, rho, r, resid = _burial_closed_form(oa, x)
+    assert abs(want) > 10.0 and abs(e[17] - want) < 1e-9 * abs(want)
+    assert np.count_nonzero(e) == 1
+    # the density really has no cutoff and no chain test: every |i - j| >= 2 pair is in it, most of them beyond 1 nm
+    far = (r > 1.0) & (np.abs(resid[:, None] - resid[None, :]) >= 2)
+    assert far.sum() > oa.nres
+
+
+def test_burial_term_oracle_forces_match_finite_differences(tmp_path, monkeypatch, oracle_api):
+    oa, traj, _ = golden_system("1ubq")
+    _in_project_dir(tmp_path, monkeypatch, oa)
+    f = contactTerms.burial_term(oa, k_burial=2.5)
+    ctx = awsem_oracle.make_context(_system_of(oa, f), n_replicas=1)
+    atoms = np.random.default_rng(5).choice(np.array(f.atom), size=24, replace=False)
+    got, fd = _fd_check(ctx, traj[5], 1 << 17, atoms)
+    assert np.abs(fd).max() > 1.0
+    assert np.abs(got - fd).max() / max(1.0, np.abs(fd).max()) < 2e-6
+    other = np.setdiff1d(np.arange(oa.natoms), np.array(f.atom))
+    ctx.set_positions(traj[5], replica=0)
+    assert not ctx.forces(1 << 17, redistribute=False)[0][other].any()     # every other atom carries isCb = 0 and is excluded
+
+
+def test_burial_in_the_contact_term_is_this_burial_term(tmp_path, monkeypatch, oracle_api):
+    """Cross-check against the golden-pinned column: contact_term minus its pair energy is the burial energy inside 1.0 nm, which
+    equals the NoCutoff one to ~1e-13 (theta_I(1.0 nm) = 6e-16)."""
+    oa, traj, _ = golden_system("1ubq")
+    _in_project_dir(tmp_path, monkeypatch, oa)
+    with_b = contactTerms.contact_term(oa)
+    without = contactTerms.contact_term(oa, burialPartOn=False, forceGroup=5)
+    alone = contactTerms.burial_term(oa)
+    ctx = awsem_oracle.make_context(_system_of(oa, with_b, without, alone), n_replicas=1)
+    ctx.set_positions(traj[7], replica=0)
+    e = ctx.energy_by_group()[0]
+    assert abs(e[17]) > 10.0 and abs((e[22] - e[5]) - e[17]) < 1e-9 * abs(e[17])
+
+
+@pytest.mark.parametrize("which", ["membrane_term", "membrane_preassigned_term"])
+def test_membrane_terms_oracle_matches_the_closed_form(which, tmp_path, monkeypatch, oracle_api):
+    oa, traj, _ = golden_system("1ubq")
+    _in_project_dir(tmp_path, monkeypatch, oa)
+    c = 0.3
+    if which == "membrane_term":         # membraneTerms.py:43-52: CA atoms, scale = zim[res]
+        f = membraneTerms.membrane_term(oa, k=2 * u.kilocalorie_per_mole, k_m=15, z_m=1.2, membrane_center=10 * c * u.angstrom)
+        atoms = np.array(oa.ca)
+        scale = np.loadtxt("zim")
+    else:                                # membraneTerms.py:144-153: CB (CA for Gly) sites, scale = -1 where zimPosition == 2 else +1
+        f = membraneTerms.membrane_preassigned_term(oa, k=2 * u.kilocalorie_per_mole, k_m=15, z_m=1.2, membrane_center=10 * c * u.angstrom)
+        atoms = np.array([cb if cb > 0 else ca for cb, ca in zip(oa.cb, oa.ca)])
+        scale = np.where(np.loadtxt("zimPosition") == 2, -1.0, 1.0)
+        assert (scale == -1).any() and (scale == 1).any()
+    assert f.getForceGroup() == 24 and list(f.atoms) == list(atoms) and np.array_equal(f.scale, scale)
+    ctx = awsem_oracle.make_context(_system_of(oa, f), n_replicas=1)
+    for shift in (0.0, 1.15, -1.25):     # protein centred in the slab, and straddling either edge
+        x = _centred(traj[4], oa, shift)
+        ctx.set_positions(x, replica=0)
+        e = ctx.energy_by_group()[0, 24]
+        want = np.sum(2 * 4.184 * _slab(x[atoms, 2], 15.0, 1.2, c) * scale)
+        assert abs(e - want) < 1e-10 * max(1.0, abs(want))
+        fz = ctx.forces(redistribute=False)[0]
+        h = 1e-6
+        dz = 2 * 4.184 * scale * (_slab(x[atoms, 2] + h, 15.0, 1.2, c) - _slab(x[atoms, 2] - h, 15.0, 1.2, c)) / (2 * h)
+        want_f = np.zeros_like(fz)
+        want_f[atoms, 2] = -dz
+        assert np.abs(fz - want_f).max() < 1e-6 * max(1.0, np.abs(want_f).max())
+    assert np.abs(want_f).max() > 1.0
+
+
+def test_debye_huckel_oracle_matches_the_closed_form(oracle_api):
+    oa, traj, _ = golden_system("1brs")
+    for charge_file in (None, os.path.join(GOLDEN, "1brs-charge.txt")):
+        f = debyeHuckelTerms.debye_huckel_term(oa, screening_length=0.8, chargeFile=charge_file)
+        if charge_file is None:          # debyeHuckelTerms.py:38-49
+            q = np.array([1.0 if s in "RK" else -1.0 if s in "DE" else 0.0 for s in oa.seq[:oa.nres]])
+        else:                            # :60
+            q = np.loadtxt(charge_file)[:oa.nres, 1]
+        site = np.array([oa.cb[i] if oa.cb[i] != -1 else oa.ca[i] for i in range(oa.nres)])
+        x = traj[3]
+        i, j = np.triu_indices(oa.nres, 1)                       # min_seq_sep = 1, pairs across chains included
+        keep = q[i] * q[j] != 0
+        i, j = i[keep], j[keep]
+        r = np.linalg.norm(x[site[i]] - x[site[j]], axis=1)
+        want = np.sum(4.15 * 4.184 * 0.1 * q[i] * q[j] / r * np.exp(-r / 0.8))          # :33
+        assert f.getNumBonds() == len(i) and f.getForceGroup() == 30
+        ctx = awsem_oracle.make_context(_system_of(oa, f), n_replicas=1)
+        ctx.set_positions(x, replica=0)
+        e = ctx.energy_by_group()[0, 30]
+        assert abs(want) > 1.0 and abs(e - want) < 1e-10 * abs(want)
+        atoms = np.random.default_rng(1).choice(site[np.unique(np.concatenate([i, j]))], size=12, replace=False)
+        got, fd = _fd_check(ctx, x, 1 << 30, atoms)
+        assert np.abs(got - fd).max() / max(1.0, np.abs(fd).max()) < 2e-6
+
+
+# ------------------------------------------------------------------ GPU: HIP kernels against the oracle
+def _compare(system, oa, frames, groups, precision, etol, ftol, fabs):
+    gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=len(frames), precision=precision)
+    system.upload(gpu)
+    cpu = awsem_oracle.make_context(system, n_replicas=len(frames))
+    for r, x in enumerate(frames):
+        gpu.set_positions(x, replica=r)
+        cpu.set_positions(x, replica=r)
+    eg, ec = gpu.energy_by_group(), cpu.energy_by_group()
+    for g in groups:
+        assert np.abs(ec[:, g]).min() > 1.0, g
+        assert (np.abs(eg[:, g] - ec[:, g]) <= etol * np.abs(ec[:, g]) + 2e-7).all(), (g, eg[:, g], ec[:, g])   # 2e-7: Q31.32 sums of both signs
+    others = [g for g in range(32) if g not in groups]
+    assert not eg[:, others].any()
+    for redistribute in (False, True):
+        fg, fc = gpu.forces(redistribute=redistribute), cpu.forces(redistribute=redistribute)
+        assert np.abs(fc).max() > 1.0
+        assert np.abs(fg - fc).max() <= ftol * np.abs(fc).max() + fabs
+    return gpu
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,etol,ftol", [(0, 1e-4, 1e-3), (1, 1e-9, 1e-7)])
+@pytest.mark.parametrize("cell", ["0", "1"])
+@pytest.mark.parametrize("protein", ["1ubq", "1brs"])
+def test_burial_term_gpu_matches_oracle(protein, cell, precision, etol, ftol, tmp_path, monkeypatch):
+    monkeypatch.setenv("AWSEM_FORCE_CELL", cell)
+    oa, traj, _ = golden_system(protein)
+    _in_project_dir(tmp_path, monkeypatch, oa)
+    f = contactTerms.burial_term(oa)
+    frames = [traj[k] for k in (0, 6, 11)]
+    fabs = 5e-3 if precision == 0 and cell == "0" else 1e-7 if precision else 1e-5     # resident fp32: Q19.12 accumulators
+    gpu = _compare(_system_of(oa, f), oa, frames, [17], precision, etol, ftol, fabs)
+    if cell == "0":
+        # NoCutoff on the replica-resident path: the term's pair list is every site pair with |resid_i - resid_j| >= 2, whatever
+        # its distance (the cell-list path cuts its rows where theta_I < e^-60, see Engine::cell_setup)
+        pairs = gpu.neighbors(_capi.LIST_CONTACT, 0, replica=1)
+        resid = np.array(f.resid)
+        i, j = np.triu_indices(oa.nres, 1)
+        keep = np.abs(resid[i] - resid[j]) >= 2
+        assert np.array_equal(pairs, np.stack([i[keep], j[keep]], 1))
+        x = frames[1][np.array(f.atom)]
+        assert (np.linalg.norm(x[pairs[:, 0]] - x[pairs[:, 1]], axis=1) > 1.0).sum() > oa.nres
+    gpu.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,etol,ftol", [(0, 1e-4, 1e-3), (1, 1e-9, 1e-7)])
+@pytest.mark.parametrize("cell", ["0", "1"])
+def test_burial_term_next_to_the_contact_term_gpu(cell, precision, etol, ftol, tmp_path, monkeypatch):
+    """Both CustomGB terms in one system, as a forces_setup.py that adds burial_term to the default list would have them."""
+    if cell == "1":
+        pytest.skip("the cell-list path takes one contact-shaped term per system (DESIGN.md section 8)")
+    monkeypatch.setenv("AWSEM_FORCE_CELL", cell)
+    oa, traj, _ = golden_system("1ubq")
+    _in_project_dir(tmp_path, monkeypatch, oa)
+    system = _system_of(oa, contactTerms.contact_term(oa), contactTerms.burial_term(oa, k_burial=3.0))
+    _compare(system, oa, [traj[k] for k in (2, 9)], [17, 22], precision, etol, ftol, 5e-3 if precision == 0 else 1e-7).close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,etol,ftol", [(0, 1e-4, 1e-3), (1, 1e-9, 1e-7)])
+@pytest.mark.parametrize("cell", ["0", "1"])
+def test_membrane_terms_gpu_match_oracle(cell, precision, etol, ftol, tmp_path, monkeypatch):
+    monkeypatch.setenv("AWSEM_FORCE_CELL", cell)
+    oa, traj, _ = golden_system("1ubq")
+    _in_project_dir(tmp_path, monkeypatch, oa)
+    system = _system_of(oa, membraneTerms.membrane_term(oa, k_m=20, z_m=1.5, forceGroup=24),
+                        membraneTerms.membrane_preassigned_term(oa, k=2 * u.kilocalorie_per_mole, forceGroup=25))
+    frames = [_centred(traj[4], oa, s) for s in (0.0, 1.45, -1.55)]
+    _compare(system, oa, frames, [24, 25], precision, etol, ftol, 5e-3 if precision == 0 and cell == "0" else 1e-7 if precision else 1e-5).close()
+
+
+@pytest.mark.gpu
+def test_burial_term_drives_dynamics_like_the_oracle(tmp_path, monkeypatch):
+    """Step-locked fp64 run (shared Philox stream) with the backbone + standalone burial term: the NoCutoff list is rebuilt and
+    walked inside the step kernel as well."""
+    oa, traj, _ = golden_system("1ubq")
+    _in_project_dir(tmp_path, monkeypatch, oa)
+    backbone = [f for f in oa.system.forces if f.getForceGroup() in (20, 21)]
+    system = _system_of(oa, *backbone, contactTerms.burial_term(oa))
+    gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=2, precision=1)
+    system.upload(gpu)
+    cpu = awsem_oracle.make_context(system, n_replicas=2)
+    T = [300.0, 500.0]
+    for c in (gpu, cpu):
+        c.set_positions(traj[0])
+        c.set_velocities_to_temperature(T, 3)
+        c.step(40, T, 0.002, 1.0, 17)
+    gpu.synchronize()
+    for r in range(2):
+        assert np.abs(gpu.get_positions(r) - cpu.get_positions(r)).max() < 1e-8
+    gpu.close()
