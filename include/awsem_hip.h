@@ -252,6 +252,25 @@ int awsem_minimize(awsem_handle h, double tolerance_kj_mol_nm, int max_iteration
 int awsem_last_kernel_ms(awsem_handle h, double* ms);
 int awsem_synchronize(awsem_handle h);
 
+/* ---- allocation-free evaluation ---------------------------------------------------------------------------
+ * NO COUNTERPART IN THE REFERENCE.  A variant of awsem_energy_by_group for callers that cannot allocate device
+ * memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It runs the same
+ * kernels on caller-owned DEVICE buffers and keeps everything else it needs (the per-replica Verlet pair lists of the
+ * pair terms and the device status word) in a file-scope `static __device__` array of AWSEM_NOALLOC_SCRATCH_BYTES that
+ * every GPU the library runs on holds until the process ends.  The call allocates and frees nothing, copies nothing to
+ * or from the host and does not synchronise: it enqueues one memset node and one kernel on `hip_stream` (a hipStream_t
+ * of the HIP runtime this library is linked against; NULL = the null stream) and returns.
+ *   d_xyz     device pointer, n_replicas x natoms x 3 doubles (nm), the caller's atom order
+ *   d_energy  device pointer, n_replicas x 32 doubles: the energy of every force group, as awsem_energy_by_group
+ * n_replicas is free per call (it need not equal the handle's): the handle contributes the finalized system only.
+ * Limits: replica-resident handles only (AWSEM_ESTATE on a cell-list handle); 256 + n_replicas x (pair-list entries
+ * reserved per replica) x 4 bytes must fit the array, else AWSEM_ELIMIT with the numbers in awsem_last_error().
+ * All calls on one GPU share the one array (it keeps the previous call's lists): calls that overlap in time on the same
+ * GPU -- two streams, two handles, two host threads -- race; serialise them. */
+#define AWSEM_NOALLOC_SCRATCH_BYTES (32u << 20)
+int awsem_energy_by_group_noalloc(awsem_handle h, int n_replicas, const double* d_xyz, double* d_energy,
+                                  void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,7 +66,9 @@ _SIGNATURES = {
     "version": (C.c_char_p, []),
 }
 # entry points that exist only in libawsem_hip.so (declared in include/awsem_hip.h, no oracle counterpart)
-_HIP_ONLY = {}
+_HIP_ONLY = {
+    "energy_by_group_noalloc": (C.c_int, ["H", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
 
 EXPORTED_SYMBOLS = tuple("awsem_" + n for n in list(_SIGNATURES) + list(_HIP_ONLY))
 
@@ -347,6 +349,12 @@ class Context:
             if n.value <= cap:
                 return pairs[:n.value].copy()
             cap = n.value
+
+    def energy_by_group_noalloc(self, n_replicas, d_xyz, d_energy, stream=None):
+        """awsem_energy_by_group_noalloc: device pointers (ints) in and out, asynchronous on `stream` (a hipStream_t as int,
+        None = the null stream); allocates nothing -- see include/awsem_hip.h."""
+        self.api.check(self.api.fn["energy_by_group_noalloc"](self.h, int(n_replicas), C.c_void_p(int(d_xyz)), C.c_void_p(int(d_energy)),
+                                                              C.c_void_p(int(stream)) if stream else None))
 
     def last_kernel_ms(self):
         ms = C.c_double()

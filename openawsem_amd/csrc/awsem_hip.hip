@@ -21,6 +21,15 @@
 #include "awsem_kernels.h"
 #include "awsem_cell.h"
 
+// ---- awsem_energy_by_group_noalloc: the one piece of device memory that is not behind a handle -----------------------
+// Pair lists and status word of the allocation-free entry point.  In host code the NAME of a __device__ array is only a
+// stand-in for the symbol: its device address is looked up once per device (hipGetSymbolAddress, with that device
+// current -- every GPU holds its own copy at its own address) when a handle is finalized there, kept in
+// g_noalloc_ptr[device], and only that pointer is ever handed to a kernel or a memset.
+static __device__ __align__(256) unsigned char scratch[AWSEM_NOALLOC_SCRATCH_BYTES];
+#define AWSEM_MAX_DEVICES 64
+static void* g_noalloc_ptr[AWSEM_MAX_DEVICES] = {};
+
 namespace {
 
 thread_local char g_err[1024] = "";
@@ -34,6 +43,7 @@ int fail(int code, const char* fmt, ...) {
 }
 
 struct HipError { hipError_t e; const char* what; };
+struct StateError { const char* what; };
 #define HIP_TRY(call)                                               \
     do {                                                            \
         hipError_t _e = (call);                                     \
@@ -89,6 +99,7 @@ struct EngineBase {
     virtual void get_state_all(double* xyz, double* v) = 0;
     virtual void minimize(double tolerance, int max_iterations, int32_t* iterations, double* rms) = 0;
     virtual int neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) = 0;
+    virtual void energy_noalloc(int nrep, const double* d_xyz, double* d_energy, hipStream_t stream) = 0;
     double last_ms = 0.0;
 };
 
@@ -155,7 +166,7 @@ public:
         HIP_TRY(hipSetDevice(device_));
         if (cell_mode_) { cell_evaluate(true, mask, 0, e, nullptr); return; }
         HIP_TRY(hipEventRecord(ev0_, stream_));
-        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, dsys_, pos_, mask, 0, dE_, (double*)nullptr);
+        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, dsys_, pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1_, stream_));
         HIP_TRY(hipMemcpyAsync(e, dE_, sizeof(double) * nrep_ * AWSEM_NGROUPS, hipMemcpyDeviceToHost, stream_));
@@ -167,7 +178,7 @@ public:
         HIP_TRY(hipSetDevice(device_));
         if (cell_mode_) { cell_evaluate(false, mask, redistribute, nullptr, f); return; }
         HIP_TRY(hipEventRecord(ev0_, stream_));
-        hipLaunchKernelGGL((awsem_eval_kernel<false, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, dsys_, pos_, mask, redistribute, (double*)nullptr, dF_);
+        hipLaunchKernelGGL((awsem_eval_kernel<false, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, dsys_, pos_, mask, redistribute, (double*)nullptr, dF_, (const double*)nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1_, stream_));
         HIP_TRY(hipMemcpyAsync(f, dF_, sizeof(double) * 3 * natoms_ * nrep_, hipMemcpyDeviceToHost, stream_));
@@ -249,6 +260,28 @@ public:
         if (timing_pending_) { record_ring_ms(); check_status(); }
     }
     int neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) override;
+    // No hipMalloc / hipFree / host copy / synchronisation in here: one memset node and one kernel on the caller's stream.
+    void energy_noalloc(int nrep, const double* d_xyz, double* d_energy, hipStream_t stream) override {
+        if (cell_mode_) throw StateError{"energy_by_group_noalloc: this handle runs on the cell-list path (the system does not fit the LDS of one CU); use awsem_energy_by_group"};
+        unsigned char* base = device_ < AWSEM_MAX_DEVICES ? (unsigned char*)g_noalloc_ptr[device_] : nullptr;
+        if (!base) throw StateError{"energy_by_group_noalloc: no scratch address for this device (finalize did not run here)"};
+        const unsigned long long need = 256ull + (unsigned long long)nrep * (unsigned long long)dsys_.list_stride * 4ull;
+        if (need > AWSEM_NOALLOC_SCRATCH_BYTES) {
+            char msg[320];
+            snprintf(msg, sizeof msg, "energy_by_group_noalloc: %d replicas x %lld pair-list entries reserved per replica need %llu bytes of scratch; the "
+                     "static array holds %u (at most %llu replicas of this system per call)", nrep, dsys_.list_stride, need,
+                     (unsigned)AWSEM_NOALLOC_SCRATCH_BYTES, (unsigned long long)((AWSEM_NOALLOC_SCRATCH_BYTES - 256ull) / ((unsigned long long)dsys_.list_stride * 4ull)));
+            throw std::string(msg);
+        }
+        HIP_TRY(hipSetDevice(device_));
+        DevSys<real> S = dsys_;                      // the handle's descriptors, with the lists and the status word moved into the static array
+        S.status = (int*)base;
+        S.lists = (unsigned*)(base + 256);
+        HIP_TRY(hipMemsetAsync(base, 0, 256, stream));   // the status word must start at zero; the lists are written before they are read
+        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep), dim3(block_), lds_eval_, stream, S, (const real*)nullptr, 0xffffffffu, 0,
+                           d_energy, (double*)nullptr, d_xyz);
+        HIP_TRY(hipGetLastError());
+    }
 
 private:
     template <class T> T* dalloc(size_t n) {
@@ -532,6 +565,11 @@ static HostSystem renumbered(const HostSystem& H, const std::vector<int>& to) {
 
 template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     HIP_TRY(hipSetDevice(device_));
+    if (device_ < AWSEM_MAX_DEVICES && !g_noalloc_ptr[device_]) {   // set-up: this device's copy of the static scratch array
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_noalloc_ptr[device_] = p;
+    }
     host_ = &H0;
     DevSys<real> S;
     memset(&S, 0, sizeof S);
@@ -1517,6 +1555,7 @@ struct awsem_context {
     }                                                                                                          \
     catch (const HipError& e) { return fail(AWSEM_EDEVICE, "HIP error %d (%s) in %s", (int)e.e, hipGetErrorString(e.e), e.what); } \
     catch (const std::string& s) { return fail(AWSEM_ELIMIT, "%s", s.c_str()); }                               \
+    catch (const StateError& e) { return fail(AWSEM_ESTATE, "%s", e.what); }                                   \
     catch (const std::bad_alloc&) { return fail(AWSEM_ENOMEM, "out of host memory"); }
 
 #define NEED_BUILD(h, group)                                                              \
@@ -1834,6 +1873,11 @@ int awsem_last_kernel_ms(awsem_handle h, double* ms) {
 int awsem_synchronize(awsem_handle h) {
     NEED_RUN(h);
     GUARD_BEGIN h->eng->synchronize(); return AWSEM_OK; GUARD_END
+}
+int awsem_energy_by_group_noalloc(awsem_handle h, int n_replicas, const double* d_xyz, double* d_energy, void* hip_stream) {
+    NEED_RUN(h);
+    if (n_replicas <= 0 || !d_xyz || !d_energy) return fail(AWSEM_EINVAL, "energy_by_group_noalloc: n_replicas must be positive and both device pointers non-null");
+    GUARD_BEGIN h->eng->energy_noalloc(n_replicas, d_xyz, d_energy, (hipStream_t)hip_stream); return AWSEM_OK; GUARD_END
 }
 
 }  // extern "C"

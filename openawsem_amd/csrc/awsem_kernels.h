@@ -1223,12 +1223,20 @@ template <class V> __device__ inline void load_positions(const typename V::real_
 // ------------------------------------------------------------------ evaluation kernel (energies and/or forces)
 template <bool ENERGY, class real>
 __global__ void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__ pos, unsigned mask, int redistribute,
-                                  double* __restrict__ e_out /* [R][32] or null */, double* __restrict__ f_out /* [R][natoms][3] or null */) {
+                                  double* __restrict__ e_out /* [R][32] or null */, double* __restrict__ f_out /* [R][natoms][3] or null */,
+                                  const double* __restrict__ xyz_aos /* null, or [R][natoms][3] in the caller's atom order instead of `pos` */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = blockIdx.x;
     Lds<real> L = carve_lds((real)0, smem, lds_shape(S), false);
     L.lists = S.lists + (size_t)rep * S.list_stride;
-    load_positions(pos + (size_t)rep * 3 * natoms, L, natoms);
+    if (xyz_aos) {   // uniform; awsem_energy_by_group_noalloc: the caller's device buffer, converted like the host does ((real) of the double)
+        const double* x = xyz_aos + (size_t)rep * 3 * natoms;
+        for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
+            const int o = S.orig ? S.orig[i] : i;
+            L.set_pos(i, R3<real>{(real)x[3 * o], (real)x[3 * o + 1], (real)x[3 * o + 2]});
+            L.zero_force(i);
+        }
+    } else load_positions(pos + (size_t)rep * 3 * natoms, L, natoms);
     for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
     if (threadIdx.x < AWSEM_NGROUPS) L.eg[threadIdx.x] = 0;
     if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
