@@ -54,6 +54,12 @@ int awsem_create(int natoms, int n_replicas, int device, int precision, awsem_ha
 void awsem_destroy(awsem_handle h);
 int awsem_set_masses(awsem_handle h, const double* mass_amu, int natoms);
 
+/* CMMotionRemover(frequency 1): ForceField.createSystem(topology) (openAWSEM.py:826,878) is called with its default
+ * removeCMMotion=True, so every OpenMM System the reference builds carries one.  At the start of every awsem_step step the
+ * mass-weighted mean velocity of the massive particles is subtracted from each of them (OpenMM's updateContextState order).
+ * Off by default at this level, as in a bare openmm.System; the Python mirror of OpenMMAWSEMSystem switches it on. */
+int awsem_set_cm_motion_removal(awsem_handle h, int enabled);
+
 /* ThreeParticleAverageSite(p1,p2,p3,w1,w2,w3) per virtual atom -- setup_virtual_sites, openAWSEM.py:666-696.
  * parents[3*i..] and weights[3*i..] belong to site[i]. */
 int awsem_set_virtual_sites(awsem_handle h, int n, const int32_t* site, const int32_t* parents,

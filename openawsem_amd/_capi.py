@@ -23,6 +23,7 @@ _SIGNATURES = {
     "create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "destroy": (None, ["H"]),
     "set_masses": (C.c_int, ["H", c_dbl_p, C.c_int]),
+    "set_cm_motion_removal": (C.c_int, ["H", C.c_int]),
     "set_virtual_sites": (C.c_int, ["H", C.c_int, c_int_p, c_int_p, c_dbl_p]),
     "add_harmonic_bonds": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, c_dbl_p]),
     "add_chi": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, C.c_double, C.c_double]),
@@ -158,6 +159,9 @@ class Context:
     def set_masses(self, mass):
         m = _f64(mass)
         self._call("set_masses", _dp(m), len(m))
+
+    def set_cm_motion_removal(self, enabled=True):
+        self._call("set_cm_motion_removal", int(bool(enabled)))
 
     def set_virtual_sites(self, site, parents, weights):
         s, p, w = _i32(site), _i32(parents).reshape(-1), _f64(weights).reshape(-1)

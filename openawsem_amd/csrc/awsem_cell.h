@@ -61,6 +61,8 @@ template <class real> struct CellSys {
     real* ref;                  // [R][3][natoms] positions at the last build
     real skin_half2;
     int* status;                // bit 1: neighbour row overflow
+    u64* cm;                    // [2][R][nblk_int][3] per-workgroup momentum sums of the integrator (Q31.32), by step parity (CMMotionRemover)
+    int nblk_int;               // workgroups per replica of the integrator's grid
 };
 
 __device__ __forceinline__ int ordered_int(float f) { int o = __float_as_int(f); return o >= 0 ? o : o ^ 0x7fffffff; }
@@ -691,6 +693,37 @@ template <class real> __global__ void cell_output_kernel(CellSys<real> C, double
             for (int k = 0; k < 3; k++) f_out[((size_t)rep * n + i) * 3 + k] = fixed_to_double(f[(size_t)k * n + i]);
     if (e_out && blockIdx.x == 0 && threadIdx.x < AWSEM_NGROUPS) e_out[(size_t)rep * AWSEM_NGROUPS + threadIdx.x] = fixed_to_double(C.eg[(size_t)rep * AWSEM_NGROUPS + threadIdx.x]);
 }
+// Centre-of-mass motion removal on the cell-list path.  A same-address global atomic from every workgroup costs ~0.1 us each
+// (DESIGN.md section 8), so the integrator's workgroups leave their momentum sums side by side -- C.cm[parity][rep][workgroup][3],
+// plain stores -- and the next step's integrator adds them up again in every workgroup (a few KB out of L2).  Q31.32 integers:
+// the total is the same whatever the grid.  cell_block_sum: sum of three per-thread values over the workgroup, to every thread.
+__device__ __forceinline__ void cell_block_sum(u64 s[3], u64* sh /* [3][16] shared */) {
+    for (int q = 0; q < 3; q++) {
+        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off);
+        if ((threadIdx.x & 63) == 0) sh[q * 16 + (threadIdx.x >> 6)] = s[q];
+    }
+    __syncthreads();
+    const int nw = blockDim.x >> 6;
+    for (int q = 0; q < 3; q++) { u64 t = 0; for (int w = 0; w < nw; w++) t += sh[q * 16 + w]; s[q] = t; }
+    __syncthreads();
+}
+// momentum of the velocities as they stand (first step of an awsem_step call): partial sums into the parity the first step reads
+template <class real>
+__global__ void cell_momentum_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ vel, const long long* __restrict__ step_base) {
+    __shared__ u64 sh[48];
+    const int rep = blockIdx.y, n = C.natoms, par = (int)(*step_base & 1);
+    const real* v = vel + (size_t)rep * 3 * n;
+    u64 s[3] = {0, 0, 0};
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S.nmassive; k += gridDim.x * blockDim.x) {
+        const MassiveItem<real> mi = S.massive[k];
+        const double m = 1.0 / (double)mi.inv_mass;
+        s[0] += (u64)__double2ll_rn(m * (double)v[mi.atom] * AWSEM_FIXED_SCALE);
+        s[1] += (u64)__double2ll_rn(m * (double)v[n + mi.atom] * AWSEM_FIXED_SCALE);
+        s[2] += (u64)__double2ll_rn(m * (double)v[2 * (size_t)n + mi.atom] * AWSEM_FIXED_SCALE);
+    }
+    cell_block_sum(s, sh);
+    if (threadIdx.x < 3) C.cm[(((size_t)par * C.nrep + rep) * C.nblk_int + blockIdx.x) * 3 + threadIdx.x] = s[threadIdx.x];
+}
 // Langevin update; every massive particle gathers the forces of the virtual sites it parents (no atomics) and clears
 // its own accumulator (those of the sites are cleared by the next step's pre kernel, once every parent has read them).
 template <class real>
@@ -703,6 +736,19 @@ __global__ void cell_integrate_kernel(DevSys<real> S, CellSys<real> C, real* __r
     const double a_d = ::exp(-friction * dt);
     const real a = (real)a_d, fs = (real)(friction == 0.0 ? dt : (1.0 - a_d) / friction);
     const real ns = (real)::sqrt(AWSEM_KB * T[rep] * (1.0 - a_d * a_d)), dtr = (real)dt;
+    __shared__ u64 sh[48];
+    const bool cmr = S.remove_cm != 0;   // uniform
+    const int par = (int)(step & 1);
+    real vcx = 0, vcy = 0, vcz = 0;
+    u64 mom[3] = {0, 0, 0};
+    if (cmr) {   // total momentum = sum of the partial sums every workgroup of the previous step (or cell_momentum_kernel) left
+        const u64* part = C.cm + ((size_t)par * C.nrep + rep) * C.nblk_int * 3;
+        u64 s[3] = {0, 0, 0};
+        for (int b = threadIdx.x; b < C.nblk_int; b += blockDim.x) { s[0] += part[3 * b]; s[1] += part[3 * b + 1]; s[2] += part[3 * b + 2]; }
+        cell_block_sum(s, sh);
+        const double f = (double)S.inv_total_mass / AWSEM_FIXED_SCALE;
+        vcx = (real)((double)(long long)s[0] * f); vcy = (real)((double)(long long)s[1] * f); vcz = (real)((double)(long long)s[2] * f);
+    }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S.nmassive; k += gridDim.x * blockDim.x) {
         const MassiveItem<real> mi = S.massive[k];
         const GatherItem<real> gi = S.gather[k];
@@ -718,11 +764,21 @@ __global__ void cell_integrate_kernel(DevSys<real> S, CellSys<real> C, real* __r
         real g[3];
         gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step, mi.id, g);
         const real im = fs * mi.inv_mass, sq = ns * mi.sqrt_inv_mass;
-        const real vx = a * v[i] + im * F.x + sq * g[0];
-        const real vy = a * v[n + i] + im * F.y + sq * g[1];
-        const real vz = a * v[2 * (size_t)n + i] + im * F.z + sq * g[2];
+        const real vx = a * (v[i] - vcx) + im * F.x + sq * g[0];
+        const real vy = a * (v[n + i] - vcy) + im * F.y + sq * g[1];
+        const real vz = a * (v[2 * (size_t)n + i] - vcz) + im * F.z + sq * g[2];
         v[i] = vx; v[n + i] = vy; v[2 * (size_t)n + i] = vz;
         L.px[i] += dtr * vx; L.py[i] += dtr * vy; L.pz[i] += dtr * vz;
+        if (cmr) {
+            const double m = 1.0 / (double)mi.inv_mass;
+            mom[0] += (u64)__double2ll_rn(m * (double)vx * AWSEM_FIXED_SCALE);
+            mom[1] += (u64)__double2ll_rn(m * (double)vy * AWSEM_FIXED_SCALE);
+            mom[2] += (u64)__double2ll_rn(m * (double)vz * AWSEM_FIXED_SCALE);
+        }
+    }
+    if (cmr) {   // this workgroup's share of the new momentum, for the next step (the other parity: nobody reads it during this kernel)
+        cell_block_sum(mom, sh);
+        if (threadIdx.x < 3) C.cm[(((size_t)(par ^ 1) * C.nrep + rep) * C.nblk_int + blockIdx.x) * 3 + threadIdx.x] = mom[threadIdx.x];
     }
 }
 

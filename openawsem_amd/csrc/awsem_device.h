@@ -149,6 +149,8 @@ template <class real> struct DevSys {
     long long list_stride;
     int n_lists;
     real skin_half2;                      // (skin/2)^2: lists are rebuilt once an atom has moved further than skin/2
+    int remove_cm;                        // CMMotionRemover: subtract the mass-weighted mean velocity at the top of every step
+    real inv_total_mass;                  // 1 / sum of the masses
     int* status;                          // device error word: bit 0 = a pair list overflowed
     long long* prof;                      // 16 phase-cycle accumulators (written by -DAWSEM_PROF builds only)
 };

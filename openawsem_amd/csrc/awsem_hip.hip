@@ -71,6 +71,7 @@ struct HGauss { int group; std::vector<int> pairs; std::vector<double> r0, sigma
 
 struct HostSystem {
     int natoms = 0;
+    bool remove_cm = false;
     std::vector<double> mass;
     std::vector<int> vs_site, vs_par;
     std::vector<double> vs_w;
@@ -640,6 +641,10 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         }
         S.inv_mass = upload(im);
         S.sqrt_inv_mass = upload(sim);
+        double mtot = 0;
+        for (int i = 0; i < natoms_; i++) mtot += H.mass[i];
+        S.remove_cm = H.remove_cm && mtot > 0 ? 1 : 0;
+        S.inv_total_mass = mtot > 0 ? (real)(1.0 / mtot) : (real)0;
         std::vector<MassiveItem<real>> mv;
         for (int i = 0; i < natoms_; i++) if (H.mass[i] > 0) mv.push_back(MassiveItem<real>{i, im[i], sim[i], to_orig_.empty() ? i : to_orig_[i]});
         S.massive = upload(mv);
@@ -1161,6 +1166,9 @@ template <class real> void Engine<real>::cell_setup(DevSys<real>& S, const HostS
     }
     C.flag = dalloc<unsigned>(R * 2);
     HIP_TRY(hipMemset(C.flag, 0, R * 2 * sizeof(unsigned)));
+    C.nblk_int = (int)cell_grid(S.nmassive).x;
+    C.cm = dalloc<u64>(2 * R * C.nblk_int * 3);
+    HIP_TRY(hipMemset(C.cm, 0, 2 * R * C.nblk_int * 3 * sizeof(u64)));
     C.eg = dalloc<u64>(R * AWSEM_NGROUPS);
     const size_t ns = std::max(1, C.nsites);
     C.rho = dalloc<u64>(R * ns); C.drho = dalloc<u64>(R * ns);
@@ -1385,6 +1393,10 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
     HIP_TRY(hipMemsetAsync(cell_.f, 0, (size_t)nrep_ * 3 * natoms_ * sizeof(u64), stream_));
     int s = 0;
     auto set_base = [&](long long v) { hipLaunchKernelGGL(cell_set_word_kernel<long long>, dim3(1), dim3(1), 0, stream_, cell_step_base_, v); };
+    if (dsys_.remove_cm) {   // the momentum the first step removes (later steps get it from the integrator before them)
+        set_base((long long)step0);
+        hipLaunchKernelGGL(cell_momentum_kernel<real>, cell_grid(dsys_.nmassive), dim3(256), 0, stream_, dsys_, cell_, vel_, (const long long*)cell_step_base_);
+    }
     while (s < nsteps) {
         // the rows are rebuilt unconditionally (a host-side decision baked into the launch) right after the coordinates were set
         if (use_graph && !cell_stale_ && nsteps - s >= AWSEM_CELL_CHUNK) {
@@ -1603,6 +1615,11 @@ int awsem_set_masses(awsem_handle h, const double* m, int natoms) {
     if (!m || natoms != h->natoms) return fail(AWSEM_EINVAL, "set_masses: natoms mismatch");
     for (int i = 0; i < natoms; i++) if (!(m[i] >= 0)) return fail(AWSEM_EINVAL, "set_masses: negative mass");
     h->H.mass.assign(m, m + natoms);
+    return AWSEM_OK;
+}
+int awsem_set_cm_motion_removal(awsem_handle h, int enabled) {
+    NEED_BUILD(h, 0);
+    h->H.remove_cm = enabled != 0;
     return AWSEM_OK;
 }
 int awsem_set_virtual_sites(awsem_handle h, int n, const int32_t* site, const int32_t* par, const double* w) {

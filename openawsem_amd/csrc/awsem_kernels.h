@@ -100,6 +100,7 @@ template <class real> struct ViewCommon {
     real* gamma;             // gamma tables of the current contact term (env-major)
     u64* eg;                 // per-group energies (fixed point)
     u64* cv;                 // sums of the collective-variable terms (fixed point), DevSys::n_cv of them
+    u64* cm;                 // [2][3] total momentum of the massive particles (fixed point, CmFix<real>::scale), double buffered by step parity
     int* satom;              // contact site -> atom, [contact term][max_contact_sites]
     unsigned* lcount;        // pair-list entry counts, one per list
     unsigned* flag;          // [2]: largest squared displacement since the last list build (float bits), double buffered
@@ -1165,7 +1166,7 @@ template <class real> __host__ __device__ inline size_t lds_bytes(const LdsShape
     size_t b = 0;
     b += (size_t)natoms * (Y::pos + Y::force + (with_vel ? Y::ref : 0)) + (with_vel ? (size_t)sh.nmassive * Y::vel : 0);
     b += (size_t)2 * nsites * sizeof(u64);            // rho, drho
-    b += (AWSEM_NGROUPS + (size_t)sh.ncv) * sizeof(u64);   // group energies, collective-variable sums
+    b += (AWSEM_NGROUPS + (size_t)sh.ncv + 6) * sizeof(u64);   // group energies, collective-variable sums, momentum sums
     b += (size_t)3 * nsites * sizeof(real);           // rhov, alpha, dalpha
     b += (size_t)sh.ngamma * sizeof(real);            // gamma staging
     b += (size_t)(ncontact > 0 ? ncontact : 1) * nsites * sizeof(int);   // contact site -> atom
@@ -1179,6 +1180,8 @@ template <class real> __device__ inline void carve_common(ViewCommon<real>& L, u
     L.eg = w; w += AWSEM_NGROUPS;
     L.cv = w; w += sh.ncv;
     if ((int)threadIdx.x < sh.ncv) L.cv[threadIdx.x] = 0;   // every kernel has a barrier between the carve-up and its first evaluation
+    L.cm = w; w += 6;
+    if (threadIdx.x < 6) L.cm[threadIdx.x] = 0;
     real* r = (real*)w;
     L.rhov = r; r += nsites; L.alpha = r; r += nsites; L.dalpha = r; r += nsites;
     L.gamma = r; r += sh.ngamma;
@@ -1369,6 +1372,53 @@ __device__ __forceinline__ void book_displacement(unsigned* flag, float m) {
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
     if ((threadIdx.x & 63) == 0) atomicMax(flag, __float_as_uint(m));   // non-negative floats order like their bits
 }
+// ---- centre-of-mass motion removal (OpenMM CMMotionRemover, frequency 1)
+// The total momentum sum_i m_i v_i of a replica is accumulated in fixed point (integer adds commute: the sum does not depend on
+// which lane owns which particle, so a trajectory stays bit-identical under any workgroup size or atom order).  fp32: Q15.16 in
+// 32-bit lanes (one lane-step resolves 1.5e-5 amu nm/ps, i.e. < 1e-7 nm/ps in the mean velocity, below an fp32 ulp of a
+// thermal velocity), reduced over the wave with six DPP adds per component; fp64: Q31.32, 64-bit shuffles.
+__device__ __forceinline__ int wave_sum_lane63(int v) {   // inclusive scan over the wave: lane 63 ends with the total
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1  (lanes without a source add 0)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8  -> lane 15 of every row holds the row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+template <class real> struct CmAcc;
+template <> struct CmAcc<float> {
+    static constexpr float scale = 65536.0f;
+    int x = 0, y = 0, z = 0;
+    __device__ __forceinline__ void add(float m, const R3<float>& v) {
+        const float s = m * scale;
+        x += __float2int_rn(s * v.x); y += __float2int_rn(s * v.y); z += __float2int_rn(s * v.z);
+    }
+    __device__ __forceinline__ void flush(u64* cm) const {   // whole wave, converged
+        const int X = wave_sum_lane63(x), Y = wave_sum_lane63(y), Z = wave_sum_lane63(z);
+        if ((threadIdx.x & 63) == 63) { fixed_add(&cm[0], (u64)(long long)X); fixed_add(&cm[1], (u64)(long long)Y); fixed_add(&cm[2], (u64)(long long)Z); }
+    }
+};
+template <> struct CmAcc<double> {
+    static constexpr double scale = AWSEM_FIXED_SCALE;
+    u64 x = 0, y = 0, z = 0;
+    __device__ __forceinline__ void add(double m, const R3<double>& v) {
+        x += (u64)__double2ll_rn(m * v.x * scale); y += (u64)__double2ll_rn(m * v.y * scale); z += (u64)__double2ll_rn(m * v.z * scale);
+    }
+    __device__ __forceinline__ void flush(u64* cm) const {
+        u64 s[3] = {x, y, z};
+        for (int q = 0; q < 3; q++) {
+            for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off);
+            if ((threadIdx.x & 63) == 0) fixed_add(&cm[q], s[q]);
+        }
+    }
+};
+// mean velocity from a momentum sum
+template <class real> __device__ __forceinline__ R3<real> cm_velocity(const u64* cm, real inv_total_mass) {
+    const real f = inv_total_mass * (real)(1.0 / (double)CmAcc<real>::scale);
+    return R3<real>{(real)(long long)cm[0] * f, (real)(long long)cm[1] * f, (real)(long long)cm[2] * f};
+}
+
 #ifndef AWSEM_STEP_ATTR
 #define AWSEM_STEP_ATTR
 #endif
@@ -1395,6 +1445,12 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
     if (threadIdx.x < 2) L.flag[threadIdx.x] = 0;
     __syncthreads();
     compute_virtual_sites(S, L);
+    const bool cmr = S.remove_cm != 0;
+    if (cmr) {   // momentum of the incoming velocities: what the first step removes (L.cm[0..2]; zeroed at the carve-up, a barrier ago)
+        CmAcc<real> acc;
+        for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) acc.add(M<real>::rcp(S.massive[k].inv_mass), L.vel(k));
+        acc.flush(L.cm);
+    }
     __syncthreads();
     AWSEM_STAMP_INIT;
     // The lists are rebuilt when a MASSIVE particle has moved further than skin/2 since the last build; lists screened on a
@@ -1403,6 +1459,7 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
     for (int s = 0; s < nsteps; s++) {
         const int cur = s & 1;
         const bool rebuild = s == 0 || __uint_as_float(L.flag[cur]) > (float)S.skin_half2;   // uniform across the workgroup
+        if (cmr && threadIdx.x < 3) L.cm[(cur ^ 1) * 3 + threadIdx.x] = 0;   // read for the last time in the previous step's integrator; this step's adds to it
         if (rebuild || !fuse) {   // the virtual sites in a phase of their own: the hydrogen-bond list builders read them
             update_virtual_sites(S, L);
             __syncthreads();
@@ -1421,7 +1478,7 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
         }
         // the step's random numbers depend on nothing but the counter: generated here, ahead of the force phases
         // (for up to two particles per lane; larger systems draw them in the integrator as before)
-        real g_pre[2][3] = {{0, 0, 0}, {0, 0, 0}}, im_pre[2] = {0, 0};
+        real g_pre[2][3] = {{0, 0, 0}, {0, 0, 0}}, im_pre[2] = {0, 0}, ms_pre[2] = {0, 0};
         int at_pre[2] = {0, 0};
         const bool pre = S.nmassive <= 2 * (int)blockDim.x;
         if (pre) {
@@ -1434,6 +1491,7 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
                     const real sq = ns * mi.sqrt_inv_mass;
                     g_pre[q][0] *= sq; g_pre[q][1] *= sq; g_pre[q][2] *= sq;
                     im_pre[q] = fs * mi.inv_mass; at_pre[q] = mi.atom;
+                    if (cmr) ms_pre[q] = M<real>::rcp(mi.inv_mass);
                 }
             }
         }
@@ -1441,17 +1499,21 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
         if (threadIdx.x == 0) L.flag[cur] = 0;   // read by everyone before the barriers of the evaluation; written again next step
         {
             float m = 0;
+            R3<real> vcm{0, 0, 0};
+            if (cmr) vcm = cm_velocity<real>(&L.cm[cur * 3], S.inv_total_mass);   // the momentum the previous step (or the launch start) left
+            CmAcc<real> acc;
             for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {   // compact list: no lane idles on a virtual site
                 const GatherItem<real> gi = S.gather[k];
                 const bool second = k >= (int)blockDim.x;
-                real g[3], im;
+                real g[3], im, ms = 0;
                 int i;
                 if (pre) {
-                    i = second ? at_pre[1] : at_pre[0]; im = second ? im_pre[1] : im_pre[0];
+                    i = second ? at_pre[1] : at_pre[0]; im = second ? im_pre[1] : im_pre[0]; ms = second ? ms_pre[1] : ms_pre[0];
                     g[0] = second ? g_pre[1][0] : g_pre[0][0]; g[1] = second ? g_pre[1][1] : g_pre[0][1]; g[2] = second ? g_pre[1][2] : g_pre[0][2];
                 } else {
                     const MassiveItem<real> mi = S.massive[k];
                     i = mi.atom; im = fs * mi.inv_mass;
+                    if (cmr) ms = M<real>::rcp(mi.inv_mass);
                     gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, mi.id, g);
                     const real sq = ns * mi.sqrt_inv_mass;
                     g[0] *= sq; g[1] *= sq; g[2] *= sq;
@@ -1468,14 +1530,16 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
                 // atoms -- flag it (bit 2 of the status word) instead of letting the fixed-point sums wrap silently
                 if (sizeof(real) == 4 && !(fabsf((float)F.x) < 2.6e5f && fabsf((float)F.y) < 2.6e5f && fabsf((float)F.z) < 2.6e5f)) atomicOr(S.status, 4);
                 R3<real> v = L.vel(k), x = L.pos(i);
-                v.x = a * v.x + im * F.x + g[0];
-                v.y = a * v.y + im * F.y + g[1];
-                v.z = a * v.z + im * F.z + g[2];
+                v.x = a * (v.x - vcm.x) + im * F.x + g[0];
+                v.y = a * (v.y - vcm.y) + im * F.y + g[1];
+                v.z = a * (v.z - vcm.z) + im * F.z + g[2];
                 x.x += dtr * v.x; x.y += dtr * v.y; x.z += dtr * v.z;
                 L.set_vel(k, v); L.set_pos(i, x);
+                if (cmr) acc.add(ms, v);
                 m = fmaxf(m, (float)dist2(x - L.refpos(i)));
             }
             for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;   // last read in the per-site pass
+            if (cmr) acc.flush(&L.cm[(cur ^ 1) * 3]);
             book_displacement(&L.flag[cur ^ 1], m);
         }
         __syncthreads();

@@ -360,7 +360,8 @@ class StateDataReporter(_Reporter):
         need_e = self._cols["potentialEnergy"] or self._cols["totalEnergy"]
         pe = float(ctx.energies()[0]) if need_e else 0.0
         ke = float(ctx.kineticEnergies()[0])
-        dof = 3 * int((simulation.system.masses > 0).sum())
+        # OpenMM's StateDataReporter: 3 per massive particle, minus 3 when the System has a CMMotionRemover
+        dof = 3 * int((simulation.system.masses > 0).sum()) - (3 if getattr(simulation.system, "remove_cm_motion", False) else 0)
         vals = {"step": simulation.currentStep, "time": ctx._time_ps, "potentialEnergy": pe, "kineticEnergy": ke,
                 "totalEnergy": pe + ke, "temperature": 2 * ke / (dof * KB)}
         print(self._sep.join(str(vals[k]) for k, on in self._cols.items() if on), file=self._out)

@@ -366,8 +366,10 @@ class BondSumForce(Force):
 class System:
     """Light stand-in for openmm.System: particle masses, virtual sites and the list of forces."""
 
-    def __init__(self, masses):
+    def __init__(self, masses, remove_cm_motion=False):
         self.masses = np.asarray(masses, dtype=float)
+        # ForceField.createSystem(topology) adds a CMMotionRemover by default (removeCMMotion=True); a bare openmm.System has none
+        self.remove_cm_motion = bool(remove_cm_motion)
         self.virtual_sites = {}   # site atom -> (p1, p2, p3, w1, w2, w3)
         self.forces = []
 
@@ -403,6 +405,7 @@ class System:
     def upload(self, ctx):
         """Push masses, virtual sites and every force to a fresh `_capi.Context`, then finalize it."""
         ctx.set_masses(self.masses)
+        ctx.set_cm_motion_removal(self.remove_cm_motion)
         if self.virtual_sites:
             sites = sorted(self.virtual_sites)
             par = [self.virtual_sites[s][:3] for s in sites]

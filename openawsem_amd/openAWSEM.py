@@ -265,7 +265,8 @@ class OpenMMAWSEMSystem:
         for a in atoms:
             if a.name not in masses_by_type:
                 raise ValueError(f"atom name {a.name!r} (residue {a.residue.name} {a.residue.id}) is not an AWSEM atom type")
-        self.system = System([masses_by_type[a.name] for a in atoms])
+        # forcefield.createSystem(topology) (reference openAWSEM.py:826,878): removeCMMotion defaults to True -> CMMotionRemover
+        self.system = System([masses_by_type[a.name] for a in atoms], remove_cm_motion=True)
         self.atom_lists, self.res_type = build_lists_of_atoms_2(self.nres, self.residues, atoms)
         self.n = self.atom_lists['n']
         self.h = self.atom_lists['h']

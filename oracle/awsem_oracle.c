@@ -68,6 +68,7 @@ typedef struct awsem_oracle_ctx {
     int64_t step;
     int nthreads;
     int precision;   /* 0 = fp32, 1 = fp64: only awsem_oracle_neighbors looks at it (distance screen in that precision) */
+    int remove_cm;   /* CMMotionRemover present (ForceField.createSystem default, openAWSEM.py:826,878) */
 } ctx_t;
 
 static __thread char g_err[512];
@@ -138,6 +139,11 @@ void awsem_oracle_destroy(ctx_t* c) {
 }
 int awsem_oracle_set_threads(ctx_t* c, int n) { if (!c || n < 1) return fail(-1, "bad thread count"); c->nthreads = n; return 0; }
 
+int awsem_oracle_set_cm_motion_removal(ctx_t* c, int enabled) {
+    CHECK_BUILD(c, 0);
+    c->remove_cm = enabled != 0;
+    return 0;
+}
 int awsem_oracle_set_masses(ctx_t* c, const double* m, int natoms) {
     CHECK_BUILD(c, 0);
     if (!m || natoms != c->natoms) return fail(-1, "set_masses: natoms mismatch");
@@ -860,6 +866,12 @@ int awsem_oracle_step(ctx_t* c, int nsteps, const double* T, double dt, double f
         double* f = malloc((size_t)n * 3 * sizeof(double));
         const double ns = sqrt(KB * T[r] * (1 - a * a));
         for (int s = 0; s < nsteps; s++) {
+            if (c->remove_cm) {   /* OpenMM ReferenceRemoveCMMotionKernel, run by updateContextState at the top of the step:
+                                     v_i -= (sum m v) / (sum m) for every particle with a mass */
+                double p[3] = {0, 0, 0}, mt = 0;
+                for (int i = 0; i < n; i++) { mt += c->mass[i]; for (int k = 0; k < 3; k++) p[k] += c->mass[i] * v[3 * i + k]; }
+                for (int i = 0; i < n; i++) if (c->mass[i] != 0) for (int k = 0; k < 3; k++) v[3 * i + k] -= p[k] / mt;
+            }
             virtual_sites(c, x);
             memset(f, 0, (size_t)n * 3 * sizeof(double));
             evaluate(c, x, 0xffffffffu, NULL, f);

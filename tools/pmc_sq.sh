@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_sq1_$tag -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 $PMC_ARGS > $O/pmc_sq1_$tag.log 2>&1 || { tail -5 $O/pmc_sq1_$tag.log; exit 1; }
-timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS --output-format csv -d $O/pmc_sq2_$tag -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 $PMC_ARGS > $O/pmc_sq2_$tag.log 2>&1 || { tail -5 $O/pmc_sq2_$tag.log; exit 2; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_sq1_$tag -- python3 $R/bench.py --no-cpu-baseline --no-schedule-legs --steps 3 --warmup 1 $PMC_ARGS > $O/pmc_sq1_$tag.log 2>&1 || { tail -5 $O/pmc_sq1_$tag.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS --output-format csv -d $O/pmc_sq2_$tag -- python3 $R/bench.py --no-cpu-baseline --no-schedule-legs --steps 3 --warmup 1 $PMC_ARGS > $O/pmc_sq2_$tag.log 2>&1 || { tail -5 $O/pmc_sq2_$tag.log; exit 2; }
 python3 - <<PY
 import csv, glob, collections
 for d in ("$O/pmc_sq1_$tag", "$O/pmc_sq2_$tag"):
