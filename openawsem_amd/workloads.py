@@ -109,13 +109,13 @@ def build_2xov(quiet=True):
 
 def build_synthetic(n_chains=122, seed=2026, spacing_nm=5.5, quiet=True, hbonds=False):
     """Synthetic multi-chain system of BASELINE.json configs[4]: `n_chains` copies of the 164-residue 2lzm chain
-    (tests/golden/2lzm-openmmawsem.pdb: one of the reference's own test structures) on a jittered cubic lattice with
+    (openawsem_amd/data/2lzm: one of the reference's own test structures, tests/data/2lzm-openmmawsem.pdb) on a jittered cubic lattice with
     random rigid rotations (seeded), 122 chains = 20008 residues / 118k atoms.  Terms: con, chain, chi, excl, rama,
     rama_proline, contact (with burial) -- the hydrogen-bond and fragment-memory terms are left out, as the config
     says (contact/burial cell-list scaling); `hbonds=True` adds beta 1-3, P-AP 1-2 and the helical term (dense
     nres x nres tables: meant for a few thousand residues)."""
     import numpy as np
-    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "2lzm-openmmawsem.pdb")
+    src = str(data_path.data / "2lzm" / "2lzm-openmmawsem.pdb")
     atoms = [ln for ln in open(src) if ln.startswith("ATOM")]
     xyz = np.array([[float(ln[30:38]), float(ln[38:46]), float(ln[46:54])] for ln in atoms])
     xyz -= xyz.mean(0)

@@ -5,11 +5,14 @@ proteins, covered by test_gpu_parity.py), so the check is GPU vs the fp64 CPU or
 per-group energies <= 1e-4 relative, forces <= 1e-3 relative in fp32; 1e-9 / 1e-7 in the fp64 check mode.
 The membrane term and the z-dependent contact variant are "parity unpinned" (no reference fixture at all).
 """
+import os
+
 import numpy as np
 import pytest
 
 from openawsem_amd import _capi, workloads
 from oracle import awsem_oracle
+from tests.common import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
@@ -28,28 +31,21 @@ def _system(name):
     return _cache[name]
 
 
-def _relaxed_frames(oa, n_steps=(0, 400, 3000)):
-    """Start structure plus two snapshots of a short fp32 GPU run at 500 K: compact enough to populate the pair terms."""
-    gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=1, precision=0)
-    oa.system.upload(gpu)
-    gpu.set_positions(oa.pdb.positions)
-    gpu.set_velocities_to_temperature([500.0], 3)
-    frames, done = [], 0
-    for n in n_steps:
-        if n > done:
-            gpu.step(n - done, [500.0], 0.002, 1.0, 3)
-            done = n
-        frames.append(gpu.get_positions(0))
-    gpu.close()
-    assert all(np.isfinite(f).all() for f in frames)
-    return frames
+def _relaxed_frames(oa, name):
+    """Start structure plus two snapshots (400 and 3000 steps) of a 500 K Langevin run of the fp64 CPU oracle, committed as
+    tests/golden/workload_frames_<name>.npy by tools/make_workload_frames.py: compact enough to populate the pair terms, and
+    independent of the GPU integrator."""
+    frames = np.load(os.path.join(GOLDEN, f"workload_frames_{name}.npy"))
+    assert frames.shape == (3, oa.natoms, 3) and np.isfinite(frames).all()
+    assert np.abs(frames[0] - np.asarray(oa.pdb.positions)).max() < 1e-12
+    return list(frames)
 
 
 @pytest.mark.parametrize("name", list(BUILDERS))
 @pytest.mark.parametrize("precision,etol,ftol", [(0, 1e-4, 1e-3), (1, 1e-9, 1e-7)])
 def test_energies_and_forces_match_oracle(name, precision, etol, ftol):
     oa = _system(name)
-    frames = _relaxed_frames(oa)
+    frames = _relaxed_frames(oa, name)
     R = len(frames)
     gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=R, precision=precision)
     oa.system.upload(gpu)

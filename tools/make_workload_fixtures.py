@@ -46,6 +46,16 @@ def t0958():
     print("T0958:", n, "residues")
 
 
+def lzm():
+    """The chain the synthetic multi-chain system (BASELINE.json configs[4]) is tiled from: the reference's own 2lzm test structure."""
+    import shutil
+    d = os.path.join(OUT, "2lzm")
+    os.makedirs(d, exist_ok=True)
+    for name in ("2lzm-openmmawsem.pdb", "2lzm-crystal_structure.fasta"):
+        shutil.copy(os.path.join(REF, "tests/data", name), os.path.join(d, name))
+    print("2lzm: copied")
+
+
 def r69_library():
     src = os.path.join(REF, "examples/1r69")
     d = os.path.join(OUT, "1r69")
@@ -80,4 +90,5 @@ def r69_library():
 
 if __name__ == "__main__":
     t0958()
+    lzm()
     r69_library()
