@@ -33,6 +33,7 @@ WORKLOADS = {
     "2xov": ("build_2xov", {}, 256, 50, "2xov membrane protein (276 residues), membrane_term + z-dependent contact, annealing ensemble"),
     "2xov-remd": ("build_2xov", {}, 64, 200, "2xov membrane protein, temperature replica exchange 300-600 K, exchange every launch (all-gather of energies, label swap)"),
     "synthetic-hb": ("build_synthetic", {"n_chains": 16, "seed": 3, "hbonds": True}, 1, 100, "synthetic multi-chain system (16 x 2lzm, 2624 residues) with the full backbone + contact + beta 1-3 + P-AP 1-2 + helical force field on the cell-list path"),
+    "synthetic-hb-20k": ("build_synthetic", {"n_chains": 122, "hbonds": True}, 1, 20, "synthetic multi-chain system (122 x 2lzm, 20 008 residues) with the full backbone + contact + beta 1-3 + P-AP 1-2 + helical force field on the cell-list path; lambda / gamma tables in functional form (the dense ones would be 5 x 3.2 GB)"),
     "synthetic-60k": ("build_synthetic", {"n_chains": 366}, 1, 20, "synthetic multi-chain system (366 x 2lzm, 60 024 residues), con/chain/chi/excl/rama/contact+burial, cell-list path"),
     "synthetic": ("build_synthetic", {}, 1, 20, "synthetic multi-chain system (122 x 2lzm), con/chain/chi/excl/rama/contact+burial, cell-list path, Langevin (dt 2 fs, friction 1/ps)"),
 }

@@ -131,6 +131,34 @@ int awsem_add_hbond_pap(awsem_handle h, int group, int nacc, const int32_t* acc_
                         int ndon, const int32_t* don_atoms, const int32_t* don_res, int nres,
                         const double* gamma, double k, double eta, double r0, double d_i4, double cutoff);
 
+/* The same two terms with the lambda / gamma table given as a FUNCTION of the residue pair instead of a dense nres x nres
+ * array (which is the reference's own limit on system size: hydrogenBondTerms.py:441,460,513-519 build five such tables,
+ * 3.2 GB each in fp64 at 20 000 residues).  The kernels evaluate the entry of a pair when they need it:
+ *   kind AWSEM_HB_LAMBDA_1   lambda_1  get_lambda_by_index(i, j, 0)                       hydrogenBondTerms.py:160-184, 441-447
+ *        AWSEM_HB_LAMBDA_2   lambda_2  get_Lambda_2, zero on chain edges (n = 1)          :300-328, 513-519
+ *        AWSEM_HB_LAMBDA_3   lambda_3  get_Lambda_3, zero on chain edges (n = 1)          :331-359, 577-583
+ *        AWSEM_HB_GAMMA_PAP_1  get_pap_gamma_APH + get_pap_gamma_AP                       :216-267, 649-658
+ *        AWSEM_HB_GAMMA_PAP_2  get_pap_gamma_P                                            :270-297, 728-736
+ * with i the donor residue, j the acceptor residue, c the class of |i - j| (4..17, 18..44, >= 45; no entry below 4):
+ *   LAMBDA_1: C[0][c]
+ *   LAMBDA_2: C[0][c] + C[1][c] T1[a_i][a_j] + C[2][c] (T2[a_i+1][a_j-1] + T2[a_i-1][a_j+1]) + C[3][c] (O[a_i] + O[a_j])
+ *   LAMBDA_3: C[0][c] + C[1][c] T1[a_i+1][a_j] + C[2][c] O[a_i+1] + C[1][c] O[a_j]
+ *   PAP_1:    (13 <= i-j <= 16 and same chain ? G[0] : 0) + (i-j >= 17 or other chain ? s G[1] : 0),  s = 1.5 if both helical else 1
+ *   PAP_2:    (i-j >= 9 or other chain ? s G[2] : 0)
+ * res_info is nres x 4 int32: residue type a (0..19, the H-bond ordering se_map_1_letter :15-18), chain index, chain-edge flag
+ * (isChainEdge(i, n=1)), helix flag (ssweight[i][1] == 1).  coef is 838 doubles: C[5][3], G[3], T1[20][20], T2[20][20], O[20]
+ * (the factory folds the signs and the 0.5 / 0.25 factors of get_Lambda_2/3 into C). */
+enum { AWSEM_HB_LAMBDA_1 = 1, AWSEM_HB_LAMBDA_2 = 2, AWSEM_HB_LAMBDA_3 = 3, AWSEM_HB_GAMMA_PAP_1 = 4, AWSEM_HB_GAMMA_PAP_2 = 5 };
+#define AWSEM_HB_FN_COEFS 838
+int awsem_add_hbond_beta_fn(awsem_handle h, int group, int two_theta, int nacc, const int32_t* acc_atoms,
+                            const int32_t* acc_res, int ndon, const int32_t* don_atoms, const int32_t* don_res, int nres,
+                            int kind, const int32_t* res_info, const double* coef, double k, double r_ON, double sigma_NO,
+                            double r_OH, double sigma_HO, double cutoff);
+int awsem_add_hbond_pap_fn(awsem_handle h, int group, int nacc, const int32_t* acc_atoms, const int32_t* acc_res,
+                           int ndon, const int32_t* don_atoms, const int32_t* don_res, int nres, int kind,
+                           const int32_t* res_info, const double* coef, double k, double eta, double r0, double d_i4,
+                           double cutoff);
+
 /* helical_term hydrogenBondTerms.py:790-832: E = -coef theta(O_i; N_{i+4}, H_{i+4}), coef = k(fa_i + fa_{i+4}). */
 int awsem_add_helical(awsem_handle h, int group, int n, const int32_t* atoms3, const double* coef, double r_ON,
                       double sigma_NO, double r_OH, double sigma_HO);

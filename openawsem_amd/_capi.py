@@ -35,6 +35,10 @@ _SIGNATURES = {
                                  c_dbl_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
     "add_hbond_pap": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int, c_dbl_p,
                                 C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "add_hbond_beta_fn": (C.c_int, ["H", C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int, C.c_int, c_int_p,
+                                    c_dbl_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "add_hbond_pap_fn": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int, C.c_int, c_int_p, c_dbl_p,
+                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
     "add_helical": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double, C.c_double, C.c_double]),
     "add_fragment_memory": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, C.c_int, c_dbl_p, C.c_double, C.c_double]),
     "add_membrane": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double, C.c_double, C.c_double]),
@@ -214,6 +218,23 @@ class Context:
         g = _f64(gamma)
         assert g.ndim == 2 and g.shape[0] == g.shape[1]
         self._call("add_hbond_pap", group, len(ar), _ip(aa), _ip(ar), len(dr), _ip(da), _ip(dr), g.shape[0], _dp(g),
+                   float(k), float(eta), float(r0), float(d_i4), float(cutoff))
+
+    def add_hbond_beta_fn(self, group, two_theta, acc_atoms, acc_res, don_atoms, don_res, nres, kind, res_info, coef, k, r_ON, sigma_NO,
+                          r_OH, sigma_HO, cutoff):
+        aa, ar = _i32(acc_atoms).reshape(-1), _i32(acc_res)
+        da, dr = _i32(don_atoms).reshape(-1), _i32(don_res)
+        info, cf = _i32(res_info).reshape(-1), _f64(coef).reshape(-1)
+        assert len(info) == 4 * nres and len(cf) == 838
+        self._call("add_hbond_beta_fn", group, int(two_theta), len(ar), _ip(aa), _ip(ar), len(dr), _ip(da), _ip(dr), int(nres), int(kind),
+                   _ip(info), _dp(cf), float(k), float(r_ON), float(sigma_NO), float(r_OH), float(sigma_HO), float(cutoff))
+
+    def add_hbond_pap_fn(self, group, acc_atoms, acc_res, don_atoms, don_res, nres, kind, res_info, coef, k, eta, r0, d_i4, cutoff):
+        aa, ar = _i32(acc_atoms).reshape(-1), _i32(acc_res)
+        da, dr = _i32(don_atoms).reshape(-1), _i32(don_res)
+        info, cf = _i32(res_info).reshape(-1), _f64(coef).reshape(-1)
+        assert len(info) == 4 * nres and len(cf) == 838
+        self._call("add_hbond_pap_fn", group, len(ar), _ip(aa), _ip(ar), len(dr), _ip(da), _ip(dr), int(nres), int(kind), _ip(info), _dp(cf),
                    float(k), float(eta), float(r0), float(d_i4), float(cutoff))
 
     def add_helical(self, group, atoms3, coef, r_ON, sigma_NO, r_OH, sigma_HO):

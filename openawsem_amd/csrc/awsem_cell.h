@@ -558,7 +558,10 @@ template <class real, class Desc> __device__ __forceinline__ void hb_rows_body(c
             const int dres = Desc::res_slot == 3 ? D.w : D.z, dq = dres - ares;
             const real r2 = dist2(ax - p[D.x], ay - p[n + D.x], az - p[2 * n + D.x]);
             bool pass = vq && r2 < rc2 && (dq <= d.band_lo || dq >= d.band_hi);
-            if (pass) { const size_t bit = (size_t)dres * d.nres + ares; pass = (d.nzmask[bit >> 5] >> (bit & 31)) & 1u; }
+            if (pass) {
+                if (d.fn) pass = hb_fn_value(*d.fn, dres, ares) != (real)0;
+                else { const size_t bit = (size_t)dres * d.nres + ares; pass = (d.nzmask[bit >> 5] >> (bit & 31)) & 1u; }
+            }
             const unsigned rowmask = (unsigned)(__ballot(pass) >> (row_in_wave * AWSEM_ROW)) & 0xffffu;
             if (pass) {
                 const int slot = cnt + __popc(rowmask & ((1u << sub) - 1u));

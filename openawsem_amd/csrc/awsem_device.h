@@ -74,12 +74,21 @@ template <class real> struct ContactD {
     real eta_sw2, z_m, zc, kb;
     ListSlot ls; real list_rc2;           // entry = site_i | site_j << 10 | (type_i*20+type_j) << 20 | in_density << 30 | has_pair_energy << 31
 };
+// Functional form of a lambda / gamma table (include/awsem_hip.h: awsem_add_hbond_beta_fn): lives in device memory, one per term.
+template <class real> struct HbFn {
+    int kind, pad;
+    const int* rinfo;                     // per residue: type | type(i-1) << 5 | type(i+1) << 10 | chain edge << 15 | helix << 16 | chain << 17
+    real scale;                           // -k
+    real cc[5][3], g[3];
+    real t1[400], t2[400], ob[20];
+};
 template <class real> struct BetaD {
     static constexpr int res_slot = 3;    // acc/don records carry the residue index in .w
     int group, two_theta, nacc, ndon, nres;
     const Int4* acc;                      // a1, a2, a3, residue
     const Int4* don;                      // d1, d2, d3, residue
-    const real* lambda;                   // nres x nres, row = donor residue, pre-multiplied by -k
+    const real* lambda;                   // nres x nres, row = donor residue, pre-multiplied by -k (null when fn is set)
+    const HbFn<real>* fn;                 // functional form of the same table, or null
     const unsigned* nzmask;               // bit (don_res * nres + acc_res) set where lambda != 0
     int nz_lds;                           // the mask fits the list builder's LDS scratch next to the acceptor / donor words
     real r_ON, r_OH, inv_sNO2, inv_sHO2, cutoff2;   // inv_s*2 = 1/sigma^2
@@ -92,7 +101,8 @@ template <class real> struct PapD {
     int group, nacc, ndon, nres;
     const Int4* acc;                      // a1, a2, residue, -
     const Int4* don;                      // d1, d2, residue, -
-    const real* gamma;                    // nres x nres, row = donor residue, pre-multiplied by -k
+    const real* gamma;                    // nres x nres, row = donor residue, pre-multiplied by -k (null when fn is set)
+    const HbFn<real>* fn;                 // functional form of the same table, or null
     const unsigned* nzmask;               // bit (don_res * nres + acc_res) set where gamma != 0
     int nz_lds;
     real eta2, r0, d_i4, cutoff2;

@@ -61,8 +61,10 @@ struct HContact {
     double p[AWSEM_CP_COUNT];
     std::vector<double> gamma, bgamma;
 };
-struct HBeta { int group, two_theta, nres; std::vector<int> acc_atoms, acc_res, don_atoms, don_res; std::vector<double> lambda; double k, r_ON, s_NO, r_OH, s_HO, cutoff; };
-struct HPap { int group, nres; std::vector<int> acc_atoms, acc_res, don_atoms, don_res; std::vector<double> gamma; double k, eta, r0, d_i4, cutoff; };
+// functional form of a lambda / gamma table (awsem_add_hbond_beta_fn / _pap_fn): kind 0 = none (dense table)
+struct HFn { int kind = 0; std::vector<int> info; std::vector<double> coef; };
+struct HBeta { int group, two_theta, nres; std::vector<int> acc_atoms, acc_res, don_atoms, don_res; std::vector<double> lambda; double k, r_ON, s_NO, r_OH, s_HO, cutoff; HFn fn; };
+struct HPap { int group, nres; std::vector<int> acc_atoms, acc_res, don_atoms, don_res; std::vector<double> gamma; double k, eta, r0, d_i4, cutoff; HFn fn; };
 struct HHelical { int group; std::vector<int> atoms; std::vector<double> coef; double r_ON, s_NO, r_OH, s_HO; };
 struct HFm { int group, ntab; std::vector<int> pairs; std::vector<double> table; double k, dr; };
 struct HMemb { int group; std::vector<int> atoms; std::vector<double> scale; double k, k_m, z_m, center; int kind = 0; };
@@ -301,6 +303,26 @@ private:
         if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
         return p;
     }
+    // functional lambda / gamma table: per-residue words and the small coefficient tables, in one device struct
+    const HbFn<real>* upload_fn(const HFn& f, int nres, double scale) {
+        std::vector<int> rinfo(nres);
+        for (int i = 0; i < nres; i++) {
+            const int* q = &f.info[4 * (size_t)i];
+            const bool edge = q[2] != 0;
+            const int prev = (i > 0 && !edge) ? f.info[4 * (size_t)(i - 1)] : 0, next = (i + 1 < nres && !edge) ? f.info[4 * (size_t)(i + 1)] : 0;
+            rinfo[i] = q[0] | (prev << 5) | (next << 10) | (edge ? 1 << 15 : 0) | (q[3] ? 1 << 16 : 0) | (q[1] << 17);
+        }
+        std::vector<HbFn<real>> one(1);
+        HbFn<real>& d = one[0];
+        memset(&d, 0, sizeof d);
+        d.kind = f.kind; d.rinfo = upload(rinfo); d.scale = (real)scale;
+        const double* c = f.coef.data();
+        for (int a = 0; a < 5; a++) for (int b = 0; b < 3; b++) d.cc[a][b] = (real)c[3 * a + b];
+        for (int a = 0; a < 3; a++) d.g[a] = (real)c[15 + a];
+        for (int a = 0; a < 400; a++) { d.t1[a] = (real)c[18 + a]; d.t2[a] = (real)c[418 + a]; }
+        for (int a = 0; a < 20; a++) d.ob[a] = (real)c[818 + a];
+        return upload(one);
+    }
     const real* upload_real(const std::vector<double>& v, double scale = 1.0) {
         std::vector<real> t(v.size());
         for (size_t i = 0; i < v.size(); i++) t[i] = (real)(v[i] * scale);
@@ -511,6 +533,16 @@ static void zero_band(const std::vector<double>& t, int nres, int* lo, int* hi) 
     *lo = l; *hi = h;
 }
 
+// The same band for a table given in functional form (HFn): beta kinds vanish for |q - p| < 4; the P-AP gammas of a single
+// chain vanish below q - p = 13 (pap_1) / 9 (pap_2); with several chains a pair of neighbouring residues can straddle a chain
+// boundary, so only the diagonal itself is known to be zero.
+static void fn_band(const HFn& f, int nres, int* lo, int* hi) {
+    if (f.kind <= 3) { *lo = -4; *hi = 4; return; }
+    bool one_chain = true;
+    for (int i = 1; i < nres; i++) one_chain = one_chain && f.info[4 * i + 1] == f.info[1];
+    if (one_chain) { *lo = -nres; *hi = f.kind == 4 ? 13 : 9; }
+    else { *lo = -1; *hi = 1; }
+}
 // one bit per table entry: set where t[q][p] != 0 (the list builders test it instead of loading the table)
 static std::vector<unsigned> nonzero_mask(const std::vector<double>& t, int nres) {
     std::vector<unsigned> m(((size_t)nres * nres + 31) / 32, 0u);
@@ -806,10 +838,15 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
             for (int i = 0; i < d.nacc; i++) acc[i] = Int4{h.acc_atoms[3 * i], h.acc_atoms[3 * i + 1], h.acc_atoms[3 * i + 2], h.acc_res[i]};
             for (int i = 0; i < d.ndon; i++) don[i] = Int4{h.don_atoms[3 * i], h.don_atoms[3 * i + 1], h.don_atoms[3 * i + 2], h.don_res[i]};
             d.acc = upload(acc); d.don = upload(don);
-            d.lambda = upload_real(h.lambda, -h.k);
-            d.nzmask = upload(nonzero_mask(h.lambda, h.nres));
-            d.nz_lds = ((size_t)d.nacc + d.ndon + ((size_t)h.nres * h.nres + 31) / 32) * 4 <= (size_t)natoms_ * (sizeof(real) == 4 ? 16 : 24);
-            zero_band(h.lambda, h.nres, &d.band_lo, &d.band_hi);
+            if (h.fn.kind) {
+                d.fn = upload_fn(h.fn, h.nres, -h.k);
+                fn_band(h.fn, h.nres, &d.band_lo, &d.band_hi);
+            } else {
+                d.lambda = upload_real(h.lambda, -h.k);
+                d.nzmask = upload(nonzero_mask(h.lambda, h.nres));
+                d.nz_lds = ((size_t)d.nacc + d.ndon + ((size_t)h.nres * h.nres + 31) / 32) * 4 <= (size_t)natoms_ * (sizeof(real) == 4 ? 16 : 24);
+                zero_band(h.lambda, h.nres, &d.band_lo, &d.band_hi);
+            }
             d.r_ON = (real)h.r_ON; d.r_OH = (real)h.r_OH; d.inv_sNO2 = (real)(1.0 / (h.s_NO * h.s_NO)); d.inv_sHO2 = (real)(1.0 / (h.s_HO * h.s_HO));
             d.cutoff2 = (real)(h.cutoff * h.cutoff);
             if (sizeof(real) == 4) {   // conservative fp32 pre-screen: Gaussian factors below e^-30 are dropped
@@ -835,10 +872,15 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
             for (int i = 0; i < d.nacc; i++) acc[i] = Int4{h.acc_atoms[2 * i], h.acc_atoms[2 * i + 1], h.acc_res[i], 0};
             for (int i = 0; i < d.ndon; i++) don[i] = Int4{h.don_atoms[2 * i], h.don_atoms[2 * i + 1], h.don_res[i], 0};
             d.acc = upload(acc); d.don = upload(don);
-            d.gamma = upload_real(h.gamma, -h.k);
-            d.nzmask = upload(nonzero_mask(h.gamma, h.nres));
-            d.nz_lds = ((size_t)d.nacc + d.ndon + ((size_t)h.nres * h.nres + 31) / 32) * 4 <= (size_t)natoms_ * (sizeof(real) == 4 ? 16 : 24);
-            zero_band(h.gamma, h.nres, &d.band_lo, &d.band_hi);
+            if (h.fn.kind) {
+                d.fn = upload_fn(h.fn, h.nres, -h.k);
+                fn_band(h.fn, h.nres, &d.band_lo, &d.band_hi);
+            } else {
+                d.gamma = upload_real(h.gamma, -h.k);
+                d.nzmask = upload(nonzero_mask(h.gamma, h.nres));
+                d.nz_lds = ((size_t)d.nacc + d.ndon + ((size_t)h.nres * h.nres + 31) / 32) * 4 <= (size_t)natoms_ * (sizeof(real) == 4 ? 16 : 24);
+                zero_band(h.gamma, h.nres, &d.band_lo, &d.band_hi);
+            }
             d.eta2 = (real)(2 * h.eta); d.r0 = (real)h.r0; d.d_i4 = (real)h.d_i4; d.cutoff2 = (real)(h.cutoff * h.cutoff);
             d.min_arg = sizeof(real) == 4 ? (real)-30 : (real)-1e300;
             D.push_back(d);
@@ -1704,7 +1746,7 @@ int awsem_add_hbond_beta(awsem_handle h, int group, int two_theta, int nacc, con
         if (two_theta && don_atoms[3 * i + 2] < 0) return fail(AWSEM_EINVAL, "add_hbond_beta: donor %d needs d3", i);
     }
     h->H.beta.push_back(HBeta{group, two_theta ? 1 : 0, nres, vec(acc_atoms, 3 * (size_t)nacc), vec(acc_res, nacc), vec(don_atoms, 3 * (size_t)ndon),
-                              vec(don_res, ndon), vec(lambda, (size_t)nres * nres), k, r_ON, s_NO, r_OH, s_HO, cutoff});
+                              vec(don_res, ndon), vec(lambda, (size_t)nres * nres), k, r_ON, s_NO, r_OH, s_HO, cutoff, HFn{}});
     return AWSEM_OK;
 }
 int awsem_add_hbond_pap(awsem_handle h, int group, int nacc, const int32_t* acc_atoms, const int32_t* acc_res, int ndon, const int32_t* don_atoms,
@@ -1716,7 +1758,56 @@ int awsem_add_hbond_pap(awsem_handle h, int group, int nacc, const int32_t* acc_
     for (int i = 0; i < nacc; i++) if (acc_res[i] < 0 || acc_res[i] >= nres) return fail(AWSEM_EINVAL, "add_hbond_pap: bad acceptor residue");
     for (int i = 0; i < ndon; i++) if (don_res[i] < 0 || don_res[i] >= nres) return fail(AWSEM_EINVAL, "add_hbond_pap: bad donor residue");
     h->H.pap.push_back(HPap{group, nres, vec(acc_atoms, 2 * (size_t)nacc), vec(acc_res, nacc), vec(don_atoms, 2 * (size_t)ndon), vec(don_res, ndon),
-                            vec(gamma, (size_t)nres * nres), k, eta, r0, d_i4, cutoff});
+                            vec(gamma, (size_t)nres * nres), k, eta, r0, d_i4, cutoff, HFn{}});
+    return AWSEM_OK;
+}
+static int check_fn(const char* who, int kind, bool beta, int nres, const int32_t* info, const double* coef) {
+    if (!info || !coef) return fail(AWSEM_EINVAL, "%s: res_info and coef are required", who);
+    if (beta ? (kind < AWSEM_HB_LAMBDA_1 || kind > AWSEM_HB_LAMBDA_3) : (kind != AWSEM_HB_GAMMA_PAP_1 && kind != AWSEM_HB_GAMMA_PAP_2))
+        return fail(AWSEM_EINVAL, "%s: kind %d does not belong to this term", who, kind);
+    for (int i = 0; i < nres; i++) {
+        if (info[4 * i] < 0 || info[4 * i] >= 20) return fail(AWSEM_EINVAL, "%s: residue type out of range 0..19 at residue %d", who, i);
+        if (info[4 * i + 1] < 0 || info[4 * i + 1] >= (1 << 14)) return fail(AWSEM_EINVAL, "%s: chain index out of range 0..16383 at residue %d", who, i);
+    }
+    return AWSEM_OK;
+}
+int awsem_add_hbond_beta_fn(awsem_handle h, int group, int two_theta, int nacc, const int32_t* acc_atoms, const int32_t* acc_res, int ndon,
+                            const int32_t* don_atoms, const int32_t* don_res, int nres, int kind, const int32_t* res_info, const double* coef,
+                            double k, double r_ON, double s_NO, double r_OH, double s_HO, double cutoff) {
+    NEED_BUILD(h, group);
+    if (nres <= 0) return fail(AWSEM_EINVAL, "add_hbond_beta_fn: bad arguments");
+    if (int rc = check_fn("add_hbond_beta_fn", kind, true, nres, res_info, coef)) return rc;
+    std::vector<double> none;   // no dense table
+    if (nacc < 0 || ndon < 0 || (nacc && (!acc_atoms || !acc_res)) || (ndon && (!don_atoms || !don_res))) return fail(AWSEM_EINVAL, "add_hbond_beta_fn: bad arguments");
+    if (!atoms_ok(h, acc_atoms, 3 * (size_t)nacc, true) || !atoms_ok(h, don_atoms, 3 * (size_t)ndon, true)) return fail(AWSEM_EINVAL, "add_hbond_beta_fn: atom index out of range");
+    for (int i = 0; i < nacc; i++) {
+        if (acc_res[i] < 0 || acc_res[i] >= nres || acc_atoms[3 * i] < 0) return fail(AWSEM_EINVAL, "add_hbond_beta_fn: bad acceptor %d", i);
+        if (two_theta && (acc_atoms[3 * i + 1] < 0 || acc_atoms[3 * i + 2] < 0)) return fail(AWSEM_EINVAL, "add_hbond_beta_fn: acceptor %d needs a2,a3", i);
+    }
+    for (int i = 0; i < ndon; i++) {
+        if (don_res[i] < 0 || don_res[i] >= nres || don_atoms[3 * i] < 0 || don_atoms[3 * i + 1] < 0) return fail(AWSEM_EINVAL, "add_hbond_beta_fn: bad donor %d", i);
+        if (two_theta && don_atoms[3 * i + 2] < 0) return fail(AWSEM_EINVAL, "add_hbond_beta_fn: donor %d needs d3", i);
+    }
+    HBeta b{group, two_theta ? 1 : 0, nres, vec(acc_atoms, 3 * (size_t)nacc), vec(acc_res, nacc), vec(don_atoms, 3 * (size_t)ndon),
+            vec(don_res, ndon), none, k, r_ON, s_NO, r_OH, s_HO, cutoff, HFn{}};
+    b.fn.kind = kind; b.fn.info = vec(res_info, 4 * (size_t)nres); b.fn.coef = vec(coef, AWSEM_HB_FN_COEFS);
+    h->H.beta.push_back(std::move(b));
+    return AWSEM_OK;
+}
+int awsem_add_hbond_pap_fn(awsem_handle h, int group, int nacc, const int32_t* acc_atoms, const int32_t* acc_res, int ndon, const int32_t* don_atoms,
+                           const int32_t* don_res, int nres, int kind, const int32_t* res_info, const double* coef, double k, double eta, double r0,
+                           double d_i4, double cutoff) {
+    NEED_BUILD(h, group);
+    if (nres <= 0) return fail(AWSEM_EINVAL, "add_hbond_pap_fn: bad arguments");
+    if (int rc = check_fn("add_hbond_pap_fn", kind, false, nres, res_info, coef)) return rc;
+    if (nacc < 0 || ndon < 0 || (nacc && (!acc_atoms || !acc_res)) || (ndon && (!don_atoms || !don_res))) return fail(AWSEM_EINVAL, "add_hbond_pap_fn: bad arguments");
+    if (!atoms_ok(h, acc_atoms, 2 * (size_t)nacc) || !atoms_ok(h, don_atoms, 2 * (size_t)ndon)) return fail(AWSEM_EINVAL, "add_hbond_pap_fn: atom index out of range");
+    for (int i = 0; i < nacc; i++) if (acc_res[i] < 0 || acc_res[i] >= nres) return fail(AWSEM_EINVAL, "add_hbond_pap_fn: bad acceptor residue");
+    for (int i = 0; i < ndon; i++) if (don_res[i] < 0 || don_res[i] >= nres) return fail(AWSEM_EINVAL, "add_hbond_pap_fn: bad donor residue");
+    HPap p{group, nres, vec(acc_atoms, 2 * (size_t)nacc), vec(acc_res, nacc), vec(don_atoms, 2 * (size_t)ndon), vec(don_res, ndon),
+           std::vector<double>(), k, eta, r0, d_i4, cutoff, HFn{}};
+    p.fn.kind = kind; p.fn.info = vec(res_info, 4 * (size_t)nres); p.fn.coef = vec(coef, AWSEM_HB_FN_COEFS);
+    h->H.pap.push_back(std::move(p));
     return AWSEM_OK;
 }
 int awsem_add_helical(awsem_handle h, int group, int n, const int32_t* atoms, const double* coef, double r_ON, double s_NO, double r_OH, double s_HO) {

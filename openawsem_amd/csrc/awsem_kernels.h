@@ -870,6 +870,37 @@ template <class V> __device__ __forceinline__ void contact_chain_rule(const Cont
 // ---- acceptor x donor terms (CustomHbondForce shape)
 // In fp32 the lists use a conservative pre-screen (Gaussian factors below e^-30 of their maximum are skipped, far
 // under fp32 resolution); the fp64 check mode applies only the reference's cutoff.
+// Entry (donor residue i, acceptor residue j) of a lambda / gamma table in its functional form, WITHOUT the -k factor; the
+// formulas and their order of operations are those of the reference's table builders (hydrogenBondTerms.py:160-359), so the
+// fp64 instantiation reproduces the dense tables to the last bits.
+template <class real> __device__ __forceinline__ real hb_fn_value(const HbFn<real>& f, int i, int j) {
+    const int ri = f.rinfo[i], rj = f.rinfo[j];
+    if (f.kind <= 3) {
+        const int d = i > j ? i - j : j - i;
+        if (d < 4) return (real)0;
+        const int c = d >= 45 ? 2 : (d >= 18 ? 1 : 0);
+        if (f.kind == 1) return f.cc[0][c];
+        if ((ri | rj) & (1 << 15)) return (real)0;   // a chain edge: the table builders leave the row / column zero
+        const int ai = ri & 31, aip = (ri >> 5) & 31, ain = (ri >> 10) & 31, aj = rj & 31, ajp = (rj >> 5) & 31, ajn = (rj >> 10) & 31;
+        real Lm = f.cc[0][c];
+        if (f.kind == 2) {
+            Lm = Lm + f.cc[1][c] * f.t1[ai * 20 + aj];
+            Lm = Lm + f.cc[2][c] * (f.t2[ain * 20 + ajp] + f.t2[aip * 20 + ajn]);
+            Lm = Lm + f.cc[3][c] * (f.ob[ai] + f.ob[aj]);
+        } else {
+            Lm = Lm + f.cc[1][c] * f.t1[ain * 20 + aj];
+            Lm = Lm + f.cc[2][c] * f.ob[ain];
+            Lm = Lm + f.cc[1][c] * f.ob[aj];
+        }
+        return Lm;
+    }
+    const int d = i - j;   // donor - acceptor
+    const bool other = (ri >> 17) != (rj >> 17);
+    const real s = ((ri & rj) >> 16) & 1 ? (real)1.5 : (real)1;
+    if (f.kind == 4) return ((d >= 13 && d <= 16 && !other) ? f.g[0] : (real)0) + ((d >= 17 || other) ? s * f.g[1] : (real)0);
+    return (d >= 9 || other) ? s * f.g[2] : (real)0;
+}
+
 template <class V, class Desc> __device__ __forceinline__ void build_hbond(const Desc& d, const V& L, int* status) {
     typedef typename V::real_t real;
     AWSEM_WAVE_VARS;
@@ -883,7 +914,7 @@ template <class V, class Desc> __device__ __forceinline__ void build_hbond(const
     for (int i = threadIdx.x; i < d.ndon; i += blockDim.x) { const Int4 D = d.don[i]; sd[i] = (unsigned)D.x | ((unsigned)(resw == 3 ? D.w : D.z) << 16); }
     // which (donor residue, acceptor residue) pairs have a non-zero table entry: one bit each, staged as well when it fits
     const unsigned* nz = d.nzmask;
-    if (d.nz_lds) {
+    if (d.nz_lds && !d.fn) {
         unsigned* sm = sd + d.ndon;
         const int words = (d.nres * d.nres + 31) >> 5;
         for (int i = threadIdx.x; i < words; i += blockDim.x) sm[i] = d.nzmask[i];
@@ -915,7 +946,10 @@ template <class V, class Desc> __device__ __forceinline__ void build_hbond(const
                 const int dres = (int)(D[u] >> 16), dq = dres - ares;
                 const real r2 = dist2(pa - L.pos((int)(D[u] & 0xffffu)));
                 pass[u] = pass[u] && r2 < d.list_rc2 && (dq <= d.band_lo || dq >= d.band_hi);
-                if (pass[u]) { const unsigned bit = (unsigned)(dres * d.nres + ares); pass[u] = (nz[bit >> 5] >> (bit & 31)) & 1u; }
+                if (pass[u]) {
+                    if (d.fn) pass[u] = hb_fn_value(*d.fn, dres, ares) != (real)0;   // uniform branch
+                    else { const unsigned bit = (unsigned)(dres * d.nres + ares); pass[u] = (nz[bit >> 5] >> (bit & 31)) & 1u; }
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; u++) list_append(e, cnt, d.ls.list_cap, status, pass[u], ((unsigned)ia << 16) | (unsigned)q[u]);
@@ -936,7 +970,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void beta_pair(const 
     const real da = r1s * i1 - d.r_ON, db = r2s * i2 - d.r_OH;
     const real ex1 = (real)0.5 * (da * da * d.inv_sNO2 + db * db * d.inv_sHO2);
     if (ex1 > d.max_expo) return;
-    const real c = d.lambda[(size_t)D.w * d.nres + A.w];   // -k * lambda[don_res][acc_res]
+    const real c = d.fn ? d.fn->scale * hb_fn_value(*d.fn, D.w, A.w) : d.lambda[(size_t)D.w * d.nres + A.w];   // -k * lambda[don_res][acc_res]
     const real th1 = M<real>::exp(-ex1), g1 = -th1 * da * d.inv_sNO2, g2 = -th1 * db * d.inv_sHO2;
     if (!d.two_theta) {
         if (ENERGY) e += (double)(c * th1);
@@ -983,7 +1017,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void pap_pair(const P
     const real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
     const real arg2 = d.eta2 * (d.r0 - r2s * i2);
     if (arg2 < d.min_arg) return;
-    const real c = d.gamma[(size_t)D.z * d.nres + A.z];   // -k * gamma[don_res][acc_res]
+    const real c = d.fn ? d.fn->scale * hb_fn_value(*d.fn, D.z, A.z) : d.gamma[(size_t)D.z * d.nres + A.z];   // -k * gamma[don_res][acc_res]
     const real s1 = sigmoid(d.eta2 * (d.r0 - r1s * i1)), s2 = sigmoid(arg2), s3 = sigmoid(arg3);
     if (ENERGY) e += (double)(c * s1 * s2 * s3);
     L.pair_force(A.x, D.x, a.x, a.y, a.z, c * d.eta2 * s1 * (one - s1) * s2 * s3 * i1);

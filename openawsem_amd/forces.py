@@ -139,12 +139,74 @@ class ContactForce(Force):
                         self.dparams, self.gamma, self.burial_gamma)
 
 
+HB_DENSE_MAX_RESIDUES = 2048   # above this the nres x nres lambda / gamma tables are not built: the functional form is uploaded
+
+
+class HbTableFn:
+    """A lambda / gamma table of the hydrogen-bond terms as a function of the residue pair (include/awsem_hip.h:
+    awsem_add_hbond_beta_fn): kind 1..5, res_info [nres][4] (type, chain, chain edge, helix), coef[838] = C[5][3], G[3],
+    T1[20][20], T2[20][20], O[20].  `dense()` builds the nres x nres array the reference feeds to OpenMM (the checker, and
+    the form small systems upload)."""
+
+    def __init__(self, kind, res_info, class_coef=None, gammas=None, t1=None, t2=None, one_body=None, dense=None):
+        self.kind = int(kind)
+        self.res_info = np.ascontiguousarray(res_info, dtype=np.int32).reshape(-1, 4)
+        c = np.zeros(838)
+        if class_coef is not None:
+            cc = np.asarray(class_coef, dtype=float)
+            c[:3 * len(cc)] = cc.reshape(-1)
+        if gammas is not None:
+            c[15:18] = gammas
+        if t1 is not None:
+            c[18:418] = np.asarray(t1, dtype=float).reshape(-1)
+        if t2 is not None:
+            c[418:818] = np.asarray(t2, dtype=float).reshape(-1)
+        if one_body is not None:
+            c[818:838] = one_body
+        self.coef = c
+        self._dense = dense
+
+    @property
+    def nres(self):
+        return len(self.res_info)
+
+    def dense(self):
+        return np.asarray(self._dense(), dtype=float)
+
+    def wants_functional(self):
+        import os
+        mode = os.environ.get("AWSEM_HB_TABLES", "")
+        if mode in ("functional", "dense"):
+            return mode == "functional"
+        return self.nres > HB_DENSE_MAX_RESIDUES
+
+
+class _LazyTable:
+    """`force.lam` / `force.gamma`: the dense table, built on first use when the force carries its functional form."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __get__(self, obj, owner=None):
+        if obj is None:
+            return self
+        v = obj.__dict__.get(self.name)
+        if v is None and obj.fn is not None:
+            v = obj.__dict__[self.name] = obj.fn.dense()
+        return v
+
+    def __set__(self, obj, value):
+        obj.__dict__[self.name] = None if value is None else np.asarray(value, dtype=float)
+
+
 class HbondBetaForce(Force):
     kind = "beta"
+    lam = _LazyTable("lam")
 
-    def __init__(self, two_theta, k, lam, r_ON=.298, sigma_NO=.068, r_OH=.206, sigma_HO=.076, cutoff=1.0, group=0):
+    def __init__(self, two_theta, k, lam=None, r_ON=.298, sigma_NO=.068, r_OH=.206, sigma_HO=.076, cutoff=1.0, group=0, fn=None):
         super().__init__(group)
-        self.two_theta, self.k, self.lam = int(two_theta), float(k), np.asarray(lam, dtype=float)
+        self.fn = fn
+        self.two_theta, self.k, self.lam = int(two_theta), float(k), lam
         self.r_ON, self.sigma_NO, self.r_OH, self.sigma_HO, self.cutoff = r_ON, sigma_NO, r_OH, sigma_HO, cutoff
         self.acc_atoms, self.acc_res, self.don_atoms, self.don_res = [], [], [], []
 
@@ -166,17 +228,23 @@ class HbondBetaForce(Force):
         return self.cutoff
 
     def _upload(self, ctx):
-        ctx.add_hbond_beta(self._group, self.two_theta, np.array(self.acc_atoms, dtype=np.int32).reshape(-1, 3), self.acc_res,
-                           np.array(self.don_atoms, dtype=np.int32).reshape(-1, 3), self.don_res, self.lam, self.k,
-                           self.r_ON, self.sigma_NO, self.r_OH, self.sigma_HO, self.cutoff)
+        acc, don = np.array(self.acc_atoms, dtype=np.int32).reshape(-1, 3), np.array(self.don_atoms, dtype=np.int32).reshape(-1, 3)
+        if self.fn is not None and self.fn.wants_functional():
+            ctx.add_hbond_beta_fn(self._group, self.two_theta, acc, self.acc_res, don, self.don_res, self.fn.nres, self.fn.kind,
+                                  self.fn.res_info, self.fn.coef, self.k, self.r_ON, self.sigma_NO, self.r_OH, self.sigma_HO, self.cutoff)
+        else:
+            ctx.add_hbond_beta(self._group, self.two_theta, acc, self.acc_res, don, self.don_res, self.lam, self.k,
+                               self.r_ON, self.sigma_NO, self.r_OH, self.sigma_HO, self.cutoff)
 
 
 class HbondPapForce(Force):
     kind = "pap"
+    gamma = _LazyTable("gamma")
 
-    def __init__(self, k, gamma, eta=70.0, r0=0.8, d_i4=1.2, cutoff=1.0, group=0):
+    def __init__(self, k, gamma=None, eta=70.0, r0=0.8, d_i4=1.2, cutoff=1.0, group=0, fn=None):
         super().__init__(group)
-        self.k, self.gamma = float(k), np.asarray(gamma, dtype=float)
+        self.fn = fn
+        self.k, self.gamma = float(k), gamma
         self.eta, self.r0, self.d_i4, self.cutoff = float(eta), float(r0), float(d_i4), float(cutoff)
         self.acc_atoms, self.acc_res, self.don_atoms, self.don_res = [], [], [], []
 
@@ -198,9 +266,13 @@ class HbondPapForce(Force):
         return self.cutoff
 
     def _upload(self, ctx):
-        ctx.add_hbond_pap(self._group, np.array(self.acc_atoms, dtype=np.int32).reshape(-1, 2), self.acc_res,
-                          np.array(self.don_atoms, dtype=np.int32).reshape(-1, 2), self.don_res, self.gamma, self.k,
-                          self.eta, self.r0, self.d_i4, self.cutoff)
+        acc, don = np.array(self.acc_atoms, dtype=np.int32).reshape(-1, 2), np.array(self.don_atoms, dtype=np.int32).reshape(-1, 2)
+        if self.fn is not None and self.fn.wants_functional():
+            ctx.add_hbond_pap_fn(self._group, acc, self.acc_res, don, self.don_res, self.fn.nres, self.fn.kind, self.fn.res_info,
+                                 self.fn.coef, self.k, self.eta, self.r0, self.d_i4, self.cutoff)
+        else:
+            ctx.add_hbond_pap(self._group, acc, self.acc_res, don, self.don_res, self.gamma, self.k,
+                              self.eta, self.r0, self.d_i4, self.cutoff)
 
 
 class HelicalForce(Force):

@@ -13,7 +13,7 @@ from pathlib import Path
 import numpy as np
 
 from .. import unit as _u
-from ..forces import HbondBetaForce, HbondPapForce, HelicalForce
+from ..forces import HbTableFn, HbondBetaForce, HbondPapForce, HelicalForce
 from .contactTerms import _chain_index, inWhichChain  # noqa: F401  (inWhichChain re-exported like the reference)
 
 se_map_1_letter = {'A': 0, 'P': 1, 'K': 2, 'N': 3, 'R': 4,
@@ -220,15 +220,44 @@ def _pap_gamma_table(oa, ssweight, parallel, gamma_aph=1.0, gamma_ap=0.4, gamma_
     return gamma
 
 
+def _res_info(oa, ssweight=None):
+    """[nres][4] per-residue integers of the functional table form: H-bond residue type, chain index, chain-edge flag (n=1), helix flag."""
+    nres = oa.nres
+    info = np.zeros((nres, 4), dtype=np.int32)
+    info[:, 0] = [se_map_1_letter[oa.seq[i]] for i in range(nres)]
+    info[:, 1] = [_chain_index(i, oa.chain_ends) for i in range(nres)]
+    info[:, 2] = [isChainEdge(i, oa.chain_starts, oa.chain_ends, n=1) for i in range(nres)]
+    if ssweight is not None:
+        info[:, 3] = np.asarray(ssweight)[:nres, 1] == 1
+    return info
+
+
+def _lambda_1_dense(nres):
+    idx = np.arange(nres)
+    sep = np.abs(idx[:, None] - idx[None, :])
+    return np.where((sep >= 4) & (sep < 18), 1.37, np.where((sep >= 18) & (sep < 45), 1.36, np.where(sep >= 45, 1.17, 0.0)))
+
+
+def _lambda_fn(oa, which):
+    """Functional form of lambda_1/2/3 (include/awsem_hip.h: AWSEM_HB_LAMBDA_*): the class tables of get_lambda_by_index /
+    get_alpha_by_index with the signs and the 0.5 / 0.25 factors of get_Lambda_2 / get_Lambda_3 folded in."""
+    p_par, p_anti, p_antihb, p_antinhb, p_parhb = read_beta_parameters()
+    L, A = np.array(_LAMBDA_TABLE), np.array(_ALPHA_TABLE)
+    info = _res_info(oa)
+    if which == 1:
+        return HbTableFn(1, info, class_coef=[L[0]], dense=lambda: _lambda_1_dense(oa.nres))
+    if which == 2:
+        return HbTableFn(2, info, class_coef=[L[1], -0.5 * A[0], -0.25 * A[1], -A[2]], t1=p_antihb[:, :, 0], t2=p_antinhb[:, :, 0],
+                         one_body=p_anti, dense=lambda: _lambda_table(oa, get_Lambda_2))
+    return HbTableFn(3, info, class_coef=[L[2], -A[3], -A[4]], t1=p_parhb[:, :, 0], one_body=p_par, dense=lambda: _lambda_table(oa, get_Lambda_3))
+
+
 def beta_term_1(oa, k=0.5 * _u.kilocalories_per_mole, forceGroup=27):
     """-k lambda_1(don, acc) theta(O_acc; N_don, H_don) (reference :418-477)."""
     print("beta_1 term ON")
     k_beta = convert_units(k) * oa.k_awsem
     nres = oa.nres
-    idx = np.arange(nres)
-    sep = np.abs(idx[:, None] - idx[None, :])
-    lam = np.where((sep >= 4) & (sep < 18), 1.37, np.where((sep >= 18) & (sep < 45), 1.36, np.where(sep >= 45, 1.17, 0.0)))
-    beta = HbondBetaForce(0, k_beta, lam)
+    beta = HbondBetaForce(0, k_beta, fn=_lambda_fn(oa, 1))
     for i in range(nres):
         if oa.o[i] != -1:
             beta.addAcceptor(oa.o[i], -1, -1, [i])
@@ -242,8 +271,7 @@ def beta_term_2(oa, k=0.5 * _u.kilocalories_per_mole, forceGroup=27):
     """-k lambda_2(don, acc) theta(O_acc; N_don, H_don) theta(O_don; N_acc, H_acc) (reference :480-541)."""
     print("beta_2 term ON")
     k_beta = convert_units(k) * oa.k_awsem
-    lam = _lambda_table(oa, get_Lambda_2)
-    beta = HbondBetaForce(1, k_beta, lam)
+    beta = HbondBetaForce(1, k_beta, fn=_lambda_fn(oa, 2))
     o, n, h = oa.o, oa.n, oa.h
     for i in range(oa.nres):
         if o[i] != -1 and n[i] != -1 and h[i] != -1:
@@ -257,8 +285,7 @@ def beta_term_3(oa, k=0.5 * _u.kilocalorie_per_mole, forceGroup=27):
     """-k lambda_3(don, acc) theta(O_acc; N_don, H_don) theta(O_don; N_{acc+2}, H_{acc+2}) (reference :544-611)."""
     print("beta_3 term ON")
     k_beta = convert_units(k) * oa.k_awsem
-    lam = _lambda_table(oa, get_Lambda_3)
-    beta = HbondBetaForce(1, k_beta, lam)
+    beta = HbondBetaForce(1, k_beta, fn=_lambda_fn(oa, 3))
     o, n, h = oa.o, oa.n, oa.h
     for i in range(oa.nres):
         if isChainEdge(i, oa.chain_starts, oa.chain_ends, n=2):
@@ -285,8 +312,9 @@ def pap_term_1(oa, k=0.5 * _u.kilocalorie_per_mole, dis_i_to_i4=1.2, forceGroup=
     nres, ca = oa.nres, oa.ca
     gamma_aph, gamma_ap = 1.0, 0.4
     ssweight = _load_ssweight(nres, ssweightFileName)
-    gamma = _pap_gamma_table(oa, ssweight, parallel=False, gamma_aph=gamma_aph, gamma_ap=gamma_ap)
-    pap = HbondPapForce(k_pap, gamma, eta=70, r0=0.8, d_i4=dis_i_to_i4)
+    fn = HbTableFn(4, _res_info(oa, ssweight), gammas=[gamma_aph, gamma_ap, 0.0],
+                   dense=lambda: _pap_gamma_table(oa, ssweight, parallel=False, gamma_aph=gamma_aph, gamma_ap=gamma_ap))
+    pap = HbondPapForce(k_pap, eta=70, r0=0.8, d_i4=dis_i_to_i4, fn=fn)
     for i in range(nres):
         if not isChainEnd(i, oa.chain_ends, n=4):
             pap.addAcceptor(ca[i], ca[i + 4], -1, [i])
@@ -304,8 +332,8 @@ def pap_term_2(oa, k=0.5 * _u.kilocalories_per_mole, dis_i_to_i4=1.2, forceGroup
     nres, ca = oa.nres, oa.ca
     gamma_p = 0.4
     ssweight = _load_ssweight(nres, ssweightFileName)
-    gamma = _pap_gamma_table(oa, ssweight, parallel=True, gamma_p=gamma_p)
-    pap = HbondPapForce(k_pap, gamma, eta=70, r0=0.8, d_i4=dis_i_to_i4)
+    fn = HbTableFn(5, _res_info(oa, ssweight), gammas=[0.0, 0.0, gamma_p], dense=lambda: _pap_gamma_table(oa, ssweight, parallel=True, gamma_p=gamma_p))
+    pap = HbondPapForce(k_pap, eta=70, r0=0.8, d_i4=dis_i_to_i4, fn=fn)
     for i in range(nres):
         if not isChainEnd(i, oa.chain_ends, n=4):
             pap.addAcceptor(ca[i], ca[i + 4], -1, [i])

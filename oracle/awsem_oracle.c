@@ -37,15 +37,19 @@ typedef struct {
     double bgamma[120];   /* [20][3]; with flag 8 a second [20][3] block for the membrane */
     double *gamma_idx, *bgamma_idx;   /* flag 16: [3][nsites][nsites] and [nsites][3] by site index */
 } contact_t;
+/* functional form of a lambda / gamma table (awsem_add_hbond_beta_fn / _pap_fn): info = [nres][4] type, chain, edge, helix */
+typedef struct { int kind, nres; int* info; double C[5][3], G[3], T1[20][20], T2[20][20], O[20]; } hbfn_t;
 typedef struct {
     int group, two_theta, nacc, ndon, nres;
     int *acc_atoms, *acc_res, *don_atoms, *don_res;
+    hbfn_t* fn;
     double *lambda;
     double k, r_ON, s_NO, r_OH, s_HO, cutoff;
 } beta_t;
 typedef struct {
     int group, nacc, ndon, nres;
     int *acc_atoms, *acc_res, *don_atoms, *don_res;
+    hbfn_t* fn;
     double *gamma;
     double k, eta, r0, d_i4, cutoff;
 } pap_t;
@@ -121,8 +125,8 @@ static void free_term(term_t* t) {
     case T_RAMA: { rama_t* x = p; free(x->atoms); free(x->wp); free(x->bw); } break;
     case T_EXCL: { excl_t* x = p; free(x->atom); free(x->cls); free(x->excl); } break;
     case T_CONTACT: { contact_t* x = p; free(x->atom); free(x->restype); free(x->resid); free(x->chain); free(x->gamma_idx); free(x->bgamma_idx); } break;
-    case T_BETA: { beta_t* x = p; free(x->acc_atoms); free(x->acc_res); free(x->don_atoms); free(x->don_res); free(x->lambda); } break;
-    case T_PAP: { pap_t* x = p; free(x->acc_atoms); free(x->acc_res); free(x->don_atoms); free(x->don_res); free(x->gamma); } break;
+    case T_BETA: { beta_t* x = p; if (x->fn) { free(x->fn->info); free(x->fn); } free(x->acc_atoms); free(x->acc_res); free(x->don_atoms); free(x->don_res); free(x->lambda); } break;
+    case T_PAP: { pap_t* x = p; if (x->fn) { free(x->fn->info); free(x->fn); } free(x->acc_atoms); free(x->acc_res); free(x->don_atoms); free(x->don_res); free(x->gamma); } break;
     case T_HELICAL: { helical_t* x = p; free(x->atoms); free(x->coef); } break;
     case T_FM: { fm_t* x = p; free(x->pairs); free(x->table); } break;
     case T_MEMB: { memb_t* x = p; free(x->atoms); free(x->scale); } break;
@@ -212,11 +216,59 @@ int awsem_oracle_add_contact(ctx_t* c, int group, int nsites, const int* atom, c
     if (bgamma) memcpy(t->bgamma, bgamma, ((flags & 8) ? 120 : 60) * sizeof(double));
     return add_term(c, T_CONTACT, t);
 }
-int awsem_oracle_add_hbond_beta(ctx_t* c, int group, int two_theta, int nacc, const int* acc_atoms, const int* acc_res, int ndon,
-                                const int* don_atoms, const int* don_res, int nres, const double* lambda, double k, double r_ON,
-                                double s_NO, double r_OH, double s_HO, double cutoff) {
+/* The lambda / gamma entry of (donor residue i, acceptor residue j) from its defining formulas instead of a dense table:
+ *   lambda_1: get_lambda_by_index(i, j, 0)                                  hydrogenBondTerms.py:160-184
+ *   lambda_2: get_Lambda_2 (300-328), lambda_3: get_Lambda_3 (331-359); both zero when i or j is a chain edge (513-519, 577-583)
+ *   P-AP: get_pap_gamma_APH + get_pap_gamma_AP (216-267) or get_pap_gamma_P (270-297)
+ * C holds the class tables with the signs and the 0.5 / 0.25 factors of the reference folded in (see include/awsem_hip.h). */
+static double hbfn_value(const hbfn_t* f, int i, int j) {
+    const int* I = f->info + 4 * (size_t)i; const int* J = f->info + 4 * (size_t)j;
+    if (f->kind <= 3) {
+        int d = abs(i - j), c;
+        if (d < 4) return 0.0;
+        c = d >= 45 ? 2 : (d >= 18 ? 1 : 0);
+        if (f->kind == 1) return f->C[0][c];
+        if (I[2] || J[2]) return 0.0;
+        int ai = I[0], aj = J[0], ain = I[4], aip = I[-4], ajn = J[4], ajp = J[-4];   /* i, j are no chain edges: i+-1, j+-1 exist */
+        double L = f->C[0][c];
+        if (f->kind == 2) {
+            L += f->C[1][c] * f->T1[ai][aj];
+            L += f->C[2][c] * (f->T2[ain][ajp] + f->T2[aip][ajn]);
+            L += f->C[3][c] * (f->O[ai] + f->O[aj]);
+        } else {
+            L += f->C[1][c] * f->T1[ain][aj];
+            L += f->C[2][c] * f->O[ain];
+            L += f->C[1][c] * f->O[aj];
+        }
+        return L;
+    }
+    int d = i - j, other = I[1] != J[1];
+    double s = (I[3] && J[3]) ? 1.5 : 1.0;
+    if (f->kind == 4) return ((d >= 13 && d <= 16 && !other) ? f->G[0] : 0.0) + ((d >= 17 || other) ? s * f->G[1] : 0.0);
+    return (d >= 9 || other) ? s * f->G[2] : 0.0;
+}
+static hbfn_t* make_fn(int kind, int nres, const int* info, const double* coef) {
+    hbfn_t* f = calloc(1, sizeof *f);
+    f->kind = kind; f->nres = nres; f->info = dup_mem(info, 4 * (size_t)nres * sizeof(int));
+    memcpy(f->C, coef, 15 * sizeof(double)); memcpy(f->G, coef + 15, 3 * sizeof(double));
+    memcpy(f->T1, coef + 18, 400 * sizeof(double)); memcpy(f->T2, coef + 418, 400 * sizeof(double)); memcpy(f->O, coef + 818, 20 * sizeof(double));
+    return f;
+}
+/* test hook: the whole table a functional form stands for, row = donor residue (checked against the dense builders) */
+int awsem_oracle_hb_fn_table(int kind, int nres, const int* info, const double* coef, double* out) {
+    if (!info || !coef || !out || kind < 1 || kind > 5 || nres <= 0) return fail(-1, "hb_fn_table: bad arguments");
+    hbfn_t* f = make_fn(kind, nres, info, coef);
+    for (int i = 0; i < nres; i++) for (int j = 0; j < nres; j++) out[(size_t)i * nres + j] = hbfn_value(f, i, j);
+    free(f->info); free(f);
+    return 0;
+}
+static double beta_lambda(const beta_t* t, int q, int p) { return t->fn ? hbfn_value(t->fn, q, p) : t->lambda[(size_t)q * t->nres + p]; }
+static double pap_gamma(const pap_t* t, int q, int p) { return t->fn ? hbfn_value(t->fn, q, p) : t->gamma[(size_t)q * t->nres + p]; }
+static int add_beta(ctx_t* c, int group, int two_theta, int nacc, const int* acc_atoms, const int* acc_res, int ndon,
+                    const int* don_atoms, const int* don_res, int nres, const double* lambda, hbfn_t* fn, double k, double r_ON,
+                    double s_NO, double r_OH, double s_HO, double cutoff) {
     CHECK_BUILD(c, group);
-    if (nacc < 0 || ndon < 0 || nres <= 0 || !lambda || (nacc && (!acc_atoms || !acc_res)) || (ndon && (!don_atoms || !don_res)))
+    if (nacc < 0 || ndon < 0 || nres <= 0 || (!lambda && !fn) || (nacc && (!acc_atoms || !acc_res)) || (ndon && (!don_atoms || !don_res)))
         return fail(-1, "add_hbond_beta: bad arguments");
     if (!check_atoms(c, acc_atoms, 3 * nacc, 1) || !check_atoms(c, don_atoms, 3 * ndon, 1)) return fail(-1, "add_hbond_beta: atom index out of range");
     for (int i = 0; i < nacc; i++) {
@@ -230,14 +282,35 @@ int awsem_oracle_add_hbond_beta(ctx_t* c, int group, int two_theta, int nacc, co
     beta_t* t = calloc(1, sizeof *t); t->group = group; t->two_theta = two_theta; t->nacc = nacc; t->ndon = ndon; t->nres = nres;
     t->acc_atoms = dup_mem(acc_atoms, 3 * nacc * sizeof(int)); t->acc_res = dup_mem(acc_res, nacc * sizeof(int));
     t->don_atoms = dup_mem(don_atoms, 3 * ndon * sizeof(int)); t->don_res = dup_mem(don_res, ndon * sizeof(int));
-    t->lambda = dup_mem(lambda, (size_t)nres * nres * sizeof(double));
+    t->lambda = lambda ? dup_mem(lambda, (size_t)nres * nres * sizeof(double)) : NULL;
+    t->fn = fn;
     t->k = k; t->r_ON = r_ON; t->s_NO = s_NO; t->r_OH = r_OH; t->s_HO = s_HO; t->cutoff = cutoff;
     return add_term(c, T_BETA, t);
 }
-int awsem_oracle_add_hbond_pap(ctx_t* c, int group, int nacc, const int* acc_atoms, const int* acc_res, int ndon, const int* don_atoms,
-                               const int* don_res, int nres, const double* gamma, double k, double eta, double r0, double d_i4, double cutoff) {
+int awsem_oracle_add_hbond_beta(ctx_t* c, int group, int two_theta, int nacc, const int* acc_atoms, const int* acc_res, int ndon,
+                                const int* don_atoms, const int* don_res, int nres, const double* lambda, double k, double r_ON,
+                                double s_NO, double r_OH, double s_HO, double cutoff) {
+    if (!lambda) return fail(-1, "add_hbond_beta: bad arguments");
+    return add_beta(c, group, two_theta, nacc, acc_atoms, acc_res, ndon, don_atoms, don_res, nres, lambda, NULL, k, r_ON, s_NO, r_OH, s_HO, cutoff);
+}
+static int fn_ok(int kind, int lo, int hi, int nres, const int* info, const double* coef) {
+    if (!info || !coef || kind < lo || kind > hi || nres <= 0) return 0;
+    for (int i = 0; i < nres; i++) if (info[4 * i] < 0 || info[4 * i] >= 20 || info[4 * i + 1] < 0) return 0;
+    return 1;
+}
+int awsem_oracle_add_hbond_beta_fn(ctx_t* c, int group, int two_theta, int nacc, const int* acc_atoms, const int* acc_res, int ndon,
+                                   const int* don_atoms, const int* don_res, int nres, int kind, const int* info, const double* coef,
+                                   double k, double r_ON, double s_NO, double r_OH, double s_HO, double cutoff) {
+    if (!fn_ok(kind, 1, 3, nres, info, coef)) return fail(-1, "add_hbond_beta_fn: bad arguments");
+    hbfn_t* fn = make_fn(kind, nres, info, coef);
+    int rc = add_beta(c, group, two_theta, nacc, acc_atoms, acc_res, ndon, don_atoms, don_res, nres, NULL, fn, k, r_ON, s_NO, r_OH, s_HO, cutoff);
+    if (rc) { free(fn->info); free(fn); }
+    return rc;
+}
+static int add_pap(ctx_t* c, int group, int nacc, const int* acc_atoms, const int* acc_res, int ndon, const int* don_atoms,
+                   const int* don_res, int nres, const double* gamma, hbfn_t* fn, double k, double eta, double r0, double d_i4, double cutoff) {
     CHECK_BUILD(c, group);
-    if (nacc < 0 || ndon < 0 || nres <= 0 || !gamma || (nacc && (!acc_atoms || !acc_res)) || (ndon && (!don_atoms || !don_res)))
+    if (nacc < 0 || ndon < 0 || nres <= 0 || (!gamma && !fn) || (nacc && (!acc_atoms || !acc_res)) || (ndon && (!don_atoms || !don_res)))
         return fail(-1, "add_hbond_pap: bad arguments");
     if (!check_atoms(c, acc_atoms, 2 * nacc, 0) || !check_atoms(c, don_atoms, 2 * ndon, 0)) return fail(-1, "add_hbond_pap: atom index out of range");
     for (int i = 0; i < nacc; i++) if (acc_res[i] < 0 || acc_res[i] >= nres) return fail(-1, "add_hbond_pap: bad acceptor residue");
@@ -245,9 +318,24 @@ int awsem_oracle_add_hbond_pap(ctx_t* c, int group, int nacc, const int* acc_ato
     pap_t* t = calloc(1, sizeof *t); t->group = group; t->nacc = nacc; t->ndon = ndon; t->nres = nres;
     t->acc_atoms = dup_mem(acc_atoms, 2 * nacc * sizeof(int)); t->acc_res = dup_mem(acc_res, nacc * sizeof(int));
     t->don_atoms = dup_mem(don_atoms, 2 * ndon * sizeof(int)); t->don_res = dup_mem(don_res, ndon * sizeof(int));
-    t->gamma = dup_mem(gamma, (size_t)nres * nres * sizeof(double));
+    t->gamma = gamma ? dup_mem(gamma, (size_t)nres * nres * sizeof(double)) : NULL;
+    t->fn = fn;
     t->k = k; t->eta = eta; t->r0 = r0; t->d_i4 = d_i4; t->cutoff = cutoff;
     return add_term(c, T_PAP, t);
+}
+int awsem_oracle_add_hbond_pap(ctx_t* c, int group, int nacc, const int* acc_atoms, const int* acc_res, int ndon, const int* don_atoms,
+                               const int* don_res, int nres, const double* gamma, double k, double eta, double r0, double d_i4, double cutoff) {
+    if (!gamma) return fail(-1, "add_hbond_pap: bad arguments");
+    return add_pap(c, group, nacc, acc_atoms, acc_res, ndon, don_atoms, don_res, nres, gamma, NULL, k, eta, r0, d_i4, cutoff);
+}
+int awsem_oracle_add_hbond_pap_fn(ctx_t* c, int group, int nacc, const int* acc_atoms, const int* acc_res, int ndon, const int* don_atoms,
+                                  const int* don_res, int nres, int kind, const int* info, const double* coef, double k, double eta, double r0,
+                                  double d_i4, double cutoff) {
+    if (!fn_ok(kind, 4, 5, nres, info, coef)) return fail(-1, "add_hbond_pap_fn: bad arguments");
+    hbfn_t* fn = make_fn(kind, nres, info, coef);
+    int rc = add_pap(c, group, nacc, acc_atoms, acc_res, ndon, don_atoms, don_res, nres, NULL, fn, k, eta, r0, d_i4, cutoff);
+    if (rc) { free(fn->info); free(fn); }
+    return rc;
 }
 int awsem_oracle_add_helical(ctx_t* c, int group, int n, const int* atoms, const double* coef, double r_ON, double s_NO, double r_OH, double s_HO) {
     CHECK_BUILD(c, group);
@@ -599,7 +687,7 @@ static double eval_beta(const beta_t* t, const double* x, double* f) {
         const int* A = t->acc_atoms + 3 * ia; const int* D = t->don_atoms + 3 * id;
         double rON = dist(x, A[0], D[0], dON);
         if (rON >= t->cutoff) continue;
-        double lam = t->lambda[(size_t)t->don_res[id] * t->nres + t->acc_res[ia]];
+        double lam = beta_lambda(t, t->don_res[id], t->acc_res[ia]);
         if (lam == 0.0) continue;
         double rOH = dist(x, A[0], D[1], dOH), g1, g2, h1 = 0, h2 = 0, r2N = 0, r2H = 0;
         double th1 = hb_theta(rON, rOH, t->r_ON, t->s_NO, t->r_OH, t->s_HO, &g1, &g2), th2 = 1.0;
@@ -627,7 +715,7 @@ static double eval_pap(const pap_t* t, const double* x, double* f) {
         const int* A = t->acc_atoms + 2 * ia; const int* D = t->don_atoms + 2 * id;
         double r1 = dist(x, A[0], D[0], d1);
         if (r1 >= t->cutoff) continue;
-        double gam = t->gamma[(size_t)t->don_res[id] * t->nres + t->acc_res[ia]];
+        double gam = pap_gamma(t, t->don_res[id], t->acc_res[ia]);
         if (gam == 0.0) continue;
         double r2 = dist(x, A[1], D[1], d2), r3 = dist(x, A[0], A[1], d3);
         double t1 = tanh(t->eta * (t->r0 - r1)), t2 = tanh(t->eta * (t->r0 - r2)), t3 = tanh(t->eta * (r3 - t->d_i4));
@@ -1004,11 +1092,11 @@ int awsem_oracle_neighbors(ctx_t* c, int rep, int kind, int index, double skin, 
             base = sqrt((double)(float)s2);
         } else base = sqrt(t->cutoff * t->cutoff);
         for (int a = 0; a < t->nacc; a++) for (int q = 0; q < t->ndon; q++)
-            if (t->lambda[(size_t)t->don_res[q] * t->nres + t->acc_res[a]] != 0.0 && below(c, x, t->acc_atoms[3 * a], t->don_atoms[3 * q], base + skin)) PUSH(a, q);
+            if (beta_lambda(t, t->don_res[q], t->acc_res[a]) != 0.0 && below(c, x, t->acc_atoms[3 * a], t->don_atoms[3 * q], base + skin)) PUSH(a, q);
     } else {
         const pap_t* t = term;
         for (int a = 0; a < t->nacc; a++) for (int q = 0; q < t->ndon; q++)
-            if (t->gamma[(size_t)t->don_res[q] * t->nres + t->acc_res[a]] != 0.0 && below(c, x, t->acc_atoms[2 * a], t->don_atoms[2 * q], t->cutoff + skin)) PUSH(a, q);
+            if (pap_gamma(t, t->don_res[q], t->acc_res[a]) != 0.0 && below(c, x, t->acc_atoms[2 * a], t->don_atoms[2 * q], t->cutoff + skin)) PUSH(a, q);
     }
 #undef PUSH
     qsort(out, n, 2 * sizeof(int), cmp_pair);

@@ -42,6 +42,8 @@ def load():
         lib = _api.lib
         lib.awsem_oracle_gauss3.restype = None
         lib.awsem_oracle_gauss3.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double)]
+        lib.awsem_oracle_hb_fn_table.restype = C.c_int
+        lib.awsem_oracle_hb_fn_table.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     return _api
 
 
@@ -53,3 +55,18 @@ def make_context(system, n_replicas=1, threads=1):
     if threads != 1:
         ctx._call("set_threads", int(threads))
     return ctx
+
+
+def hb_fn_table(fn):
+    """The dense table an openawsem_amd.forces.HbTableFn stands for, evaluated entry by entry by the oracle's restatement of the
+    reference's formulas."""
+    import numpy as np
+    api = load()
+    n = fn.nres
+    out = np.empty((n, n))
+    info = np.ascontiguousarray(fn.res_info, dtype=np.int32)
+    coef = np.ascontiguousarray(fn.coef, dtype=np.float64)
+    rc = api.lib.awsem_oracle_hb_fn_table(fn.kind, n, info.ctypes.data_as(C.POINTER(C.c_int32)), coef.ctypes.data_as(C.POINTER(C.c_double)),
+                                          out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0
+    return out

@@ -55,7 +55,9 @@ def test_energies_and_forces_match_oracle(name, precision, etol, ftol):
         cpu.set_positions(x, replica=r)
     eg, ec = gpu.energy_by_group(), cpu.energy_by_group()
     scale = np.maximum(np.abs(ec), 1.0)
-    assert (np.abs(eg - ec) / scale).max() <= etol, f"{name}: worst group energy error {(np.abs(eg - ec) / scale).max():.3e}"
+    # 1e-8 kJ/mol absolute: the accumulators are Q31.32 (2.3e-10 per addition), and a group may sum ten thousand terms of both signs
+    worst = ((np.abs(eg - ec) - 1e-8) / scale).max()
+    assert worst <= etol, f"{name}: worst group energy error {worst:.3e}"
     assert np.abs(ec).sum() > 0
     fg, fc = gpu.forces(redistribute=True), cpu.forces(redistribute=True)
     for r in range(R):
