@@ -364,10 +364,11 @@ class Context:
     def step_count(self, v):
         self._call("set_step_count", C.c_int64(int(v)))
 
-    def neighbors(self, kind, index=0, replica=0, skin=0.0):
-        """Sorted pair set (n x 2 int32) of one pair term; kind in LIST_EXCL / LIST_CONTACT / LIST_BETA / LIST_PAP."""
+    def neighbors(self, kind, index=0, replica=0, skin=0.0, capacity=4096):
+        """Sorted pair set (n x 2 int32) of one pair term; kind in LIST_EXCL / LIST_CONTACT / LIST_BETA / LIST_PAP.  `capacity`:
+        first guess of the pair count (a second call follows when it was too small)."""
         n = C.c_int32(0)
-        cap = 4096
+        cap = int(capacity)
         while True:
             pairs = np.empty((cap, 2), dtype=np.int32)
             self._call("neighbors", int(replica), int(kind), int(index), float(skin), _ip(pairs), cap, C.byref(n))

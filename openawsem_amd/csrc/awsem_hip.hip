@@ -145,6 +145,7 @@ public:
 
     void compute_virtual_sites() override {
         HIP_TRY(hipSetDevice(device_));
+        synchronize();
         cell_stale_ = true;
         if (cell_mode_) hipLaunchKernelGGL(cell_vsite_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, pos_);
         else hipLaunchKernelGGL(awsem_vsite_kernel<real>, dim3(nrep_), dim3(64), 0, stream_, dsys_, pos_);
@@ -153,6 +154,7 @@ public:
     }
     void maxwell(const double* T, uint64_t seed) override {
         HIP_TRY(hipSetDevice(device_));
+        synchronize();
         upload_T(T);
         hipLaunchKernelGGL(awsem_maxwell_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, vel_, dT_, (unsigned long long)seed);
         HIP_TRY(hipGetLastError());
@@ -160,6 +162,7 @@ public:
     }
     void scale_velocities(const double* scale) override {
         HIP_TRY(hipSetDevice(device_));
+        synchronize();
         upload_T(scale);   // reuses the per-replica double buffer
         hipLaunchKernelGGL(awsem_scale_velocities_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, vel_, dT_, 3 * natoms_);
         HIP_TRY(hipGetLastError());
@@ -260,7 +263,12 @@ public:
     void synchronize() override {
         HIP_TRY(hipSetDevice(device_));
         HIP_TRY(hipStreamSynchronize(stream_));
-        if (timing_pending_) { record_ring_ms(); check_status(); }
+        if (timing_pending_) {
+            record_ring_ms();
+            if (cell_mode_ && !cell_pending_.empty()) cell_replay_if_overflowed();
+            cell_pending_.clear();
+            check_status();
+        }
     }
     int neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) override;
     // No hipMalloc / hipFree / host copy / synchronisation in here: one memset node and one kernel on the caller's stream.
@@ -353,7 +361,7 @@ private:
             HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
             if (st & 2) {
                 cell_stale_ = true;
-                throw std::string("neighbour list overflow on the cell-list path during dynamics: raise AWSEM_CELL_NEIGHBORS (partners reserved per contact site, default 96, grown to twice the fullest row when dynamics start)");
+                throw std::string("neighbour list overflow on the cell-list path outside a replayable launch sequence: raise AWSEM_CELL_NEIGHBORS (partners reserved per contact site, default 96, grown to twice the fullest row when dynamics start)");
             }
             if (st & 4) throw std::string("a force exceeded the range of the fp32 fixed-point accumulators (2.6e5 kJ/mol/nm): overlapping atoms or an exploding "
                                           "trajectory -- minimise the structure first (awsem_minimize), reduce the time step, or use the fp64 mode");
@@ -380,14 +388,14 @@ private:
         HIP_TRY(hipSetDevice(device_));
         std::vector<real> t((size_t)3 * natoms_);
         for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++) t[(size_t)k * natoms_ + in_(i)] = (real)src[3 * i + k];
-        HIP_TRY(hipStreamSynchronize(stream_));
+        synchronize();   // pending launches are resolved (status checked, a cell-path replay done) before the state changes under them
         int r0 = rep < 0 ? 0 : rep, r1 = rep < 0 ? nrep_ : rep + 1;
         for (int r = r0; r < r1; r++)
             HIP_TRY(hipMemcpy(dst + (size_t)r * 3 * natoms_, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
     }
     void get_state(const real* src, int rep, double* dst) {
         HIP_TRY(hipSetDevice(device_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        synchronize();
         std::vector<real> t((size_t)3 * natoms_);
         HIP_TRY(hipMemcpy(t.data(), src + (size_t)rep * 3 * natoms_, t.size() * sizeof(real), hipMemcpyDeviceToHost));
         for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++) dst[3 * i + k] = (double)t[(size_t)k * natoms_ + in_(i)];
@@ -454,6 +462,14 @@ private:
     void cell_forces_pass(bool energy, unsigned mask);
     void cell_evaluate(bool energy, unsigned mask, int redistribute, double* e, double* f);
     void cell_step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0);
+    // A neighbour row that overflows in the middle of a trajectory (the chains became denser than the rows were sized for) drops
+    // pairs; the launches since the last synchronisation are then REPLAYED from a snapshot of (x, v) with longer rows.  The
+    // random numbers are a function of (seed, replica, step, atom), so the replay is the trajectory larger rows would have given.
+    struct PendingStep { int nsteps; std::vector<double> T; double dt, friction; uint64_t seed; int64_t step0; };
+    std::vector<PendingStep> cell_pending_;
+    real *cell_snap_pos_ = nullptr, *cell_snap_vel_ = nullptr;
+    bool cell_replaying_ = false;
+    void cell_replay_if_overflowed();
     void cell_one_step(double dt, double friction, uint64_t seed, int offset);
     void cell_minimize(double tolerance, int max_iterations, int32_t* iterations, double* rms);
     struct CellGraph { hipGraphExec_t exec = nullptr; double dt = 0, friction = 0; uint64_t seed = 0; long long gen = -1; };
@@ -1394,12 +1410,38 @@ template <class real> void Engine<real>::cell_one_step(double dt, double frictio
 // A launch of `nsteps` is played as captured HIP graphs of AWSEM_CELL_CHUNK steps (the ~11 kernels of a step cost more
 // to enqueue from the host than to run) plus single steps for the remainder; AWSEM_CELL_GRAPH=0 disables the graphs.
 #define AWSEM_CELL_CHUNK 10
+template <class real> void Engine<real>::cell_replay_if_overflowed() {
+    const size_t nstate = (size_t)nrep_ * 3 * natoms_;
+    for (int attempt = 0;; attempt++) {
+        int st = 0;
+        HIP_TRY(hipMemcpy(&st, dstatus_, sizeof st, hipMemcpyDeviceToHost));
+        if (!(st & 2)) return;
+        st &= ~2;
+        HIP_TRY(hipMemcpy(dstatus_, &st, sizeof st, hipMemcpyHostToDevice));
+        if (attempt >= 6 || cell_per_site_ > 8192) throw std::string("cell-list path: neighbour rows keep overflowing during dynamics (more than 8192 partners per site)");
+        std::vector<PendingStep> pend;
+        pend.swap(cell_pending_);
+        HIP_TRY(hipMemcpy(pos_, cell_snap_pos_, nstate * sizeof(real), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(vel_, cell_snap_vel_, nstate * sizeof(real), hipMemcpyDeviceToDevice));
+        cell_per_site_ *= 2;
+        cell_alloc_lists();   // marks the rows stale: the first replayed launch sizes and rebuilds them from the snapshot
+        if (getenv("AWSEM_VERBOSE")) fprintf(stderr, "[awsem] neighbour row overflow during dynamics: rows regrown to %d per contact site, replaying %zu launch(es)\n", cell_per_site_, pend.size());
+        cell_replaying_ = true;
+        try {
+            for (const PendingStep& p : pend) cell_step(p.nsteps, p.T.data(), p.dt, p.friction, p.seed, p.step0);
+        } catch (...) { cell_replaying_ = false; throw; }
+        cell_replaying_ = false;
+        HIP_TRY(hipStreamSynchronize(stream_));
+        record_ring_ms();
+    }
+}
 template <class real> void Engine<real>::cell_step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) {
     HIP_TRY(hipSetDevice(device_));
     if (!cell_step_base_) cell_step_base_ = dalloc<long long>(1);
+    if (npend_ == NRING) synchronize();   // here, not inside begin_async below: this launch must not be on the pending list while older ones are resolved
     if (cell_stale_) {
-        // first launch after the coordinates were set: build the rows now and leave head room, because a row that
-        // overflows in the middle of a trajectory cannot be repaired (the rows are sized to twice the fullest one)
+        // first launch after the coordinates were set: build the rows now and leave head room (twice the fullest row), so that
+        // the replay a later overflow costs (cell_replay_if_overflowed) stays a rare event
         synchronize();
         for (int attempt = 0;; attempt++) {
             cell_pre(false);
@@ -1422,14 +1464,29 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
             };
             for (int t = 0; t < dsys_.n_beta && !(st & 2); t++) hb_fullest(cell_hb_beta_[t], dsys_.beta[t].nacc);
             for (int t = 0; t < dsys_.n_pap && !(st & 2); t++) hb_fullest(cell_hb_pap_[t], dsys_.pap[t].nacc);
-            if (!(st & 2) && 2 * fullest <= cell_.bin[0].stride) break;
+            // AWSEM_CELL_HEADROOM (tests only): rows sized to that multiple of the fullest row; below 1 the rows are deliberately
+            // left SHORTER than the start structure needs, so that the first rebuild of the run overflows and is replayed
+            const double hr_env = getenv("AWSEM_CELL_HEADROOM") ? atof(getenv("AWSEM_CELL_HEADROOM")) : 2.0;
+            const double headroom = std::max(1.0, hr_env);
+            if (getenv("AWSEM_VERBOSE")) fprintf(stderr, "[awsem] sizing the neighbour rows: %d reserved per contact site (stride %d), fullest row %d%s\n", cell_per_site_, cell_.bin[0].stride, fullest, (st & 2) ? ", overflowed" : "");
+            if (!(st & 2) && (int)std::ceil(headroom * fullest) <= cell_.bin[0].stride) {
+                if (hr_env > 0.0 && hr_env < 1.0 && !cell_replaying_) { cell_per_site_ = std::max(16, (int)std::ceil(hr_env * fullest)); cell_alloc_lists(); }
+                break;
+            }
             HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
             if (attempt >= 6) throw std::string("cell-list path: neighbour rows keep overflowing");
-            cell_per_site_ = std::max(2 * cell_per_site_ * ((st & 2) ? 1 : 0), 2 * fullest);
+            cell_per_site_ = std::max(2 * cell_per_site_ * ((st & 2) ? 1 : 0), (int)std::ceil(headroom * fullest));
             cell_alloc_lists();
         }
         cell_stale_ = true;   // the step sequence below rebuilds once more through the ordinary path (virtual sites placed first)
     }
+    if (cell_pending_.empty() && !cell_replaying_) {   // first launch since the last synchronisation: the state a replay would start from
+        const size_t nstate = (size_t)nrep_ * 3 * natoms_;
+        if (!cell_snap_pos_) { cell_snap_pos_ = dalloc<real>(nstate); cell_snap_vel_ = dalloc<real>(nstate); }
+        HIP_TRY(hipMemcpyAsync(cell_snap_pos_, pos_, nstate * sizeof(real), hipMemcpyDeviceToDevice, stream_));
+        HIP_TRY(hipMemcpyAsync(cell_snap_vel_, vel_, nstate * sizeof(real), hipMemcpyDeviceToDevice, stream_));
+    }
+    cell_pending_.push_back(PendingStep{nsteps, std::vector<double>(T, T + nrep_), dt, friction, seed, step0});
     begin_async(T);
     static const bool use_graph = !(getenv("AWSEM_CELL_GRAPH") && atoi(getenv("AWSEM_CELL_GRAPH")) == 0);
     HIP_TRY(hipMemsetAsync(cell_.f, 0, (size_t)nrep_ * 3 * natoms_ * sizeof(u64), stream_));

@@ -28,7 +28,7 @@
 typedef struct { int group, n; int *pairs; double *r0, *k; } harm_t;
 typedef struct { int group, n; int *atoms; double k, chi0; } chi_t;
 typedef struct { int group, n, nwell; int *atoms; double *wp, *bw; double k; } rama_t;
-typedef struct { int group, nsites, nexcl; int *atom, *cls, *excl; double k, r0; } excl_t;
+typedef struct { int group, nsites, nexcl; int *atom, *cls, *excl; double k, r0; uint64_t* keys; /* sorted (min << 32 | max) of the excluded pairs */ } excl_t;
 typedef struct {
     int group, nsites, env, min_seq_sep, flags, has_burial;
     int *atom, *restype, *resid, *chain;
@@ -123,7 +123,7 @@ static void free_term(term_t* t) {
     case T_HARM: { harm_t* x = p; free(x->pairs); free(x->r0); free(x->k); } break;
     case T_CHI: { chi_t* x = p; free(x->atoms); } break;
     case T_RAMA: { rama_t* x = p; free(x->atoms); free(x->wp); free(x->bw); } break;
-    case T_EXCL: { excl_t* x = p; free(x->atom); free(x->cls); free(x->excl); } break;
+    case T_EXCL: { excl_t* x = p; free(x->atom); free(x->cls); free(x->excl); free(x->keys); } break;
     case T_CONTACT: { contact_t* x = p; free(x->atom); free(x->restype); free(x->resid); free(x->chain); free(x->gamma_idx); free(x->bgamma_idx); } break;
     case T_BETA: { beta_t* x = p; if (x->fn) { free(x->fn->info); free(x->fn); } free(x->acc_atoms); free(x->acc_res); free(x->don_atoms); free(x->don_res); free(x->lambda); } break;
     case T_PAP: { pap_t* x = p; if (x->fn) { free(x->fn->info); free(x->fn); } free(x->acc_atoms); free(x->acc_res); free(x->don_atoms); free(x->don_res); free(x->gamma); } break;
@@ -186,12 +186,23 @@ int awsem_oracle_add_rama(ctx_t* c, int group, int n, const int* atoms, int nwel
     for (int i = 0; i < n * nwell; i++) t->bw[i] = bw ? bw[i] : 1.0;
     return add_term(c, T_RAMA, t);
 }
+/* createExclusionsFromBonds(oa.bonds, 1) (basicTerms.py:189): is the atom pair (a, b) one of the excluded ones?  Binary search in
+ * the sorted pair keys (a linear scan per candidate pair is fine for a protein, not for the 20 000-residue system). */
+static uint64_t pair_key(int a, int b) { return a < b ? ((uint64_t)a << 32 | (uint32_t)b) : ((uint64_t)b << 32 | (uint32_t)a); }
+static int cmp_u64(const void* x, const void* y) { uint64_t a = *(const uint64_t*)x, b = *(const uint64_t*)y; return a < b ? -1 : a > b; }
+static int is_excluded(const uint64_t* keys, int n, int a, int b) {
+    uint64_t k = pair_key(a, b);
+    return bsearch(&k, keys, n, sizeof(uint64_t), cmp_u64) != NULL;
+}
 int awsem_oracle_add_excl(ctx_t* c, int group, int nsites, const int* atom, const int* cls, int nexcl, const int* excl, double k, double r0) {
     CHECK_BUILD(c, group);
     if (nsites < 0 || nexcl < 0 || (nsites && (!atom || !cls)) || (nexcl && !excl) || !check_atoms(c, atom, nsites, 0) || !check_atoms(c, excl, 2 * nexcl, 0))
         return fail(-1, "add_excl: bad arguments");
     excl_t* t = calloc(1, sizeof *t); t->group = group; t->nsites = nsites; t->nexcl = nexcl; t->k = k; t->r0 = r0;
     t->atom = dup_mem(atom, nsites * sizeof(int)); t->cls = dup_mem(cls, nsites * sizeof(int)); t->excl = dup_mem(excl, 2 * nexcl * sizeof(int));
+    t->keys = malloc((nexcl ? nexcl : 1) * sizeof(uint64_t));
+    for (int q = 0; q < nexcl; q++) t->keys[q] = pair_key(excl[2 * q], excl[2 * q + 1]);
+    qsort(t->keys, nexcl, sizeof(uint64_t), cmp_u64);
     return add_term(c, T_EXCL, t);
 }
 int awsem_oracle_add_contact(ctx_t* c, int group, int nsites, const int* atom, const int* restype, const int* resid, const int* chain,
@@ -572,12 +583,7 @@ static double eval_excl(const excl_t* t, const double* x, double* f) {
         if (a == b) continue;
         double r = dist(x, a, b, d);
         if (r >= t->r0) continue;
-        int ex = 0;
-        for (int q = 0; q < t->nexcl; q++) {
-            int p0 = t->excl[2 * q], p1 = t->excl[2 * q + 1];
-            if ((p0 == a && p1 == b) || (p0 == b && p1 == a)) { ex = 1; break; }
-        }
-        if (ex) continue;
+        if (is_excluded(t->keys, t->nexcl, a, b)) continue;
         e += t->k * (r - t->r0) * (r - t->r0);
         pair_force(f, a, b, d, r, 2 * t->k * (r - t->r0));
     }
@@ -1065,19 +1071,23 @@ int awsem_oracle_neighbors(ctx_t* c, int rep, int kind, int index, double skin, 
     const double* x = c->pos + (size_t)rep * c->natoms * 3;
     int n = 0, cap = 1024;
     int* out = malloc(sizeof(int) * 2 * cap);
-#define PUSH(p, q) do { if (n == cap) { cap *= 2; out = realloc(out, sizeof(int) * 2 * cap); } out[2 * n] = (p); out[2 * n + 1] = (q); n++; } while (0)
+    /* the scans run on c->nthreads threads (set_threads); hits are rare next to tests, so they are appended under a lock and the
+     * result is sorted afterwards */
+#define PUSH(p, q) do { _Pragma("omp critical(awsem_push)") { if (n == cap) { cap *= 2; out = realloc(out, sizeof(int) * 2 * cap); } out[2 * n] = (p); out[2 * n + 1] = (q); n++; } } while (0)
+#define SCAN _Pragma("omp parallel for schedule(dynamic, 8) num_threads(c->nthreads)")
     if (kind == 0) {
         const excl_t* t = term;
+        SCAN
         for (int i = 0; i < t->nsites; i++) for (int j = i + 1; j < t->nsites; j++) {
             if (t->cls[i] != t->cls[j]) continue;
-            int a = t->atom[i], b = t->atom[j], ex = 0;
+            int a = t->atom[i], b = t->atom[j];
             if (a == b || !below(c, x, a, b, t->r0 + skin)) continue;
-            for (int q = 0; q < t->nexcl && !ex; q++) ex = (t->excl[2 * q] == a && t->excl[2 * q + 1] == b) || (t->excl[2 * q] == b && t->excl[2 * q + 1] == a);
-            if (!ex) PUSH(a < b ? a : b, a < b ? b : a);
+            if (!is_excluded(t->keys, t->nexcl, a, b)) PUSH(a < b ? a : b, a < b ? b : a);
         }
     } else if (kind == 1) {
         const contact_t* t = term;
         const double cutoff = (t->flags & 4) ? 1e15 : t->p[8];
+        SCAN
         for (int i = 0; i < t->nsites; i++) for (int j = i + 1; j < t->nsites; j++)
         {
             int dres = abs(t->resid[i] - t->resid[j]);
@@ -1091,14 +1101,17 @@ int awsem_oracle_neighbors(ctx_t* c, int rep, int kind, int index, double skin, 
             double rs = t->r_ON + sqrt(60.0) * t->s_NO, s2 = t->cutoff * t->cutoff < rs * rs ? t->cutoff * t->cutoff : rs * rs;
             base = sqrt((double)(float)s2);
         } else base = sqrt(t->cutoff * t->cutoff);
+        SCAN
         for (int a = 0; a < t->nacc; a++) for (int q = 0; q < t->ndon; q++)
             if (beta_lambda(t, t->don_res[q], t->acc_res[a]) != 0.0 && below(c, x, t->acc_atoms[3 * a], t->don_atoms[3 * q], base + skin)) PUSH(a, q);
     } else {
         const pap_t* t = term;
+        SCAN
         for (int a = 0; a < t->nacc; a++) for (int q = 0; q < t->ndon; q++)
             if (pap_gamma(t, t->don_res[q], t->acc_res[a]) != 0.0 && below(c, x, t->acc_atoms[2 * a], t->don_atoms[2 * q], t->cutoff + skin)) PUSH(a, q);
     }
 #undef PUSH
+#undef SCAN
     qsort(out, n, 2 * sizeof(int), cmp_pair);
     for (int k = 0; k < n && k < capacity; k++) { pairs[2 * k] = out[2 * k]; pairs[2 * k + 1] = out[2 * k + 1]; }
     free(out);

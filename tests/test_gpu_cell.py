@@ -202,3 +202,77 @@ def test_cell_path_minimiser_follows_the_resident_one(monkeypatch):
     e0 = ctx.energy()
     it, rms = ctx.minimize(10.0, 5000)
     assert np.all(rms <= 10.0) and np.all(ctx.energy() < e0), (it, rms)
+
+
+def test_row_overflow_during_dynamics_is_replayed_not_fatal(monkeypatch, capfd):
+    """Neighbour rows that are too short for the structure (here: deliberately sized to 40 % of what the start structure needs, the
+    stand-in for a chain that compacts during annealing) overflow at a rebuild inside an asynchronous launch.  The launches since
+    the last synchronisation are then replayed from a snapshot with longer rows.  The random stream is counter
+    based and every sum is fixed point, so the replayed trajectory must be BIT-IDENTICAL to a run whose rows were long enough
+    from the start -- in production precision -- and an energy query after asynchronous steps must trigger the repair instead of
+    swallowing the overflow."""
+    oa, traj, _ = golden_system("1ubq")
+    system = _full_system(oa)
+    x0 = traj[5]
+    T = np.array([300.0, 400.0])
+    out = {}
+    for rows in ("roomy", "tight"):
+        monkeypatch.setenv("AWSEM_VERBOSE", "1")
+        monkeypatch.setenv("AWSEM_CELL_NEIGHBORS", "512" if rows == "roomy" else "16")
+        monkeypatch.setenv("AWSEM_CELL_HEADROOM", "2.0" if rows == "roomy" else "0.4")
+        ctx = _ctx(system, 2, 0, True, monkeypatch)
+        ctx.set_positions(x0, replica=-1)
+        ctx.compute_virtual_sites()
+        ctx.set_velocities_to_temperature(T, 4)
+        for chunk in (40, 40, 120):          # asynchronous launches, resolved by the energy query
+            ctx.step(chunk, T, 0.002, 1.0, 21)
+        e = ctx.energy()
+        ctx.step(100, T, 0.002, 1.0, 21)
+        ctx.synchronize()
+        out[rows] = (ctx.get_state(), e, capfd.readouterr().err)
+        ctx.close()
+    assert "rows regrown" not in out["roomy"][2]
+    assert "rows regrown" in out["tight"][2] and "replaying" in out["tight"][2], out["tight"][2]
+    (xa, va), (xb, vb) = out["roomy"][0], out["tight"][0]
+    assert np.isfinite(xa).all() and np.abs(xa[0] - x0).max() > 0.05
+    assert np.array_equal(xa, xb) and np.array_equal(va, vb)
+    assert np.array_equal(out["roomy"][1], out["tight"][1])
+
+
+def test_full_size_synthetic_system_rows_energies_forces_and_dynamics():
+    """BASELINE.json configs[4] at its full size: 122 x 2lzm = 20 008 residues, 117 974 atoms, con/chain/chi/excl/rama/contact+burial.
+    Rows of both binnings against the oracle's brute-force O(N^2) scan (2e8 and 9e8 pair tests, 8 threads), energies and forces
+    against the oracle, then 200 steps that take the system through at least one list rebuild."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        oa = workloads.build_synthetic()
+    assert oa.nres == 20008
+    gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, 1, precision=0)
+    oa.system.upload(gpu)
+    cpu = _capi.Context(awsem_oracle.load(), oa.natoms, 1, precision=0)
+    oa.system.upload(cpu)
+    cpu._call("set_threads", 8)
+    for ctx in (gpu, cpu):
+        ctx.set_positions(oa.pdb.positions)
+    for kind in (_capi.LIST_EXCL, _capi.LIST_CONTACT):
+        a, b = gpu.neighbors(kind, 0, 0, 0.15, capacity=1 << 19), cpu.neighbors(kind, 0, 0, 0.15, capacity=1 << 19)
+        assert len(b) > 50000 and np.array_equal(a, b)
+    eg, ec = gpu.energy_by_group(), cpu.energy_by_group()
+    assert np.abs(ec[0, 20:23]).min() > 1e4
+    assert (np.abs(eg - ec) / np.maximum(np.abs(ec), 1.0)).max() <= 1e-4
+    fg, fc = gpu.forces(), cpu.forces()
+    assert np.linalg.norm(fg - fc) <= 1e-3 * np.linalg.norm(fc)
+    assert np.abs(fg - fc).max() <= 1e-3 * np.abs(fc).max()
+    # dynamics through a rebuild: at 600 K a CA moves half the default skin (0.1 nm) within ~100 steps
+    gpu.set_velocities_to_temperature([600.0], 1)
+    x0 = gpu.get_positions(0)
+    gpu.step(200, [600.0], 0.002, 1.0, 1)
+    gpu.synchronize()
+    x1 = gpu.get_positions(0)
+    moved = np.linalg.norm((x1 - x0)[np.array(oa.ca)], axis=1).max()
+    assert moved > 0.12, moved               # further than skin / 2: the lists were rebuilt on the device
+    e2 = gpu.energy_by_group()
+    assert np.isfinite(e2).all() and np.isfinite(x1).all() and not np.array_equal(e2, eg)
+    # the rows after the run still equal the brute force on the new coordinates
+    cpu.set_positions(x1)
+    a, b = gpu.neighbors(_capi.LIST_CONTACT, 0, 0, 0.15, capacity=1 << 19), cpu.neighbors(_capi.LIST_CONTACT, 0, 0, 0.15, capacity=1 << 19)
+    assert np.array_equal(a, b)
