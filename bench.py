@@ -172,13 +172,20 @@ def main():
     ctx.set_velocities_to_temperature(np.full(R, Tstart), seed)
 
     def stage_T(i):
-        if remd is not None:
-            return remd.local_temperatures()
         return np.full(R, Tstart + (Tend - Tstart) / stages * (i % stages))
 
-    def after_launch():
-        if remd is not None:   # one exchange sweep: energies -> all-gather -> Metropolis on every rank -> labels, velocity rescale
-            ctx.scale_velocities(remd.exchange(ctx.energy()))
+    if remd is not None:   # the ladder assignment, temperatures and velocity factors live on the device from here on
+        ctx.set_velocities_to_temperature(remd.local_temperatures(), seed)
+        remd.attach(ctx)
+
+    def launch(it):
+        if remd is not None:
+            # MD at the current ladder assignment, then one exchange sweep: energies into a device buffer -> (all-gather over RCCL
+            # when the ladder spans ranks) -> sweep kernel -> temperatures and velocity factors, nothing through the host
+            ctx.step_remd(args.md_steps, 0.002, 1.0, seed)
+            remd.exchange_on_device()
+        else:
+            ctx.step(args.md_steps, stage_T(it), 0.002, 1.0, seed)   # asynchronous: the launches queue up back to back
 
     def barrier():
         ctx.synchronize()
@@ -196,22 +203,17 @@ def main():
         stage_T = lambda i: np.full(R, 300.0)   # noqa: E731
     it = 0
     for _ in range(args.warmup):
-        ctx.step(args.md_steps, stage_T(it), 0.002, 1.0, seed)
-        after_launch()
+        launch(it)
         it += 1
     barrier()
     kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.step(args.md_steps, stage_T(it), 0.002, 1.0, seed)   # asynchronous: the launches queue up back to back
-        if remd is not None:
-            kernel_ms.append(ctx.last_kernel_ms())
-        after_launch()
+        launch(it)
         it += 1
     barrier()
     elapsed = time.perf_counter() - t0
-    if remd is None:
-        kernel_ms.append(ctx.last_kernel_ms())     # mean over the timed launches: HIP events on the engine's stream around each
+    kernel_ms.append(ctx.last_kernel_ms())     # mean over the timed launches: HIP events on the engine's stream around each
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -300,7 +302,12 @@ def main():
             if vc is not None:
                 out["roofline"]["valu_compact_300K"] = vc
         if remd is not None:
+            remd.pull()
             out["config"]["remd_acceptance"] = [round(float(a), 3) for a in remd.acceptance()[:8]]
+            # what one exchange costs on top of the MD launch it follows: wall time per iteration minus the step kernel's own time
+            out["remd_exchange_us"] = (elapsed / args.steps - k_ms * 1e-3) * 1e6
+            out["config"]["remd_exchange"] = ("per iteration: energy kernel + group sum into a device buffer, "
+                                              + ("one all_gather_into_tensor over RCCL, " if world > 1 else "") + "sweep kernel (Metropolis, ladder index swap), velocity rescale; no host copy")
         if not args.no_cpu_baseline and world == 1 and args.workload == "1r69":
             out["cpu_baseline"] = cpu_baseline(oa, args.md_steps)
         print(json.dumps(out), flush=True)

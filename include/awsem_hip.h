@@ -286,6 +286,33 @@ int awsem_minimize(awsem_handle h, double tolerance_kj_mol_nm, int max_iteration
 int awsem_last_kernel_ms(awsem_handle h, double* ms);
 int awsem_synchronize(awsem_handle h);
 
+/* ---- temperature replica exchange without host hops ------------------------------------------------------------------
+ * The reference hands replica exchange to openmmtools' ReplicaExchangeSampler in ONE process (scripts/mm_remd.py:85-149: a
+ * temperature ladder, `exchange_frequency` Langevin steps, a sweep of neighbour swaps).  Here the ladder is spread over ranks
+ * (one handle per GPU holds `n_replicas` consecutive replicas of the `n_total`); an exchange is: every rank leaves the
+ * potential energies of its replicas in device memory, ONE all-gather (RCCL) assembles all n_total of them on every rank,
+ * every rank runs the same sweep kernel on them and arrives at the same ladder assignment; temperatures, velocity factors
+ * sqrt(T_new/T_old) and the bookkeeping stay on the device.  Nothing crosses PCIe per exchange.
+ *   awsem_remd_setup     ladder_T[n_total] (K); gather_index[n_total] = where replica r sits in the gathered energy buffer (NULL:
+ *                        r itself); local_start = global index of this handle's replica 0.  Replica r starts at ladder_T[r].
+ *   awsem_step_remd      awsem_step with the temperatures the ladder assignment on the device currently gives the local replicas
+ *   awsem_remd_energies  potential energy (masked groups) of the local replicas -> d_energy[n_replicas] (a DEVICE pointer; NULL =
+ *                        the handle's own n_total buffer at local_start, enough when one rank holds the whole ladder)
+ *   awsem_remd_sweep     one sweep on d_all[.] (DEVICE pointer to the gathered energies; NULL = the handle's own buffer): pairs
+ *                        (i, i+1) with i of the parity of `iteration`, accepted when delta = (beta_i - beta_i+1)(U_a - U_b) >= 0
+ *                        or u < exp(delta), u = Philox4x32-10(counter (i, iteration, 'REMD'), key seed) -- the stream
+ *                        openawsem_amd/ensemble.py:counter_uniform reproduces on the host; then rescales the local velocities
+ *   awsem_remd_state     copies out the ladder index of every replica, attempt / acceptance counts per neighbouring pair and
+ *                        the local temperatures (any pointer may be NULL); the only call here that waits for the device
+ * awsem_remd_energies and awsem_remd_sweep are asynchronous on the handle's stream; a caller that gathers with another
+ * runtime's stream (torch.distributed) calls awsem_synchronize before the gather and waits for the gather before the sweep. */
+int awsem_remd_setup(awsem_handle h, int n_total, const double* ladder_T, const int32_t* gather_index, int local_start,
+                     uint64_t seed);
+int awsem_step_remd(awsem_handle h, int nsteps, double dt_ps, double friction_per_ps, uint64_t seed);
+int awsem_remd_energies(awsem_handle h, uint32_t group_mask, double* d_energy);
+int awsem_remd_sweep(awsem_handle h, const double* d_all_energies, int64_t iteration);
+int awsem_remd_state(awsem_handle h, int32_t* ladder_index, int64_t* attempted, int64_t* accepted, double* T_local);
+
 /* ---- allocation-free evaluation ---------------------------------------------------------------------------
  * NO COUNTERPART IN THE REFERENCE.  A variant of awsem_energy_by_group for callers that cannot allocate device
  * memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It runs the same

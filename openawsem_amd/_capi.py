@@ -73,6 +73,13 @@ _SIGNATURES = {
 # entry points that exist only in libawsem_hip.so (declared in include/awsem_hip.h, no oracle counterpart)
 _HIP_ONLY = {
     "energy_by_group_noalloc": (C.c_int, ["H", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    # replica exchange with the bookkeeping on the device: about device pointers, nothing for the CPU oracle to mirror (its
+    # checker is the host-side sweep of openawsem_amd/ensemble.py)
+    "remd_setup": (C.c_int, ["H", C.c_int, c_dbl_p, c_int_p, C.c_int, C.c_uint64]),
+    "step_remd": (C.c_int, ["H", C.c_int, C.c_double, C.c_double, C.c_uint64]),
+    "remd_energies": (C.c_int, ["H", C.c_uint32, C.c_void_p]),
+    "remd_sweep": (C.c_int, ["H", C.c_void_p, C.c_int64]),
+    "remd_state": (C.c_int, ["H", c_int_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_dbl_p]),
 }
 
 EXPORTED_SYMBOLS = tuple("awsem_" + n for n in list(_SIGNATURES) + list(_HIP_ONLY))
@@ -381,6 +388,32 @@ class Context:
         None = the null stream); allocates nothing -- see include/awsem_hip.h."""
         self.api.check(self.api.fn["energy_by_group_noalloc"](self.h, int(n_replicas), C.c_void_p(int(d_xyz)), C.c_void_p(int(d_energy)),
                                                               C.c_void_p(int(stream)) if stream else None))
+
+    # ---- replica exchange on the device (include/awsem_hip.h: awsem_remd_*)
+    def remd_setup(self, ladder_T, local_start=0, gather_index=None, seed=2026):
+        T = _f64(ladder_T)
+        gi = None if gather_index is None else _i32(gather_index)
+        self._remd_n = len(T)
+        self._call("remd_setup", len(T), _dp(T), None if gi is None else _ip(gi), int(local_start), C.c_uint64(int(seed)))
+
+    def step_remd(self, nsteps, dt_ps, friction_per_ps, seed):
+        self._call("step_remd", int(nsteps), float(dt_ps), float(friction_per_ps), C.c_uint64(int(seed)))
+
+    def remd_energies(self, group_mask=0xFFFFFFFF, d_energy=None):
+        self._call("remd_energies", C.c_uint32(group_mask & 0xFFFFFFFF), C.c_void_p(int(d_energy)) if d_energy else None)
+
+    def remd_sweep(self, iteration, d_all_energies=None):
+        self._call("remd_sweep", C.c_void_p(int(d_all_energies)) if d_all_energies else None, C.c_int64(int(iteration)))
+
+    def remd_state(self):
+        """(ladder index of every replica, attempted, accepted per neighbouring pair, temperatures of the local replicas)."""
+        n = self._remd_n
+        slot = np.zeros(n, dtype=np.int32)
+        att, acc = np.zeros(max(n - 1, 0), dtype=np.int64), np.zeros(max(n - 1, 0), dtype=np.int64)
+        T = np.zeros(self.n_replicas)
+        p64 = C.POINTER(C.c_int64)
+        self._call("remd_state", _ip(slot), att.ctypes.data_as(p64), acc.ctypes.data_as(p64), _dp(T))
+        return slot, att, acc, T
 
     def last_kernel_ms(self):
         ms = C.c_double()

@@ -103,6 +103,11 @@ struct EngineBase {
     virtual void minimize(double tolerance, int max_iterations, int32_t* iterations, double* rms) = 0;
     virtual int neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) = 0;
     virtual void energy_noalloc(int nrep, const double* d_xyz, double* d_energy, hipStream_t stream) = 0;
+    virtual void remd_setup(int n_total, const double* ladder, const int32_t* where, int local_start, uint64_t seed) = 0;
+    virtual void step_remd(int nsteps, double dt, double friction, uint64_t seed, int64_t step0) = 0;
+    virtual void remd_energies(unsigned mask, double* d_energy) = 0;
+    virtual void remd_sweep(const double* d_all, int64_t iteration) = 0;
+    virtual void remd_state(int32_t* slot, int64_t* attempted, int64_t* accepted, double* T_local) = 0;
     double last_ms = 0.0;
 };
 
@@ -192,7 +197,74 @@ public:
         record_ms();
         check_status();
     }
-    void step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) override {
+    // ---- replica exchange on the device (include/awsem_hip.h: awsem_remd_*)
+    void remd_setup(int n_total, const double* ladder, const int32_t* where, int local_start, uint64_t seed) override {
+        HIP_TRY(hipSetDevice(device_));
+        synchronize();
+        if (n_total < nrep_ || local_start < 0 || local_start + nrep_ > n_total) throw std::string("remd_setup: the local replicas must be a block of the ladder");
+        if (n_total > 8192) throw std::string("remd_setup: at most 8192 replicas in one ladder");
+        remd_n_ = n_total; remd_start_ = local_start; remd_seed_ = seed;
+        std::vector<int> slot(n_total), wh(n_total);
+        double tmax = 0;
+        for (int r = 0; r < n_total; r++) {
+            slot[r] = r; wh[r] = where ? where[r] : r; tmax = std::max(tmax, ladder[r]);
+            if (wh[r] < 0) throw std::string("remd_setup: negative gather index");
+            if (!(ladder[r] > 0)) throw std::string("remd_setup: temperatures must be positive");
+        }
+        remd_tmax_ = tmax;
+        remd_ladder_ = upload(std::vector<double>(ladder, ladder + n_total));
+        remd_slot_ = const_cast<int*>(upload(slot));
+        remd_where_ = upload(wh);
+        remd_counts_ = dalloc<unsigned long long>(2 * (size_t)std::max(1, n_total - 1));
+        HIP_TRY(hipMemset(remd_counts_, 0, 2 * (size_t)std::max(1, n_total - 1) * sizeof(unsigned long long)));
+        remd_U_ = dalloc<double>(n_total);
+        HIP_TRY(hipMemset(remd_U_, 0, n_total * sizeof(double)));
+        remd_scale_ = dalloc<double>(nrep_);
+        HIP_TRY(hipMemcpy(dT_, ladder + local_start, sizeof(double) * nrep_, hipMemcpyHostToDevice));   // replica r starts at ladder[r]
+    }
+    void need_remd() const { if (!remd_n_) throw StateError{"replica exchange: call awsem_remd_setup first"}; }
+    void step_remd(int nsteps, double dt, double friction, uint64_t seed, int64_t step0) override {
+        need_remd();
+        step_impl(nsteps, nullptr, dt, friction, seed, step0);
+    }
+    void remd_energies(unsigned mask, double* d_energy) override {
+        need_remd();
+        HIP_TRY(hipSetDevice(device_));
+        double* out = d_energy ? d_energy : remd_U_ + remd_start_;
+        if (cell_mode_) {   // the cell-list evaluation is a host-driven sequence with its own retries: one upload of n_replicas doubles
+            std::vector<double> eg((size_t)nrep_ * AWSEM_NGROUPS), e(nrep_, 0.0);
+            cell_evaluate(true, mask, 0, eg.data(), nullptr);
+            for (int r = 0; r < nrep_; r++) for (int g = 0; g < AWSEM_NGROUPS; g++) if ((mask >> g) & 1u) e[r] += eg[(size_t)r * AWSEM_NGROUPS + g];
+            HIP_TRY(hipMemcpy(out, e.data(), sizeof(double) * nrep_, hipMemcpyHostToDevice));
+            return;
+        }
+        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, dsys_, pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr);
+        hipLaunchKernelGGL(awsem_group_sum_kernel, dim3((nrep_ + 255) / 256), dim3(256), 0, stream_, (const double*)dE_, mask, out, nrep_);
+        HIP_TRY(hipGetLastError());
+    }
+    void remd_sweep(const double* d_all, int64_t iteration) override {
+        need_remd();
+        HIP_TRY(hipSetDevice(device_));
+        const int N = remd_n_;
+        hipLaunchKernelGGL(awsem_remd_sweep_kernel, dim3(1), dim3(256), 2 * (size_t)N * sizeof(int), stream_, d_all ? d_all : (const double*)remd_U_, remd_where_,
+                           remd_ladder_, remd_slot_, remd_counts_, remd_counts_ + std::max(1, N - 1), N, (long long)iteration, (unsigned long long)remd_seed_,
+                           remd_start_, nrep_, dT_, remd_scale_);
+        hipLaunchKernelGGL(awsem_scale_velocities_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, vel_, (const double*)remd_scale_, 3 * natoms_);
+        HIP_TRY(hipGetLastError());
+    }
+    void remd_state(int32_t* slot, int64_t* attempted, int64_t* accepted, double* T_local) override {
+        need_remd();
+        HIP_TRY(hipSetDevice(device_));
+        synchronize();
+        const size_t np = (size_t)std::max(1, remd_n_ - 1);
+        if (slot) HIP_TRY(hipMemcpy(slot, remd_slot_, sizeof(int) * remd_n_, hipMemcpyDeviceToHost));
+        if (attempted && remd_n_ > 1) HIP_TRY(hipMemcpy(attempted, remd_counts_, sizeof(long long) * (remd_n_ - 1), hipMemcpyDeviceToHost));
+        if (accepted && remd_n_ > 1) HIP_TRY(hipMemcpy(accepted, remd_counts_ + np, sizeof(long long) * (remd_n_ - 1), hipMemcpyDeviceToHost));
+        if (T_local) HIP_TRY(hipMemcpy(T_local, dT_, sizeof(double) * nrep_, hipMemcpyDeviceToHost));
+    }
+    void step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) override { step_impl(nsteps, T, dt, friction, seed, step0); }
+    // T == nullptr: the temperatures already on the device (replica exchange) drive the launch
+    void step_impl(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) {
         if (cell_mode_) { cell_step(nsteps, T, dt, friction, seed, step0); return; }
         if (!step_ok_) {
             char msg[256];
@@ -203,7 +275,7 @@ public:
         HIP_TRY(hipSetDevice(device_));
         apply_skin(T);
         begin_async(T);
-        hipLaunchKernelGGL(awsem_step_kernel<real>, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, dT_, nsteps, dt, friction,
+        hipLaunchKernelGGL(awsem_step_kernel<real>, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, (const double*)dT_, nsteps, dt, friction,
                            (unsigned long long)seed, (long long)step0);
         HIP_TRY(hipGetLastError());
         end_async();   // asynchronous: resolved by synchronize() / last_kernel_ms
@@ -341,8 +413,10 @@ private:
         if (npend_ == NRING) synchronize();
         const int k = npend_;
         if (!ring0_[k]) { HIP_TRY(hipEventCreate(&ring0_[k])); HIP_TRY(hipEventCreate(&ring1_[k])); HIP_TRY(hipHostMalloc((void**)&ringT_[k], sizeof(double) * nrep_, hipHostMallocDefault)); }
-        memcpy(ringT_[k], T, sizeof(double) * nrep_);
-        HIP_TRY(hipMemcpyAsync(dT_, ringT_[k], sizeof(double) * nrep_, hipMemcpyHostToDevice, stream_));
+        if (T) {   // null: the temperatures are on the device already (replica exchange)
+            memcpy(ringT_[k], T, sizeof(double) * nrep_);
+            HIP_TRY(hipMemcpyAsync(dT_, ringT_[k], sizeof(double) * nrep_, hipMemcpyHostToDevice, stream_));
+        }
         HIP_TRY(hipEventRecord(ring0_[k], stream_));
     }
     void end_async() {
@@ -402,6 +476,15 @@ private:
     }
 
     int natoms_, nrep_, device_;
+    // replica exchange state (awsem_remd_setup); all of it lives on the device
+    int remd_n_ = 0, remd_start_ = 0;
+    uint64_t remd_seed_ = 0;
+    double remd_tmax_ = 0;
+    const double* remd_ladder_ = nullptr;
+    int* remd_slot_ = nullptr;
+    const int* remd_where_ = nullptr;
+    unsigned long long* remd_counts_ = nullptr;   // attempted[N-1], accepted[N-1]
+    double *remd_U_ = nullptr, *remd_scale_ = nullptr;
     int block_ = 256;
     size_t lds_eval_ = 0, lds_step_ = 0;
     hipStream_t stream_ = nullptr;
@@ -435,8 +518,8 @@ private:
     // replica of the launch; AWSEM_SKIN pins it.
     void apply_skin(const double* T) {
         if (cell_mode_ || skin_fixed_ || list_params_.empty()) return;
-        double tmax = 0;
-        for (int r = 0; r < nrep_; r++) tmax = std::max(tmax, T[r]);
+        double tmax = T ? 0 : remd_tmax_;   // null: a replica-exchange launch, any replica may hold the hottest rung
+        for (int r = 0; T && r < nrep_; r++) tmax = std::max(tmax, T[r]);
         static const double sa = getenv("AWSEM_SKIN_A") ? atof(getenv("AWSEM_SKIN_A")) : 0.028, sb = getenv("AWSEM_SKIN_B") ? atof(getenv("AWSEM_SKIN_B")) : 0.00024;   // tuning knobs
         const double skin = std::min(0.25, std::max(0.07, sa + sb * tmax));
         if (std::fabs(skin - skin_) < 2e-3) return;
@@ -1480,13 +1563,14 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
         }
         cell_stale_ = true;   // the step sequence below rebuilds once more through the ordinary path (virtual sites placed first)
     }
-    if (cell_pending_.empty() && !cell_replaying_) {   // first launch since the last synchronisation: the state a replay would start from
+    if (T && cell_pending_.empty() && !cell_replaying_) {   // first launch since the last synchronisation: the state a replay would start from
         const size_t nstate = (size_t)nrep_ * 3 * natoms_;
         if (!cell_snap_pos_) { cell_snap_pos_ = dalloc<real>(nstate); cell_snap_vel_ = dalloc<real>(nstate); }
         HIP_TRY(hipMemcpyAsync(cell_snap_pos_, pos_, nstate * sizeof(real), hipMemcpyDeviceToDevice, stream_));
         HIP_TRY(hipMemcpyAsync(cell_snap_vel_, vel_, nstate * sizeof(real), hipMemcpyDeviceToDevice, stream_));
     }
-    cell_pending_.push_back(PendingStep{nsteps, std::vector<double>(T, T + nrep_), dt, friction, seed, step0});
+    if (T) cell_pending_.push_back(PendingStep{nsteps, std::vector<double>(T, T + nrep_), dt, friction, seed, step0});
+    else cell_pending_.clear();   // device-resident temperatures (replica exchange): the sweeps in between are not recorded, so such a launch is not replayable
     begin_async(T);
     static const bool use_graph = !(getenv("AWSEM_CELL_GRAPH") && atoi(getenv("AWSEM_CELL_GRAPH")) == 0);
     HIP_TRY(hipMemsetAsync(cell_.f, 0, (size_t)nrep_ * 3 * natoms_ * sizeof(u64), stream_));
@@ -2038,6 +2122,33 @@ int awsem_last_kernel_ms(awsem_handle h, double* ms) {
 int awsem_synchronize(awsem_handle h) {
     NEED_RUN(h);
     GUARD_BEGIN h->eng->synchronize(); return AWSEM_OK; GUARD_END
+}
+int awsem_remd_setup(awsem_handle h, int n_total, const double* ladder_T, const int32_t* gather_index, int local_start, uint64_t seed) {
+    NEED_RUN(h);
+    if (n_total <= 0 || !ladder_T) return fail(AWSEM_EINVAL, "remd_setup: bad arguments");
+    GUARD_BEGIN h->eng->remd_setup(n_total, ladder_T, gather_index, local_start, seed); return AWSEM_OK; GUARD_END
+}
+int awsem_step_remd(awsem_handle h, int nsteps, double dt, double friction, uint64_t seed) {
+    NEED_RUN(h);
+    if (nsteps < 0 || !(dt > 0) || friction < 0) return fail(AWSEM_EINVAL, "step_remd: bad arguments");
+    GUARD_BEGIN
+    if (nsteps > 0) h->eng->step_remd(nsteps, dt, friction, seed, h->step);
+    h->step += nsteps;
+    return AWSEM_OK;
+    GUARD_END
+}
+int awsem_remd_energies(awsem_handle h, uint32_t mask, double* d_energy) {
+    NEED_RUN(h);
+    GUARD_BEGIN h->eng->remd_energies(mask, d_energy); return AWSEM_OK; GUARD_END
+}
+int awsem_remd_sweep(awsem_handle h, const double* d_all, int64_t iteration) {
+    NEED_RUN(h);
+    if (iteration < 0) return fail(AWSEM_EINVAL, "remd_sweep: negative iteration");
+    GUARD_BEGIN h->eng->remd_sweep(d_all, iteration); return AWSEM_OK; GUARD_END
+}
+int awsem_remd_state(awsem_handle h, int32_t* ladder_index, int64_t* attempted, int64_t* accepted, double* T_local) {
+    NEED_RUN(h);
+    GUARD_BEGIN h->eng->remd_state(ladder_index, attempted, accepted, T_local); return AWSEM_OK; GUARD_END
 }
 int awsem_energy_by_group_noalloc(awsem_handle h, int n_replicas, const double* d_xyz, double* d_energy, void* hip_stream) {
     NEED_RUN(h);

@@ -1362,6 +1362,53 @@ __global__ void awsem_scale_velocities_kernel(real* __restrict__ vel, const doub
     for (int i = threadIdx.x; i < n3; i += blockDim.x) v[i] *= s;
 }
 
+// ------------------------------------------------------------------ temperature replica exchange on the device
+// potential energy of every local replica for the masked groups, written where the caller wants it (awsem_remd_energies)
+__global__ void awsem_group_sum_kernel(const double* __restrict__ e_by_group /* [R][32] */, unsigned mask, double* __restrict__ out, int R) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    double s = 0;
+    for (int g = 0; g < AWSEM_NGROUPS; g++) if ((mask >> g) & 1u) s += e_by_group[(size_t)r * AWSEM_NGROUPS + g];
+    out[r] = s;
+}
+// U(0,1) with 53 random bits from the counter (pair, iteration) and the key `seed`: openawsem_amd/ensemble.py: counter_uniform
+// computes the same number on the host, so every rank -- and the host-side sweep the CPU tests run -- takes the same decisions
+#define AWSEM_STREAM_REMD 0x52454d44u
+__device__ __forceinline__ double remd_uniform(unsigned long long seed, long long iteration, int pair) {
+    unsigned c[4] = {(unsigned)pair, (unsigned)(unsigned long long)iteration, (unsigned)((unsigned long long)iteration >> 32), AWSEM_STREAM_REMD};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    return (double)((((unsigned long long)c[0] << 32) | c[1]) >> 11) * (1.0 / 9007199254740992.0);
+}
+// One sweep of neighbour swaps (scripts/mm_remd.py:133-149 hands this to openmmtools' ReplicaExchangeSampler): pairs (i, i+1) of
+// the ladder with i of the iteration's parity; Metropolis on (beta_i - beta_{i+1})(U_a - U_b); accepted pairs swap their
+// LADDER INDEX (slot[replica]), coordinates never move.  One workgroup; every rank runs it on the same gathered energies and
+// arrives at the same slots.  Then, for the local replicas: new temperature and velocity factor sqrt(T_new / T_old).
+__global__ void awsem_remd_sweep_kernel(const double* __restrict__ U /* gathered energies */, const int* __restrict__ where /* [N] replica -> index in U */,
+                                        const double* __restrict__ ladder /* [N] K */, int* __restrict__ slot /* [N] replica -> ladder index */,
+                                        unsigned long long* __restrict__ attempted, unsigned long long* __restrict__ accepted /* [N-1] */, int N,
+                                        long long iteration, unsigned long long seed, int local_start, int nlocal,
+                                        double* __restrict__ T_local /* [nlocal] */, double* __restrict__ scale_local /* [nlocal] */) {
+    extern __shared__ int sh[];   // holder[N] (ladder index -> replica), old_slot[N]
+    int* holder = sh;
+    int* old = sh + N;
+    for (int r = threadIdx.x; r < N; r += blockDim.x) { const int s = slot[r]; old[r] = s; holder[s] = r; }
+    __syncthreads();
+    const int parity = (int)(iteration & 1);
+    for (int i = parity + 2 * (int)threadIdx.x; i < N - 1; i += 2 * blockDim.x) {   // disjoint pairs: one thread each
+        const int a = holder[i], b = holder[i + 1];   // a runs at T_i, b at T_{i+1}
+        const double delta = (1.0 / (AWSEM_KB * ladder[i]) - 1.0 / (AWSEM_KB * ladder[i + 1])) * (U[where[a]] - U[where[b]]);
+        attempted[i] += 1;
+        if (delta >= 0.0 || remd_uniform(seed, iteration, i) < ::exp(delta)) { slot[a] = i + 1; slot[b] = i; accepted[i] += 1; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nlocal; k += blockDim.x) {
+        const int r = local_start + k;
+        const double Tn = ladder[slot[r]], To = ladder[old[r]];
+        T_local[k] = Tn;
+        scale_local[k] = ::sqrt(Tn / To);
+    }
+}
+
 // kinetic energy of every replica: sum over the massive particles of 1/2 m v^2 (StateDataReporter's temperature column)
 template <class real>
 __global__ void awsem_kinetic_kernel(const DevSys<real> S, const real* __restrict__ vel, double* __restrict__ ke) {

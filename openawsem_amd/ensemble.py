@@ -23,27 +23,62 @@ def shard(n_total: int, world: int, rank: int):
     return range(start, start + base + (1 if rank < rem else 0))
 
 
-def counter_uniform(seed: int, *counters) -> float:
-    """Deterministic U(0,1) from (seed, counters): identical on every rank without communication."""
-    h = hashlib.blake2b(np.array([seed, *counters], dtype=np.int64).tobytes(), digest_size=8).digest()
-    return (int.from_bytes(h, "little") >> 11) * (1.0 / (1 << 53))
+_M32 = 0xFFFFFFFF
 
 
-def all_gather_energies(local: np.ndarray, world: int, device=None) -> np.ndarray:
-    """Concatenate per-rank energy vectors (equal or unequal length) in rank order."""
+def _philox4x32_10(c, k0, k1):
+    """Philox4x32-10 (Salmon et al. 2011): the counter-based generator of the engine's kernels (csrc/awsem_kernels.h)."""
+    c0, c1, c2, c3 = c
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & _M32, p1 & _M32, ((p0 >> 32) ^ c3 ^ k1) & _M32, p0 & _M32
+        k0, k1 = (k0 + 0x9E3779B9) & _M32, (k1 + 0xBB67AE85) & _M32
+    return c0, c1, c2, c3
+
+
+def counter_uniform(seed: int, iteration: int, pair: int) -> float:
+    """Deterministic U(0,1) of (seed, iteration, pair), 53 bits: identical on every rank without communication, and the number
+    awsem_remd_sweep_kernel draws on the device (counter (pair, iteration, 'REMD'), key seed)."""
+    seed, iteration = int(seed) & 0xFFFFFFFFFFFFFFFF, int(iteration) & 0xFFFFFFFFFFFFFFFF
+    c0, c1, _, _ = _philox4x32_10((int(pair) & _M32, iteration & _M32, iteration >> 32, 0x52454D44), seed & _M32, seed >> 32)
+    return (((c0 << 32) | c1) >> 11) * (1.0 / (1 << 53))
+
+
+class _Gather:
+    """One all-gather of per-replica doubles across ranks: shard sizes are static, so they are worked out once (no collective),
+    the buffers are allocated once, and an exchange is a single all_gather_into_tensor (RCCL on GPUs, gloo on CPU)."""
+
+    def __init__(self, n_total, world, rank, device=None):
+        import torch
+        self.world, self.rank = world, rank
+        self.shards = [shard(n_total, world, r) for r in range(world)]
+        self.m = max(len(s) for s in self.shards)                    # shards are padded to the longest one
+        self.local = torch.zeros(self.m, dtype=torch.float64, device=device)
+        self.all = torch.zeros(world * self.m, dtype=torch.float64, device=device)
+        # replica r sits at rank * m + (r - start(rank)) of the gathered buffer
+        self.index = np.concatenate([r * self.m + np.arange(len(s)) for r, s in enumerate(self.shards)]).astype(np.int32)
+
+    def gather(self):
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(self.all, self.local)
+        return self.all
+
+
+def all_gather_energies(local: np.ndarray, world: int, device=None, gather=None) -> np.ndarray:
+    """Per-rank energy vectors concatenated in rank order (host in, host out: the path of drivers that report every energy).
+    `gather`: a _Gather to reuse (its buffers are allocated once); built on the fly otherwise."""
     if world == 1:
         return np.asarray(local, dtype=np.float64)
     import torch
     import torch.distributed as dist
-    n = torch.tensor([len(local)], dtype=torch.int64, device=device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    m = int(max(int(s.item()) for s in sizes))
-    buf = torch.zeros(m, dtype=torch.float64, device=device)
-    buf[:len(local)] = torch.as_tensor(np.asarray(local, dtype=np.float64), device=device)
-    out = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
-    return np.concatenate([o[:int(s.item())].cpu().numpy() for o, s in zip(out, sizes)])
+    if gather is None:
+        total = torch.tensor([len(local)], dtype=torch.int64, device=device)
+        dist.all_reduce(total)
+        gather = _Gather(int(total.item()), world, dist.get_rank(), device)
+    mine = gather.shards[gather.rank]
+    assert len(local) == len(mine)
+    gather.local[:len(mine)] = torch.as_tensor(np.asarray(local, dtype=np.float64))
+    return gather.gather().cpu().numpy()[gather.index]
 
 
 class ReplicaExchange:
@@ -65,7 +100,9 @@ class ReplicaExchange:
     def exchange(self, local_energies):
         """One sweep of neighbour swaps (even pairs on even iterations, odd pairs on odd ones).  Returns the
         velocity scale factors sqrt(T_new/T_old) of the local replicas."""
-        U = all_gather_energies(np.asarray(local_energies, dtype=np.float64), self.world, self.device)
+        if self.world > 1 and getattr(self, "_gather", None) is None:
+            self._gather = _Gather(self.n, self.world, self.rank, self.device)      # static shard sizes: no collective, buffers allocated once
+        U = all_gather_energies(np.asarray(local_energies, dtype=np.float64), self.world, self.device, getattr(self, "_gather", None))
         assert len(U) == self.n
         self.last_energies = U             # every replica's potential energy at this exchange (replicated on every rank)
         beta = 1.0 / (KB * self.T)
@@ -84,6 +121,41 @@ class ReplicaExchange:
 
     def acceptance(self):
         return self.accepted / np.maximum(self.attempted, 1)
+
+    # ---- the same exchange with the bookkeeping on the device (include/awsem_hip.h: awsem_remd_*) -------------------------------
+    def attach(self, ctx):
+        """Hand the ladder to an engine handle (`openawsem_amd._capi.Context` holding this rank's block of replicas): from here on
+        the ladder assignment, temperatures and velocity factors live on the device.  With several ranks the gather buffers are
+        torch tensors allocated once; the engine writes its energies straight into them."""
+        assert ctx.n_replicas == len(self.local)
+        self._ctx = ctx
+        self._gather = _Gather(self.n, self.world, self.rank, self.device) if self.world > 1 else None
+        ctx.remd_setup(self.T, local_start=self.local.start, gather_index=None if self._gather is None else self._gather.index, seed=self.seed)
+
+    def exchange_on_device(self, group_mask=0xFFFFFFFF):
+        """One sweep without a host hop: energies -> device buffer -> (all-gather) -> sweep kernel -> temperatures and velocity
+        factors applied.  Single rank: three asynchronous launches on the engine's stream.  Several ranks: the engine's stream is
+        joined before the gather and torch's stream after it (the two sit in different HIP runtimes), nothing is copied."""
+        ctx = self._ctx
+        if self._gather is None:
+            ctx.remd_energies(group_mask)
+            ctx.remd_sweep(self.iteration)
+        else:
+            import torch
+            g = self._gather
+            ctx.remd_energies(group_mask, g.local.data_ptr())
+            ctx.synchronize()
+            g.gather()
+            if g.all.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            ctx.remd_sweep(self.iteration, g.all.data_ptr())
+        self.iteration += 1
+
+    def pull(self):
+        """Bring the bookkeeping back to the host (reporting / checkpoints): slot, attempted, accepted."""
+        slot, att, acc, _ = self._ctx.remd_state()
+        self.slot, self.attempted, self.accepted = slot.astype(np.int64), att, acc
+        return self
 
 
 def run_remd(context, remd: ReplicaExchange, n_iterations: int, steps_per_iteration: int, callback=None):

@@ -27,6 +27,16 @@ def test_shard_partitions_every_replica_exactly_once():
         assert seen == list(range(n))
 
 
+def test_counter_uniform_is_philox_4x32_10():
+    """Known-answer vectors of Random123's Philox4x32-10 (kat_vectors: all-zero and all-ones counter / key): the device kernel
+    (csrc/awsem_kernels.h) and the oracle share this generator, so the host-side sweep draws the numbers the device sweep draws."""
+    assert ensemble._philox4x32_10((0, 0, 0, 0), 0, 0) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    f = 0xffffffff
+    assert ensemble._philox4x32_10((f, f, f, f), f, f) == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+    c0, c1, _, _ = ensemble._philox4x32_10((4, 3, 0, 0x52454D44), 7, 0)
+    assert ensemble.counter_uniform(7, 3, 4) == (((c0 << 32) | c1) >> 11) / 2.0 ** 53
+
+
 def test_counter_uniform_is_deterministic_and_uniform():
     u = np.array([ensemble.counter_uniform(7, it, i) for it in range(200) for i in range(10)])
     assert np.all((u >= 0) & (u < 1))
@@ -85,8 +95,9 @@ for it in range(40):
     U_all = -400.0 + 0.5 * T[remd.slot] + 40.0 * np.sin(0.7 * np.arange(13) + it)
     s = remd.exchange(U_all[local.start:local.stop])
     slots.append(remd.slot.copy()); scales.append(s)
+g = remd._gather                            # one all_gather_into_tensor per exchange, sizes worked out without a collective
 np.savez(os.path.join({out!r}, f"rank{{rank}}.npz"), slots=np.array(slots), scales=np.array(scales),
-         accepted=remd.accepted, start=local.start, stop=local.stop)
+         accepted=remd.accepted, start=local.start, stop=local.stop, pad=g.m, index=g.index, gathered=g.all.numpy())
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -114,6 +125,9 @@ def test_two_ranks_over_gloo_take_identical_decisions(tmp_path):
     r1 = np.load(tmp_path / "rank1.npz")
     assert (int(r0["start"]), int(r0["stop"]), int(r1["start"]), int(r1["stop"])) == (0, 7, 7, 13)
     assert np.array_equal(r0["slots"], r1["slots"])             # replicated bookkeeping stays in lock step
+    # the gather buffer: shards padded to the longer one (7), replica r at rank * 7 + (r - start(rank)); both ranks hold the same
+    assert int(r0["pad"]) == 7 and list(r0["index"]) == list(range(7)) + list(range(7, 13))
+    assert np.array_equal(r0["gathered"], r1["gathered"]) and r0["gathered"].shape == (14,)
     assert np.array_equal(r0["accepted"], r1["accepted"]) and r0["accepted"].sum() > 0
 
     # single-rank run of the same ladder and seed: same decisions, and the per-rank scale vectors tile it
