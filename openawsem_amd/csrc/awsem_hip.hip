@@ -1195,7 +1195,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     }
     if (const char* env = getenv("AWSEM_BLOCK")) {
         int b = atoi(env);
-        if (b >= 64 && b <= 1024 && b % 64 == 0) block_ = b;
+        if (b >= 64 && b <= 1024 && (b & (b - 1)) == 0) block_ = b;   // a power of two: the kernels deal work to waves with masks
     }
 }
 

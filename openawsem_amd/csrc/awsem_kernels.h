@@ -100,7 +100,8 @@ template <class real> struct ViewCommon {
     real* gamma;             // gamma tables of the current contact term (env-major)
     u64* eg;                 // per-group energies (fixed point)
     u64* cv;                 // sums of the collective-variable terms (fixed point), DevSys::n_cv of them
-    u64* cm;                 // [2][3] total momentum of the massive particles (fixed point, CmFix<real>::scale), double buffered by step parity
+    u64* cm;                 // [2][3] total momentum of the massive particles (fixed point, CmFix<real>::scale), double buffered by step parity;
+                             // behind them [2][4] reals: the mean velocity each sum stands for, converted once per step
     int* satom;              // contact site -> atom, [contact term][max_contact_sites]
     unsigned* lcount;        // pair-list entry counts, one per list
     unsigned* flag;          // [2]: largest squared displacement since the last list build (float bits), double buffered
@@ -233,7 +234,7 @@ __device__ __forceinline__ int rot_tid(int rot) {
 struct Rotor {   // hands out starting waves: each job continues where the previous one stopped
     int acc = 0;
     __device__ __forceinline__ int next(int nitems) {
-        const int nw = blockDim.x >> 6, r = acc % nw;
+        const int nw = blockDim.x >> 6, r = acc & (nw - 1);   // workgroups hold a power-of-two number of waves (Engine::finalize): no scalar division
         acc += (nitems + 63) >> 6;
         return r;
     }
@@ -590,7 +591,7 @@ __device__ __forceinline__ void list_append(unsigned* __restrict__ e, unsigned* 
 #define AWSEM_WAVE_VARS const int nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63
 // list chunks of 64 entries are dealt to the waves round-robin, starting at a different wave for every list so
 // that short lists do not all land on wave 0
-#define AWSEM_LIST_CHUNKS(c0, count, rot) for (int c0 = ((wave + nw - ((rot) % nw)) % nw) * 64; c0 < (count); c0 += nw * 64)
+#define AWSEM_LIST_CHUNKS(c0, count, rot) for (int c0 = ((wave - (rot)) & (nw - 1)) * 64; c0 < (count); c0 += nw * 64)   // nw is a power of two
 
 struct ListView { const unsigned* e; int count; };
 template <class V> __device__ __forceinline__ ListView list_view(const V& L, const ListSlot& ls) {
@@ -1200,7 +1201,7 @@ template <class real> __host__ __device__ inline size_t lds_bytes(const LdsShape
     size_t b = 0;
     b += (size_t)natoms * (Y::pos + Y::force + (with_vel ? Y::ref : 0)) + (with_vel ? (size_t)sh.nmassive * Y::vel : 0);
     b += (size_t)2 * nsites * sizeof(u64);            // rho, drho
-    b += (AWSEM_NGROUPS + (size_t)sh.ncv + 6) * sizeof(u64);   // group energies, collective-variable sums, momentum sums
+    b += (AWSEM_NGROUPS + (size_t)sh.ncv + 6 + 8) * sizeof(u64);   // group energies, collective-variable sums, momentum sums and the mean velocities they stand for
     b += (size_t)3 * nsites * sizeof(real);           // rhov, alpha, dalpha
     b += (size_t)sh.ngamma * sizeof(real);            // gamma staging
     b += (size_t)(ncontact > 0 ? ncontact : 1) * nsites * sizeof(int);   // contact site -> atom
@@ -1214,7 +1215,7 @@ template <class real> __device__ inline void carve_common(ViewCommon<real>& L, u
     L.eg = w; w += AWSEM_NGROUPS;
     L.cv = w; w += sh.ncv;
     if ((int)threadIdx.x < sh.ncv) L.cv[threadIdx.x] = 0;   // every kernel has a barrier between the carve-up and its first evaluation
-    L.cm = w; w += 6;
+    L.cm = w; w += 6 + 8;
     if (threadIdx.x < 6) L.cm[threadIdx.x] = 0;
     real* r = (real*)w;
     L.rhov = r; r += nsites; L.alpha = r; r += nsites; L.dalpha = r; r += nsites;
@@ -1494,12 +1495,6 @@ template <> struct CmAcc<double> {
         }
     }
 };
-// mean velocity from a momentum sum
-template <class real> __device__ __forceinline__ R3<real> cm_velocity(const u64* cm, real inv_total_mass) {
-    const real f = inv_total_mass * (real)(1.0 / (double)CmAcc<real>::scale);
-    return R3<real>{(real)(long long)cm[0] * f, (real)(long long)cm[1] * f, (real)(long long)cm[2] * f};
-}
-
 #ifndef AWSEM_STEP_ATTR
 #define AWSEM_STEP_ATTR
 #endif
@@ -1540,7 +1535,11 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
     for (int s = 0; s < nsteps; s++) {
         const int cur = s & 1;
         const bool rebuild = s == 0 || __uint_as_float(L.flag[cur]) > (float)S.skin_half2;   // uniform across the workgroup
-        if (cmr && threadIdx.x < 3) L.cm[(cur ^ 1) * 3 + threadIdx.x] = 0;   // read for the last time in the previous step's integrator; this step's adds to it
+        if (cmr && threadIdx.x < 3) {
+            L.cm[(cur ^ 1) * 3 + threadIdx.x] = 0;   // read for the last time in the previous step's integrator; this step's adds to it
+            // the mean velocity this step removes, as reals, for every lane to pick up in the integrator (several barriers from here)
+            ((real*)(L.cm + 6))[cur * 4 + threadIdx.x] = (real)(long long)L.cm[cur * 3 + threadIdx.x] * (S.inv_total_mass * (real)(1.0 / (double)CmAcc<real>::scale));
+        }
         if (rebuild || !fuse) {   // the virtual sites in a phase of their own: the hydrogen-bond list builders read them
             update_virtual_sites(S, L);
             __syncthreads();
@@ -1581,7 +1580,7 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
         {
             float m = 0;
             R3<real> vcm{0, 0, 0};
-            if (cmr) vcm = cm_velocity<real>(&L.cm[cur * 3], S.inv_total_mass);   // the momentum the previous step (or the launch start) left
+            if (cmr) { const real* q = (const real*)(L.cm + 6) + cur * 4; vcm = R3<real>{q[0], q[1], q[2]}; }   // the momentum the previous step (or the launch start) left
             CmAcc<real> acc;
             for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {   // compact list: no lane idles on a virtual site
                 const GatherItem<real> gi = S.gather[k];
