@@ -161,6 +161,8 @@ template <class real> struct DevSys {
     real skin_half2;                      // (skin/2)^2: lists are rebuilt once an atom has moved further than skin/2
     int remove_cm;                        // CMMotionRemover: subtract the mass-weighted mean velocity at the top of every step
     real inv_total_mass;                  // 1 / sum of the masses
+    int prio;                             // step kernel: how the replicas sharing a CU take turns at issue priority (0: hardware default, oldest wave first;
+                                          // 1: rotating with the step count; 2: rotating with the clock)
     int* status;                          // device error word: bit 0 = a pair list overflowed
     long long* prof;                      // 16 phase-cycle accumulators (written by -DAWSEM_PROF builds only)
 };

@@ -16,6 +16,7 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <map>
 
 #include "../../include/awsem_hip.h"
 #include "awsem_kernels.h"
@@ -131,6 +132,42 @@ public:
                 for (int k = 0; k < 10; k++) tot += p[k];
                 if (tot > 0) for (int k = 0; k < 10; k++) fprintf(stderr, "[awsem prof] %-24s %14lld cycles  %5.1f %%\n", names[k], p[k], 100.0 * p[k] / tot);
                 fprintf(stderr, "[awsem prof] list rebuilds: %lld (all replicas, all launches)\n", p[10]);
+            }
+            // residency of the workgroups of the LAST step launch (wall clock, 100 MHz): how much of the kernel's span a replica is resident for,
+            // and how the end times spread inside a CU and between CUs (third word: XCC_ID << 32 | HW_ID)
+            std::vector<long long> w(3 * (size_t)nrep_);
+            if (hipMemcpy(w.data(), dsys_.prof + 16, w.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess && w[1] > 0) {
+                long long s0 = w[0], s1 = w[0], e0 = w[1], e1 = w[1];
+                double dsum = 0;
+                std::vector<long long> dur(nrep_);
+                std::map<long long, std::vector<long long>> by_cu;
+                for (int r = 0; r < nrep_; r++) {
+                    s0 = std::min(s0, w[3 * r]); s1 = std::max(s1, w[3 * r]); e0 = std::min(e0, w[3 * r + 1]); e1 = std::max(e1, w[3 * r + 1]);
+                    dur[r] = w[3 * r + 1] - w[3 * r]; dsum += (double)dur[r];
+                    by_cu[((w[3 * r + 2] >> 32) << 8) | ((w[3 * r + 2] >> 8) & 0xff)].push_back(dur[r]);
+                }
+                std::sort(dur.begin(), dur.end());
+                fprintf(stderr, "[awsem prof] last launch: span %.1f us, first..last start %.1f us, first..last end %.1f us; workgroup residency mean %.1f us "
+                        "(%.1f %% of the span), min %.1f, median %.1f, p90 %.1f, max %.1f\n", (e1 - s0) * 0.01, (s1 - s0) * 0.01, (e1 - e0) * 0.01, dsum / nrep_ * 0.01,
+                        100.0 * dsum / nrep_ / (double)(e1 - s0), dur[0] * 0.01, dur[nrep_ / 2] * 0.01, dur[(size_t)nrep_ * 9 / 10] * 0.01, dur[nrep_ - 1] * 0.01);
+                if (FILE* f = strlen(getenv("AWSEM_PROF_DUMP")) > 1 ? fopen(getenv("AWSEM_PROF_DUMP"), "w") : nullptr) {   // raw stamps for offline analysis
+                    for (int r = 0; r < nrep_; r++) fprintf(f, "%d %lld %lld %llx\n", r, w[3 * r] - s0, w[3 * r + 1] - s0, (unsigned long long)w[3 * r + 2]);
+                    fclose(f);
+                }
+                std::vector<double> cu_max, cu_spread, cu_n;
+                for (auto& kv : by_cu) {
+                    auto& v = kv.second;
+                    std::sort(v.begin(), v.end());
+                    cu_max.push_back(v.back() * 0.01); cu_spread.push_back((v.back() - v.front()) * 0.01); cu_n.push_back((double)v.size());
+                }
+                auto stat = [](std::vector<double> v, const char* what) {
+                    std::sort(v.begin(), v.end());
+                    fprintf(stderr, "[awsem prof]   per CU %-28s min %.1f  median %.1f  max %.1f\n", what, v.front(), v[v.size() / 2], v.back());
+                };
+                fprintf(stderr, "[awsem prof]   %zu CUs seen\n", by_cu.size());
+                stat(cu_n, "workgroups"); stat(cu_max, "last end (us)"); stat(cu_spread, "first..last end (us)");
+                int shown = 0;
+                for (auto& kv : by_cu) if (shown++ < 6) { fprintf(stderr, "[awsem prof]   cu %llx:", (unsigned long long)kv.first); for (long long d : kv.second) fprintf(stderr, " %.1f", d * 0.01); fprintf(stderr, "\n"); }
             }
         }
         for (auto& G : cell_graph_) if (G.exec) (void)hipGraphExecDestroy(G.exec);
@@ -776,6 +813,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         for (int i = 0; i < natoms_; i++) mtot += H.mass[i];
         S.remove_cm = H.remove_cm && mtot > 0 ? 1 : 0;
         S.inv_total_mass = mtot > 0 ? (real)(1.0 / mtot) : (real)0;
+        S.prio = getenv("AWSEM_PRIO") ? atoi(getenv("AWSEM_PRIO")) : 1;   // 0 switches the rotation off (A/B runs)
         std::vector<MassiveItem<real>> mv;
         for (int i = 0; i < natoms_; i++) if (H.mass[i] > 0) mv.push_back(MassiveItem<real>{i, im[i], sim[i], to_orig_.empty() ? i : to_orig_[i]});
         S.massive = upload(mv);
@@ -1093,8 +1131,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     dstatus_ = dalloc<int>(1);
     HIP_TRY(hipMemset(dstatus_, 0, sizeof(int)));
     S.status = dstatus_;
-    S.prof = dalloc<long long>(16);
-    HIP_TRY(hipMemset(S.prof, 0, 16 * sizeof(long long)));
+    S.prof = dalloc<long long>(16 + 3 * (size_t)nrep_);   // phase cycles, then (start, end, hardware id) per replica (experiment builds)
+    HIP_TRY(hipMemset(S.prof, 0, (16 + 3 * (size_t)nrep_) * sizeof(long long)));
     const size_t lds_max = lds_max_;
     lds_eval_ = lds_bytes<real>(lds_shape(S), false);
     lds_step_ = lds_bytes<real>(lds_shape(S), true);

@@ -40,6 +40,14 @@ struct AwsemProf { long long last, acc[10]; };
 #define AWSEM_STAMP_PASS
 #endif
 
+// -DAWSEM_WALL (implied by -DAWSEM_PROF): wall-clock start and end of every workgroup of the step kernel, and where it ran
+#if defined(AWSEM_PROF) || defined(AWSEM_WALL)
+#define AWSEM_STAMP_WALL(S, k) do { if (threadIdx.x == 0) { (S).prof[16 + 3 * blockIdx.x + (k)] = (long long)wall_clock64(); \
+    if ((k) == 0) (S).prof[16 + 3 * blockIdx.x + 2] = ((long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); } } while (0)
+#else
+#define AWSEM_STAMP_WALL(S, k) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------ scalar helpers
 template <class real> struct M;
 template <> struct M<float> {
@@ -1495,6 +1503,20 @@ template <> struct CmAcc<double> {
         }
     }
 };
+// Issue priority of a wave (s_setprio takes an immediate).  The SIMD arbiter serves the highest priority first and, among equals,
+// the OLDEST wave: left alone, the replica dispatched first on a CU runs at nearly its solo speed, the three behind it get what
+// is left, and the CU ends the launch with one, two, three of its four replicas already gone (measured with -DAWSEM_WALL: the
+// replicas of a CU ended 157 us apart in a 873 us launch, finishing in dispatch order on 231 of 256 CUs).  Rotating the priority
+// step by step makes them advance together (40 us apart, +6 % throughput).  A feedback form -- the replica furthest behind goes
+// first, step counts shared through one L2 atomic per wave and step -- ends them 28 us apart but costs more than it gains.
+__device__ __forceinline__ void set_wave_priority(int p) {
+    switch (p & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
 #ifndef AWSEM_STEP_ATTR
 #define AWSEM_STEP_ATTR
 #endif
@@ -1503,6 +1525,7 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
                                   const double* __restrict__ T, int nsteps, double dt, double friction, unsigned long long seed,
                                   long long step0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    AWSEM_STAMP_WALL(S, 0);
     const int natoms = S.natoms, rep = blockIdx.x;
     Lds<real> L = carve_lds((real)0, smem, lds_shape(S), true);
     L.lists = S.lists + (size_t)rep * S.list_stride;
@@ -1519,7 +1542,9 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
     const real ns = (real)::sqrt(AWSEM_KB * T[rep] * (1.0 - a_d * a_d)), dtr = (real)dt;
     stage_tables(S, L);
     if (threadIdx.x < 2) L.flag[threadIdx.x] = 0;
+    if (threadIdx.x == 0) L.flag[2] = __builtin_amdgcn_s_getreg((3 << 11) | 4);   // HW_ID[3:0]: wave 0's slot on its SIMD -- distinct among the replicas that share the CU (measured: 0..3 in dispatch order)
     __syncthreads();
+    const int prio_slot = uniform((int)L.flag[2]);
     compute_virtual_sites(S, L);
     const bool cmr = S.remove_cm != 0;
     if (cmr) {   // momentum of the incoming velocities: what the first step removes (L.cm[0..2]; zeroed at the carve-up, a barrier ago)
@@ -1535,6 +1560,8 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
     for (int s = 0; s < nsteps; s++) {
         const int cur = s & 1;
         const bool rebuild = s == 0 || __uint_as_float(L.flag[cur]) > (float)S.skin_half2;   // uniform across the workgroup
+        if (S.prio == 1) set_wave_priority(prio_slot + s);   // this replica's turn at each of the four levels comes round every four steps
+        else if (S.prio == 2) set_wave_priority(prio_slot + (int)(wall_clock64() >> 11));   // by the clock instead (100 MHz: turns of 20 us); measured equal
         if (cmr && threadIdx.x < 3) {
             L.cm[(cur ^ 1) * 3 + threadIdx.x] = 0;   // read for the last time in the previous step's integrator; this step's adds to it
             // the mean velocity this step removes, as reals, for every lane to pick up in the integrator (several barriers from here)
@@ -1637,6 +1664,7 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
         const R3<real> v = L.vel(k);
         gv[i] = v.x; gv[natoms + i] = v.y; gv[2 * natoms + i] = v.z;
     }
+    AWSEM_STAMP_WALL(S, 1);
 }
 
 // ------------------------------------------------------------------ energy minimiser (simulation.minimizeEnergy())
