@@ -72,6 +72,7 @@ __device__ __forceinline__ float ordered_float(int o) { return __int_as_float(o 
 template <class real> struct CellView : ViewCommon<real>, SoaOps<real> { typedef real real_t; };
 template <class real> __device__ inline CellView<real> cell_view(const DevSys<real>& S, const CellSys<real>& C, const real* pos, int rep) {
     CellView<real> L;
+    L.nthr = blockDim.x; L.ramap = nullptr;
     const size_t n = C.natoms;
     real* p = const_cast<real*>(pos) + (size_t)rep * 3 * n;
     L.px = p; L.py = p + n; L.pz = p + 2 * n;
@@ -522,6 +523,7 @@ struct HbRows { unsigned* rows; int* row_count; int stride; };   // [R][nacc][st
 
 template <class real> __device__ inline CellView<real> cell_view_plain(const CellSys<real>& C, const real* pos, int rep) {
     CellView<real> L;
+    L.nthr = blockDim.x; L.ramap = nullptr;
     const size_t n = C.natoms;
     real* p = const_cast<real*>(pos) + (size_t)rep * 3 * n;
     L.px = p; L.py = p + n; L.pz = p + 2 * n;
@@ -642,6 +644,7 @@ template <bool ENERGY, class real> __global__ void cell_window_kernel(DevSys<rea
     for (int i = threadIdx.x; i < na; i += blockDim.x)
         for (int k = 0; k < 3; k++) { sp[k][i] = p[(size_t)k * n + a0 + i]; sf[k][i] = 0; }
     WinView<real> L;
+    L.nthr = blockDim.x; L.ramap = nullptr;
     L.px = &sp[0][0] - a0; L.py = &sp[1][0] - a0; L.pz = &sp[2][0] - a0;
     L.fx = &sf[0][0] - a0; L.fy = &sf[1][0] - a0; L.fz = &sf[2][0] - a0;
     L.rho = L.drho = nullptr; L.rhov = L.alpha = L.dalpha = L.gamma = nullptr; L.satom = nullptr; L.cv = nullptr;

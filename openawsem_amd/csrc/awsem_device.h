@@ -55,6 +55,17 @@ template <class real> struct RamaD {
     real sigma[AWSEM_MAX_WELLS], omega_phi[AWSEM_MAX_WELLS], omega_psi[AWSEM_MAX_WELLS];
     real cphi0[AWSEM_MAX_WELLS], sphi0[AWSEM_MAX_WELLS], cpsi0[AWSEM_MAX_WELLS], spsi0[AWSEM_MAX_WELLS];
 };
+// Every Ramachandran-shaped term of one force group in ONE item list (replica-resident path): a term with two items (rama_proline_term
+// of a protein with two prolines) otherwise costs a whole wave pass of ~360 instructions.  An item carries the index of its term's
+// parameter set; the sets are staged in LDS ([set][well][8]: sigma, omega_phi, omega_psi, cos/sin phi0, cos/sin psi0, pad) and read
+// per lane; wells a set does not have are padded with zero weights and contribute exact zeros.
+struct RamaItem { int a[5]; int set; };
+template <class real> struct RamaMergedD {
+    int group, n, nwell, nset;            // n == 0: not merged (the kernels walk DevSys::rama term by term)
+    const RamaItem* items;
+    const real* bw;                       // n x nwell, as in RamaD (zero where the item's term has fewer wells)
+    const real* params;                   // nset x nwell x 8
+};
 template <class real> struct ExclD {
     int group, nsites, nclass;
     const int* atom;                      // sites sorted by class
@@ -145,6 +156,7 @@ template <class real> struct DevSys {
     const int* orig;                      // internal atom index -> the caller's (null: identical); see Engine::finalize
     int n_harm, n_chi, n_rama, n_excl, n_contact, n_beta, n_pap, n_helical, n_fm, n_memb, n_dh, n_gauss;
     HarmD<real> harm[AWSEM_MAX_HARM]; ChiD<real> chi[AWSEM_MAX_CHI]; RamaD<real> rama[AWSEM_MAX_RAMA];
+    RamaMergedD<real> ramam;
     ExclD<real> excl[AWSEM_MAX_EXCL]; ContactD<real> contact[AWSEM_MAX_CONTACT]; BetaD<real> beta[AWSEM_MAX_BETA];
     PapD<real> pap[AWSEM_MAX_PAP]; HelicalD<real> helical[AWSEM_MAX_HELICAL]; FmD<real> fm[AWSEM_MAX_FM];
     MembD<real> memb[AWSEM_MAX_MEMB]; DhD<real> dh[AWSEM_MAX_DH];

@@ -132,6 +132,15 @@ public:
                 for (int k = 0; k < 10; k++) tot += p[k];
                 if (tot > 0) for (int k = 0; k < 10; k++) fprintf(stderr, "[awsem prof] %-24s %14lld cycles  %5.1f %%\n", names[k], p[k], 100.0 * p[k] / tot);
                 fprintf(stderr, "[awsem prof] list rebuilds: %lld (all replicas, all launches)\n", p[10]);
+                long long wv[16 * 20] = {0};   // per wave: own work and barrier wait of every phase
+                if (tot > 0 && hipMemcpy(wv, dsys_.prof + 16 + 3 * (size_t)nrep_, sizeof wv, hipMemcpyDeviceToHost) == hipSuccess)
+                    for (int w = 0; w < 16; w++) {
+                        long long any = 0; for (int k = 0; k < 20; k++) any += wv[w * 20 + k];
+                        if (!any) continue;
+                        fprintf(stderr, "[awsem prof]   wave %2d work%%/wait%%:", w);
+                        for (int k : {0, 2, 4, 5, 6, 7, 9}) fprintf(stderr, "  %s %4.1f/%4.1f", names[k], 100.0 * wv[w * 20 + k] / tot, 100.0 * wv[w * 20 + 10 + k] / tot);
+                        fprintf(stderr, "\n");
+                    }
             }
             // residency of the workgroups of the LAST step launch (wall clock, 100 MHz): how much of the kernel's span a replica is resident for,
             // and how the end times spread inside a CU and between CUs (third word: XCC_ID << 32 | HW_ID)
@@ -891,6 +900,40 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         }
         if (D.size() > AWSEM_MAX_RAMA) throw std::string("too many rama terms: at most " + std::to_string(AWSEM_MAX_RAMA) + " per system");
         S.n_rama = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.rama[t] = D[t];
+        // replica-resident path: all terms of one group walk as one item list (AWSEM_RAMA_MERGE=0: term by term, for A/B runs)
+        bool merge = !cell_mode_ && D.size() >= 2 && !(getenv("AWSEM_RAMA_MERGE") && atoi(getenv("AWSEM_RAMA_MERGE")) == 0);
+        for (auto& d : D) if (d.group != D[0].group) merge = false;
+        if (merge) {
+            RamaMergedD<real>& m = S.ramam;
+            m.group = D[0].group; m.nset = (int)D.size(); m.nwell = 0; m.n = 0;
+            for (auto& h : H.rama) { m.nwell = std::max(m.nwell, h.nwell); m.n += (int)(h.atoms.size() / 5); }
+            std::vector<int> atoms; std::vector<int> set_of; std::vector<double> w;   // concatenated in the caller's order
+            for (size_t t = 0; t < H.rama.size(); t++) {
+                const auto& h = H.rama[t];
+                const int n = (int)(h.atoms.size() / 5);
+                atoms.insert(atoms.end(), h.atoms.begin(), h.atoms.end());
+                for (int b = 0; b < n; b++) {
+                    set_of.push_back((int)t);
+                    for (int q = 0; q < m.nwell; q++) w.push_back(q < h.nwell ? -h.k * h.wp[6 * q] * h.bw[(size_t)b * h.nwell + q] : 0.0);
+                }
+            }
+            const std::vector<int> perm = item_order(m.n, 5, atoms.data());
+            std::vector<RamaItem> it(m.n);
+            std::vector<real> bw((size_t)m.n * m.nwell);
+            for (int b = 0; b < m.n; b++) {
+                const int o = perm[b];
+                for (int k = 0; k < 5; k++) it[b].a[k] = atoms[5 * o + k];
+                it[b].set = set_of[o];
+                for (int q = 0; q < m.nwell; q++) bw[(size_t)b * m.nwell + q] = (real)w[(size_t)o * m.nwell + q];
+            }
+            std::vector<real> par((size_t)m.nset * m.nwell * 8, (real)0);
+            for (int t = 0; t < m.nset; t++) for (int q = 0; q < D[t].nwell; q++) {
+                real* p = &par[((size_t)t * m.nwell + q) * 8];
+                p[0] = D[t].sigma[q]; p[1] = D[t].omega_phi[q]; p[2] = D[t].omega_psi[q];
+                p[3] = D[t].cphi0[q]; p[4] = D[t].sphi0[q]; p[5] = D[t].cpsi0[q]; p[6] = D[t].spsi0[q];
+            }
+            m.items = upload(it); m.bw = upload(bw); m.params = upload(par);
+        }
     }
     {   // excl: sort sites by class, per-site partner lists
         std::vector<ExclD<real>> D;
@@ -1131,8 +1174,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     dstatus_ = dalloc<int>(1);
     HIP_TRY(hipMemset(dstatus_, 0, sizeof(int)));
     S.status = dstatus_;
-    S.prof = dalloc<long long>(16 + 3 * (size_t)nrep_);   // phase cycles, then (start, end, hardware id) per replica (experiment builds)
-    HIP_TRY(hipMemset(S.prof, 0, (16 + 3 * (size_t)nrep_) * sizeof(long long)));
+    S.prof = dalloc<long long>(16 + 3 * (size_t)nrep_ + 16 * 20);   // phase cycles, then (start, end, hardware id) per replica (experiment builds)
+    HIP_TRY(hipMemset(S.prof, 0, (16 + 3 * (size_t)nrep_ + 16 * 20) * sizeof(long long)));
     const size_t lds_max = lds_max_;
     lds_eval_ = lds_bytes<real>(lds_shape(S), false);
     lds_step_ = lds_bytes<real>(lds_shape(S), true);
@@ -1231,6 +1274,9 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         per_cu = std::min(per_cu, std::max<size_t>(1, ((size_t)nrep_ + n_cu_ - 1) / n_cu_));   // fewer replicas than slots: a CU holds fewer (1r69, <= 256 replicas: 14.3 -> 12.1 us per step)
         block_ = per_cu >= 4 ? 256 : per_cu >= 2 && per_cu * 512 <= 1024 ? 512 : per_cu == 1 ? 1024 : 256;   // powers of two only: 320 threads (three replicas per CU) were measured 70 % slower than 256
     }
+    if (getenv("AWSEM_INFO"))
+        fprintf(stderr, "[awsem] %d atoms x %d replicas: LDS %zu B per replica stepping (%zu B evaluating) of %zu B per CU -> %zu per CU, %d threads per replica\n",
+                natoms_, nrep_, lds_step_, lds_eval_, lds_max, lds_max / std::max<size_t>(1, lds_step_), block_);
     if (const char* env = getenv("AWSEM_BLOCK")) {
         int b = atoi(env);
         if (b >= 64 && b <= 1024 && (b & (b - 1)) == 0) block_ = b;   // a power of two: the kernels deal work to waves with masks

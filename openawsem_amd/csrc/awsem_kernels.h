@@ -26,13 +26,20 @@ typedef unsigned long long u64;
 // Phase timing of the step kernel (experiment builds only: -DAWSEM_PROF): thread 0 of every workgroup adds the
 // cycles between consecutive stamps to DevSys::prof[phase]; dumped by the host when AWSEM_PROF_DUMP is set.
 #ifdef AWSEM_PROF
-struct AwsemProf { long long last, acc[10]; };
-#define AWSEM_STAMP(S, k) do { long long _t = __builtin_readcyclecounter(); awsem_prof.acc[k] += _t - awsem_prof.last; awsem_prof.last = _t; } while (0)
-#define AWSEM_STAMP_INIT AwsemProf awsem_prof; awsem_prof.last = __builtin_readcyclecounter(); for (int _k = 0; _k < 10; _k++) awsem_prof.acc[_k] = 0
-#define AWSEM_STAMP_FLUSH(S) do { if (threadIdx.x == 0) for (int _k = 0; _k < 10; _k++) atomicAdd((unsigned long long*)&(S).prof[_k], (unsigned long long)awsem_prof.acc[_k]); } while (0)
+// AWSEM_ARRIVE(k), placed in front of the barrier that ends phase k, books the time up to it as the wave's own work; the stamp behind the
+// barrier then books the rest as waiting.  Every wave keeps its own sums (the table behind the per-replica stamps, [wave][work, wait][10]).
+struct AwsemProf { long long last, acc[10], wait[10]; };
+#define AWSEM_ARRIVE(k) do { long long _t = __builtin_readcyclecounter(); awsem_prof.acc[k] += _t - awsem_prof.last; awsem_prof.last = _t; } while (0)
+#define AWSEM_STAMP(S, k) do { long long _t = __builtin_readcyclecounter(); awsem_prof.wait[k] += _t - awsem_prof.last; awsem_prof.last = _t; } while (0)
+#define AWSEM_STAMP_INIT AwsemProf awsem_prof; awsem_prof.last = __builtin_readcyclecounter(); for (int _k = 0; _k < 10; _k++) awsem_prof.acc[_k] = awsem_prof.wait[_k] = 0
+#define AWSEM_STAMP_FLUSH(S) do { if (threadIdx.x == 0) for (int _k = 0; _k < 10; _k++) atomicAdd((unsigned long long*)&(S).prof[_k], (unsigned long long)(awsem_prof.acc[_k] + awsem_prof.wait[_k])); \
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 1024) for (int _k = 0; _k < 10; _k++) { \
+        unsigned long long* _w = (unsigned long long*)(S).prof + 16 + 3 * (size_t)gridDim.x + (threadIdx.x >> 6) * 20; \
+        atomicAdd(_w + _k, (unsigned long long)awsem_prof.acc[_k]); atomicAdd(_w + 10 + _k, (unsigned long long)awsem_prof.wait[_k]); } } while (0)
 #define AWSEM_STAMP_ARG , AwsemProf& awsem_prof
 #define AWSEM_STAMP_PASS , awsem_prof
 #else
+#define AWSEM_ARRIVE(k) do { } while (0)
 #define AWSEM_STAMP(S, k) do { } while (0)
 #define AWSEM_STAMP_INIT do { } while (0)
 #define AWSEM_STAMP_FLUSH(S) do { } while (0)
@@ -102,10 +109,14 @@ template <class real> __device__ __forceinline__ real dist2(const R3<real>& d) {
 // ------------------------------------------------------------------ views of one replica
 // Members every view carries besides coordinates and forces (the contact passes' scratch, energies, pair lists).
 template <class real> struct ViewCommon {
+    int nthr;                // threads of the workgroup.  blockDim.x is a 16-bit field of the implicit kernel arguments: every place the compiler
+                             // rematerialises it costs a VECTOR load and a wait on it (there is no scalar 16-bit load); the LDS views read it once and
+                             // pin it in a scalar register
     u64 *rho, *drho;         // contact density and dE/drho accumulators (2^-32 fixed point)
     real* rhov;              // per-site water switch s_i = sig(-2 eta_s (rho_i - rho0))
     real *alpha, *dalpha;    // z-dependent membrane switch
     real* gamma;             // gamma tables of the current contact term (env-major)
+    real* ramap;             // LDS views: parameter sets of the merged Ramachandran list (RamaMergedD), [set][well][8]
     u64* eg;                 // per-group energies (fixed point)
     u64* cv;                 // sums of the collective-variable terms (fixed point), DevSys::n_cv of them
     u64* cm;                 // [2][3] total momentum of the massive particles (fixed point, CmFix<real>::scale), double buffered by step parity;
@@ -235,14 +246,16 @@ template <class real> __device__ __forceinline__ real sigmoid(real x) { return M
 
 // Item loops are block-strided; `rot` shifts which wave takes the first 64 items, so that the short terms of one
 // phase (a few dozen dihedrals, the per-site contact pass ...) land on different waves instead of all on wave 0.
-__device__ __forceinline__ int rot_tid(int rot) {
+__device__ __forceinline__ int rot_tid_n(int rot, int nthr) {
     int t = (int)threadIdx.x + 64 * rot;
-    return t >= (int)blockDim.x ? t - (int)blockDim.x : t;
+    return t >= nthr ? t - nthr : t;
 }
+#define rot_tid(rot) rot_tid_n((rot), L.nthr)   // every caller has its view `L` in scope
 struct Rotor {   // hands out starting waves: each job continues where the previous one stopped
-    int acc = 0;
+    int nthr, acc = 0;
+    __device__ __forceinline__ explicit Rotor(int nthreads) : nthr(nthreads) {}
     __device__ __forceinline__ int next(int nitems) {
-        const int nw = blockDim.x >> 6, r = acc & (nw - 1);   // workgroups hold a power-of-two number of waves (Engine::finalize): no scalar division
+        const int nw = nthr >> 6, r = acc & (nw - 1);   // workgroups hold a power-of-two number of waves (Engine::finalize): no scalar division
         acc += (nitems + 63) >> 6;
         return r;
     }
@@ -252,7 +265,7 @@ struct Rotor {   // hands out starting waves: each job continues where the previ
 template <bool ENERGY, class V> __device__ __forceinline__ void term_harmonic(const HarmD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     Energy e;
-    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += L.nthr) {
         const HarmItem<real> it = d.items[b];
         const R3<real> dd = L.pos(it.i) - L.pos(it.j);
         const real r2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z, ir = M<real>::rsqrt(r2), r = r2 * ir, dr = r - it.r0;
@@ -265,7 +278,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void term_harmonic(co
 template <bool ENERGY, class V> __device__ __forceinline__ void term_chi(const ChiD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     Energy e;
-    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += L.nthr) {
         const Int4 a = d.atoms[b];   // CA, C, N, CB
         const R3<real> pca = L.pos(a.x), u = pca - L.pos(a.y), v = L.pos(a.z) - pca, w = pca - L.pos(a.w);
         const real ux = u.x, uy = u.y, uz = u.z, vx = v.x, vy = v.y, vz = v.z, wx = w.x, wy = w.y, wz = w.z;
@@ -313,7 +326,7 @@ template <class real> __device__ __forceinline__ void dihedral(const R3<real>& q
 template <bool ENERGY, class V> __device__ __forceinline__ void term_rama(const RamaD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     Energy e;
-    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += L.nthr) {
         const Int5 a = d.atoms[b];
         real W[AWSEM_MAX_WELLS];
 #pragma unroll
@@ -344,6 +357,44 @@ template <bool ENERGY, class V> __device__ __forceinline__ void term_rama(const 
     flush_energy<ENERGY>(L, d.group, e);
 }
 
+// All Ramachandran terms of a group as one item list: the same arithmetic as term_rama, item by item, with the term's well
+// parameters read per lane from the LDS copy of the parameter sets.
+template <bool ENERGY, class V> __device__ __forceinline__ void term_rama_merged(const RamaMergedD<typename V::real_t>& d, const V& L, int rot = 0) {
+    typedef typename V::real_t real;
+    Energy e;
+    for (int b = rot_tid(rot); b < d.n; b += L.nthr) {
+        const RamaItem a = d.items[b];
+        real W[AWSEM_MAX_WELLS];
+#pragma unroll
+        for (int w = 0; w < AWSEM_MAX_WELLS; w++) W[w] = w < d.nwell ? d.bw[b * d.nwell + w] : (real)0;
+        const R3<real> q0 = L.pos(a.a[0]), q1 = L.pos(a.a[1]), q2 = L.pos(a.a[2]), q3 = L.pos(a.a[3]), q4 = L.pos(a.a[4]);
+        Dihedral<real> P, S;
+        dihedral(q0, q1, q2, q3, P);
+        dihedral(q1, q2, q3, q4, S);
+        const real* par = L.ramap + a.set * d.nwell * 8;
+        real dEdphi = 0, dEdpsi = 0;
+#pragma unroll
+        for (int w = 0; w < AWSEM_MAX_WELLS; w++) {
+            if (w >= d.nwell) break;
+            const real sigma = par[8 * w], omega_phi = par[8 * w + 1], omega_psi = par[8 * w + 2];
+            const real cphi0 = par[8 * w + 3], sphi0 = par[8 * w + 4], cpsi0 = par[8 * w + 5], spsi0 = par[8 * w + 6];
+            real cp = P.c * cphi0 + P.s * sphi0 - (real)1, sp = P.s * cphi0 - P.c * sphi0;
+            real cs = S.c * cpsi0 + S.s * spsi0 - (real)1, ss = S.s * cpsi0 - S.c * spsi0;
+            real ex = W[w] * M<real>::exp(-sigma * (omega_phi * cp * cp + omega_psi * cs * cs));
+            if (ENERGY) e += (double)ex;
+            dEdphi += ex * (real)2 * sigma * omega_phi * cp * sp;
+            dEdpsi += ex * (real)2 * sigma * omega_psi * cs * ss;
+        }
+        L.add_force(a.a[0], -dEdphi * P.g[0][0], -dEdphi * P.g[0][1], -dEdphi * P.g[0][2]);
+#pragma unroll
+        for (int m = 1; m < 4; m++)
+            L.add_force(a.a[m], -dEdphi * P.g[m][0] - dEdpsi * S.g[m - 1][0], -dEdphi * P.g[m][1] - dEdpsi * S.g[m - 1][1],
+                        -dEdphi * P.g[m][2] - dEdpsi * S.g[m - 1][2]);
+        L.add_force(a.a[4], -dEdpsi * S.g[3][0], -dEdpsi * S.g[3][1], -dEdpsi * S.g[3][2]);
+    }
+    flush_energy<ENERGY>(L, d.group, e);
+}
+
 // theta(x;y,z) = exp(-(|x-y|-r_ON)^2/(2 s_NO^2) - (|x-z|-r_OH)^2/(2 s_HO^2)); g1,g2 = d theta / d r1, d r2
 template <class real> __device__ __forceinline__ real hb_theta(real r1, real r2, real r_ON, real r_OH, real inv_sNO2, real inv_sHO2, real& g1, real& g2) {
     real a = r1 - r_ON, b = r2 - r_OH;
@@ -355,7 +406,7 @@ template <class real> __device__ __forceinline__ real hb_theta(real r1, real r2,
 template <bool ENERGY, class V> __device__ __forceinline__ void term_helical(const HelicalD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     Energy e;
-    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += L.nthr) {
         const HelicalItem<real> it = d.items[b];
         const R3<real> po = L.pos(it.o), A = po - L.pos(it.n), B = po - L.pos(it.h);
         real r1s = A.x * A.x + A.y * A.y + A.z * A.z, r2s = B.x * B.x + B.y * B.y + B.z * B.z;
@@ -418,7 +469,7 @@ template <bool ENERGY, int U, bool PACKED, class V> __device__ __forceinline__ v
 template <bool ENERGY, bool PACKED = true, class V> __device__ __forceinline__ void term_fm(const FmD<typename V::real_t>& d, const V& L, int rot = 0) {
     Energy e;
     constexpr int U = 6;
-    const unsigned stride = blockDim.x, n = (unsigned)d.n;
+    const unsigned stride = L.nthr, n = (unsigned)d.n;
     for (unsigned b = (unsigned)rot_tid(rot); b < n; b += U * stride) fm_body<ENERGY, U, PACKED>(d, L, b, stride, e);
     flush_energy<ENERGY>(L, d.group, e);
 }
@@ -431,7 +482,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void term_fm_bundled(
     constexpr int K = AWSEM_FM_BUNDLE;
     Energy e;
     const unsigned nrow = (unsigned)d.ntab - 1u;
-    for (int k = rot_tid(rot); k < d.nbundles; k += blockDim.x) {
+    for (int k = rot_tid(rot); k < d.nbundles; k += L.nthr) {
         const FmBundle h = d.bundles[k];
         const unsigned o = h.head & 0xffffu, cnt = h.head >> 16;
         unsigned pj[K], i1[K];
@@ -466,7 +517,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void term_fm_bundled(
 template <bool ENERGY, class V> __device__ __forceinline__ void term_memb(const MembD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     Energy e;
-    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += L.nthr) {
         const MembItem<real> it = d.items[b];
         if (d.kind != 0) {   // uniform: the other external-field terms (awsem_add_external)
             const R3<real> x = L.pos(it.atom);
@@ -494,7 +545,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void term_memb(const 
 template <bool ENERGY, class V> __device__ __forceinline__ void term_dh(const DhD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     Energy e;
-    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += L.nthr) {
         const DhItem<real> it = d.items[b];
         const R3<real> dd = L.pos(it.i) - L.pos(it.j);
         real r2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z, ir = M<real>::rsqrt(r2), r = r2 * ir;
@@ -518,7 +569,7 @@ template <class real> __device__ __forceinline__ void bond_value(const GaussD<re
 template <bool ENERGY, class V> __device__ __forceinline__ void term_gauss(const GaussD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     Energy e;
-    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += L.nthr) {
         const GaussItem<real> it = d.items[b];
         R3<real> dd = L.pos(it.i) - L.pos(it.j);
         if (d.kind == 2) dd.z = 0;
@@ -536,7 +587,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void term_gauss(const
 template <class V> __device__ __forceinline__ void cv_sum(const GaussD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     u64 t = 0;
-    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += L.nthr) {
         const GaussItem<real> it = d.items[b];
         real g, s;
         R3<real> dd = L.pos(it.i) - L.pos(it.j);
@@ -560,7 +611,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void cv_apply(const G
     }
     if (ENERGY && threadIdx.x == 0) fixed_add(&L.eg[d.group], (u64)__double2ll_rn(E * AWSEM_FIXED_SCALE));
     const real fpr = (real)fp;
-    for (int b = rot_tid(rot); b < d.n; b += blockDim.x) {
+    for (int b = rot_tid(rot); b < d.n; b += L.nthr) {
         const GaussItem<real> it = d.items[b];
         R3<real> dd = L.pos(it.i) - L.pos(it.j);
         if (d.kind == 2) dd.z = 0;
@@ -596,7 +647,7 @@ __device__ __forceinline__ void list_append(unsigned* __restrict__ e, unsigned* 
     }
 }
 
-#define AWSEM_WAVE_VARS const int nw = blockDim.x >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63
+#define AWSEM_WAVE_VARS const int nw = L.nthr >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63
 // list chunks of 64 entries are dealt to the waves round-robin, starting at a different wave for every list so
 // that short lists do not all land on wave 0
 #define AWSEM_LIST_CHUNKS(c0, count, rot) for (int c0 = ((wave - (rot)) & (nw - 1)) * 64; c0 < (count); c0 += nw * 64)   // nw is a power of two
@@ -618,7 +669,7 @@ template <class V> __device__ __forceinline__ void build_excl(const ExclD<typena
     unsigned* e = L.lists + d.ls.list_off;
     unsigned* cnt = &L.lcount[d.ls.list_id];
     unsigned* tab = L.scratch();
-    for (int i = threadIdx.x; i < d.nsites; i += blockDim.x) tab[i] = (unsigned)d.atom[i];
+    for (int i = threadIdx.x; i < d.nsites; i += L.nthr) tab[i] = (unsigned)d.atom[i];
     __syncthreads();
     constexpr int U = AWSEM_BUILD_UNROLL;   // candidate chunks in flight: the LDS round trips of one chunk hide behind the others
     for (int c = 0; c < d.nclass; c++) {
@@ -683,7 +734,7 @@ template <class V> __device__ __forceinline__ void build_contact(const ContactD<
     unsigned* cnt = &L.lcount[d.ls.list_id];
     const int n = d.nsites;
     unsigned* tab = L.scratch();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) tab[i] = (unsigned)d.info[i];
+    for (int i = threadIdx.x; i < n; i += L.nthr) tab[i] = (unsigned)d.info[i];
     __syncthreads();
     constexpr int U = AWSEM_BUILD_UNROLL;
     for (int dd = 1 + wave; dd < n; dd += nw) {
@@ -778,7 +829,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void single_body(cons
 }
 template <bool ENERGY, class V> __device__ __forceinline__ void contact_single(const ContactD<typename V::real_t>& d, const V& L, const int* satom, int rot = 0) {
     Energy e;
-    for (int i = rot_tid(rot); i < d.nsites; i += blockDim.x) single_body<ENERGY>(d, L, i, satom[i], e);
+    for (int i = rot_tid(rot); i < d.nsites; i += L.nthr) single_body<ENERGY>(d, L, i, satom[i], e);
     flush_energy<ENERGY>(L, d.group, e);
 }
 // pass 2: pair energy (direct + mediated), its explicit radial force, and dE/drho through sigma_water.
@@ -919,14 +970,14 @@ template <class V, class Desc> __device__ __forceinline__ void build_hbond(const
     // staged words: screening atom (a1 / d1) | residue << 16
     unsigned* sa = L.scratch();
     unsigned* sd = sa + d.nacc;
-    for (int i = threadIdx.x; i < d.nacc; i += blockDim.x) { const Int4 A = d.acc[i]; sa[i] = (unsigned)A.x | ((unsigned)(resw == 3 ? A.w : A.z) << 16); }
-    for (int i = threadIdx.x; i < d.ndon; i += blockDim.x) { const Int4 D = d.don[i]; sd[i] = (unsigned)D.x | ((unsigned)(resw == 3 ? D.w : D.z) << 16); }
+    for (int i = threadIdx.x; i < d.nacc; i += L.nthr) { const Int4 A = d.acc[i]; sa[i] = (unsigned)A.x | ((unsigned)(resw == 3 ? A.w : A.z) << 16); }
+    for (int i = threadIdx.x; i < d.ndon; i += L.nthr) { const Int4 D = d.don[i]; sd[i] = (unsigned)D.x | ((unsigned)(resw == 3 ? D.w : D.z) << 16); }
     // which (donor residue, acceptor residue) pairs have a non-zero table entry: one bit each, staged as well when it fits
     const unsigned* nz = d.nzmask;
     if (d.nz_lds && !d.fn) {
         unsigned* sm = sd + d.ndon;
         const int words = (d.nres * d.nres + 31) >> 5;
-        for (int i = threadIdx.x; i < words; i += blockDim.x) sm[i] = d.nzmask[i];
+        for (int i = threadIdx.x; i < words; i += L.nthr) sm[i] = d.nzmask[i];
         nz = sm;
     }
     __syncthreads();
@@ -1049,7 +1100,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void eval_pap(const P
 // ------------------------------------------------------------------ virtual sites, whole-system evaluation
 template <class V> __device__ __forceinline__ void compute_virtual_sites(const DevSys<typename V::real_t>& S, const V& L) {
     typedef typename V::real_t real;
-    for (int i = threadIdx.x; i < S.nvs; i += blockDim.x) {
+    for (int i = threadIdx.x; i < S.nvs; i += L.nthr) {
         const Int4 v = S.vs[i];
         const real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
         const R3<real> a = L.pos(v.y), b = L.pos(v.z), c = L.pos(v.w);
@@ -1062,18 +1113,18 @@ template <class V> __device__ __forceinline__ void compute_virtual_sites(const D
 // cleared, as are those of massless particles that are no virtual sites
 template <class V> __device__ __forceinline__ void update_virtual_sites(const DevSys<typename V::real_t>& S, const V& L) {
     typedef typename V::real_t real;
-    for (int i = threadIdx.x; i < S.nvs; i += blockDim.x) {
+    for (int i = threadIdx.x; i < S.nvs; i += L.nthr) {
         const Int4 v = S.vs[i];
         const real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
         const R3<real> pa = L.pos(v.y), pb = L.pos(v.z), pc = L.pos(v.w);
         L.set_pos(v.x, R3<real>{w0 * pa.x + w1 * pb.x + w2 * pc.x, w0 * pa.y + w1 * pb.y + w2 * pc.y, w0 * pa.z + w1 * pb.z + w2 * pc.z});
         L.zero_force(v.x);
     }
-    for (int i = threadIdx.x; i < S.nfixed; i += blockDim.x) L.zero_force(S.fixed[i]);
+    for (int i = threadIdx.x; i < S.nfixed; i += L.nthr) L.zero_force(S.fixed[i]);
 }
 template <class V> __device__ __forceinline__ void redistribute_forces(const DevSys<typename V::real_t>& S, const V& L) {
     typedef typename V::real_t real;
-    for (int i = threadIdx.x; i < S.nvs; i += blockDim.x) {
+    for (int i = threadIdx.x; i < S.nvs; i += L.nthr) {
         const Int4 v = S.vs[i];
         const R3<real> f = L.force(v.x);
         L.zero_force(v.x);
@@ -1090,12 +1141,13 @@ template <class V> __device__ __forceinline__ void stage_contact_gamma(const Con
     if (d.flags & (2 | 16)) return;   // burial only: no pair tables; index based: read from global memory
     const int ng = (d.flags & 1) ? 2400 : 1200;
     const real* src = d.gamma + ((d.flags & 1) ? 0 : d.env * 1200);
-    for (int i = threadIdx.x; i < ng; i += blockDim.x) L.gamma[i] = src[i];
+    for (int i = threadIdx.x; i < ng; i += L.nthr) L.gamma[i] = src[i];
 }
 template <class V> __device__ __forceinline__ void stage_tables(const DevSys<typename V::real_t>& S, const V& L) {
     for (int t = 0; t < S.n_contact; t++)
-        for (int i = threadIdx.x; i < S.contact[t].nsites; i += blockDim.x) L.satom[t * S.max_contact_sites + i] = S.contact[t].atom[i];
+        for (int i = threadIdx.x; i < S.contact[t].nsites; i += L.nthr) L.satom[t * S.max_contact_sites + i] = S.contact[t].atom[i];
     if (S.n_contact == 1) stage_contact_gamma(S.contact[0], L);
+    if (S.ramam.n) for (int i = threadIdx.x; i < S.ramam.nset * S.ramam.nwell * 8; i += L.nthr) L.ramap[i] = S.ramam.params[i];
 }
 
 #define AWSEM_ON(d) ((mask >> (d).group) & 1u)
@@ -1106,7 +1158,7 @@ template <class V> __device__ __forceinline__ void build_lists(const DevSys<type
     for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) build_excl(S.excl[t], L, S.status);
     for (int t = 0; t < S.n_beta; t++) if (AWSEM_ON(S.beta[t])) build_hbond(S.beta[t], L, S.status);
     for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) build_hbond(S.pap[t], L, S.status);
-    for (int i = threadIdx.x; i < S.natoms; i += blockDim.x) L.zero_force(i);   // the builders staged their tables in the accumulators
+    for (int i = threadIdx.x; i < S.natoms; i += L.nthr) L.zero_force(i);   // the builders staged their tables in the accumulators
 }
 
 // Evaluate every term whose group is in `mask` from the current pair lists.  Forces accumulate into the view and the
@@ -1128,7 +1180,7 @@ template <bool ENERGY, bool STEP = false, class V> __device__ __forceinline__ vo
     const bool multi = S.n_contact > 1;
     const bool bar = c0 || S.n_cv > 0;   // the phases need barriers: contact passes, or a collective variable's sum before its forces
     if (c0 && multi) { stage_contact_gamma(*c0, L); __syncthreads(); }
-    Rotor rotor;
+    Rotor rotor(L.nthr);
     // phase A
     if (STEP && fused_vs) update_virtual_sites(S, L);
     if (c0) contact_density(*c0, L, satom0);
@@ -1137,10 +1189,12 @@ template <bool ENERGY, bool STEP = false, class V> __device__ __forceinline__ vo
         else term_fm<ENERGY>(S.fm[u], L, rotor.next(S.fm[u].n));
     }
     if (!STEP) {
-        for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
+        if (S.ramam.n) { if (AWSEM_ON(S.ramam)) term_rama_merged<ENERGY>(S.ramam, L, rotor.next(S.ramam.n)); }
+        else for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
         for (int u = 0; u < S.n_chi; u++) if (AWSEM_ON(S.chi[u])) term_chi<ENERGY>(S.chi[u], L, rotor.next(S.chi[u].n));
     }
     for (int u = 0; u < S.n_gauss; u++) { const GaussD<real> d = S.gauss[u]; if (d.cv && AWSEM_ON(d)) cv_sum(d, L, rotor.next(d.n)); }
+    AWSEM_ARRIVE(4);
     if (bar || STEP) __syncthreads();
     AWSEM_STAMP(S, 4);
     // phase B
@@ -1157,15 +1211,18 @@ template <bool ENERGY, bool STEP = false, class V> __device__ __forceinline__ vo
     for (int u = 0; u < S.n_helical; u++) if (AWSEM_ON(S.helical[u])) term_helical<ENERGY>(S.helical[u], L, rotor.next(S.helical[u].n));
     for (int u = 0; u < S.n_memb; u++) if (AWSEM_ON(S.memb[u])) term_memb<ENERGY>(S.memb[u], L, rotor.next(S.memb[u].n));
     if (STEP) {
-        for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
+        if (S.ramam.n) { if (AWSEM_ON(S.ramam)) term_rama_merged<ENERGY>(S.ramam, L, rotor.next(S.ramam.n)); }
+        else for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
         for (int u = 0; u < S.n_chi; u++) if (AWSEM_ON(S.chi[u])) term_chi<ENERGY>(S.chi[u], L, rotor.next(S.chi[u].n));
     }
+    AWSEM_ARRIVE(5);
     if (bar) __syncthreads();
     AWSEM_STAMP(S, 5);
     // phase C
     if (threadIdx.x < S.n_cv) L.cv[threadIdx.x] = 0;   // read for the last time in phase B; the next evaluation starts from zero
     if (c0 && !(c0->flags & 2)) contact_pairs<ENERGY>(*c0, L, satom0);
     for (int u = 0; u < S.n_beta; u++) if (AWSEM_ON(S.beta[u])) eval_beta<ENERGY>(S.beta[u], L);
+    AWSEM_ARRIVE(6);
     if (bar) __syncthreads();
     AWSEM_STAMP(S, 6);
     // phase D
@@ -1179,7 +1236,7 @@ template <bool ENERGY, bool STEP = false, class V> __device__ __forceinline__ vo
         const int* satom = L.satom + t * S.max_contact_sites;
         __syncthreads();
         stage_contact_gamma(d, L);
-        for (int i = threadIdx.x; i < d.nsites; i += blockDim.x) L.rho[i] = 0;
+        for (int i = threadIdx.x; i < d.nsites; i += L.nthr) L.rho[i] = 0;
         __syncthreads();
         contact_density(d, L, satom);
         __syncthreads();
@@ -1189,6 +1246,7 @@ template <bool ENERGY, bool STEP = false, class V> __device__ __forceinline__ vo
         __syncthreads();
         contact_chain_rule(d, L, satom);
     }
+    AWSEM_ARRIVE(7);
     __syncthreads();
     AWSEM_STAMP(S, 7);
 }
@@ -1199,9 +1257,9 @@ template <> struct LdsLayout<float> { static constexpr int pos = 16, force = 16,
 template <> struct LdsLayout<double> { static constexpr int pos = 24, force = 24, vel = 24, ref = 24; };     // three 8-byte planes each
 // what sizes the LDS image of a replica: velocities exist for the massive particles only (indexed by their position in
 // DevSys::massive), the gamma staging holds one environment (1200) or both (2400, z-dependent contact)
-struct LdsShape { int natoms, nsites, ncontact, nmassive, ngamma, ncv; };
+struct LdsShape { int natoms, nsites, ncontact, nmassive, ngamma, ncv, nramap; };
 template <class real> __host__ __device__ inline LdsShape lds_shape(const DevSys<real>& S) {
-    return LdsShape{S.natoms, S.max_contact_sites, S.n_contact, S.nmassive, S.any_zdep ? 2400 : 1200, S.n_cv};
+    return LdsShape{S.natoms, S.max_contact_sites, S.n_contact, S.nmassive, S.any_zdep ? 2400 : 1200, S.n_cv, S.ramam.n ? S.ramam.nset * S.ramam.nwell * 8 : 0};
 }
 template <class real> __host__ __device__ inline size_t lds_bytes(const LdsShape& sh, bool with_vel) {
     const int natoms = sh.natoms, nsites = sh.nsites, ncontact = sh.ncontact;
@@ -1211,12 +1269,18 @@ template <class real> __host__ __device__ inline size_t lds_bytes(const LdsShape
     b += (size_t)2 * nsites * sizeof(u64);            // rho, drho
     b += (AWSEM_NGROUPS + (size_t)sh.ncv + 6 + 8) * sizeof(u64);   // group energies, collective-variable sums, momentum sums and the mean velocities they stand for
     b += (size_t)3 * nsites * sizeof(real);           // rhov, alpha, dalpha
-    b += (size_t)sh.ngamma * sizeof(real);            // gamma staging
+    b += (size_t)(sh.ngamma + sh.nramap) * sizeof(real);   // gamma staging, Ramachandran parameter sets
     b += (size_t)(ncontact > 0 ? ncontact : 1) * nsites * sizeof(int);   // contact site -> atom
     b += (AWSEM_MAX_LISTS + 4) * sizeof(unsigned);    // list counters, flags
     return (b + 15) & ~(size_t)15;
 }
+__device__ __forceinline__ int pinned_block_size() {
+    int n = __builtin_amdgcn_readfirstlane((int)blockDim.x);
+    asm volatile("" : "+s"(n));   // opaque from here on: kept in (or spilled from) a scalar register, never reloaded
+    return n;
+}
 template <class real> __device__ inline void carve_common(ViewCommon<real>& L, unsigned char* q, const LdsShape& sh) {
+    L.nthr = pinned_block_size();
     const int nsites = sh.nsites, ncontact = sh.ncontact;
     u64* w = (u64*)q;
     L.rho = w; w += nsites; L.drho = w; w += nsites;
@@ -1228,6 +1292,7 @@ template <class real> __device__ inline void carve_common(ViewCommon<real>& L, u
     real* r = (real*)w;
     L.rhov = r; r += nsites; L.alpha = r; r += nsites; L.dalpha = r; r += nsites;
     L.gamma = r; r += sh.ngamma;
+    L.ramap = r; r += sh.nramap;
     L.satom = (int*)r;
     L.lcount = (unsigned*)(L.satom + (ncontact > 0 ? ncontact : 1) * nsites);
     L.flag = L.lcount + AWSEM_MAX_LISTS;
@@ -1263,7 +1328,7 @@ __device__ inline Lds<double> carve_lds(double, unsigned char* base, const LdsSh
 // replica state in global memory: SoA per replica, [replica][xyz][natoms]
 template <class V> __device__ inline void load_positions(const typename V::real_t* g, const V& L, int natoms) {
     typedef typename V::real_t real;
-    for (int i = threadIdx.x; i < natoms; i += blockDim.x) { L.set_pos(i, R3<real>{g[i], g[natoms + i], g[2 * natoms + i]}); L.zero_force(i); }
+    for (int i = threadIdx.x; i < natoms; i += L.nthr) { L.set_pos(i, R3<real>{g[i], g[natoms + i], g[2 * natoms + i]}); L.zero_force(i); }
 }
 
 // ------------------------------------------------------------------ evaluation kernel (energies and/or forces)
@@ -1277,13 +1342,13 @@ __global__ void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__
     L.lists = S.lists + (size_t)rep * S.list_stride;
     if (xyz_aos) {   // uniform; awsem_energy_by_group_noalloc: the caller's device buffer, converted like the host does ((real) of the double)
         const double* x = xyz_aos + (size_t)rep * 3 * natoms;
-        for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
+        for (int i = threadIdx.x; i < natoms; i += L.nthr) {
             const int o = S.orig ? S.orig[i] : i;
             L.set_pos(i, R3<real>{(real)x[3 * o], (real)x[3 * o + 1], (real)x[3 * o + 2]});
             L.zero_force(i);
         }
     } else load_positions(pos + (size_t)rep * 3 * natoms, L, natoms);
-    for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
+    for (int i = threadIdx.x; i < S.max_contact_sites; i += L.nthr) L.rho[i] = 0;
     if (threadIdx.x < AWSEM_NGROUPS) L.eg[threadIdx.x] = 0;
     if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
     stage_tables(S, L);
@@ -1295,7 +1360,7 @@ __global__ void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__
     if (f_out) {
         if (redistribute) { redistribute_forces(S, L); __syncthreads(); }
         double* f = f_out + (size_t)rep * 3 * natoms;
-        for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
+        for (int i = threadIdx.x; i < natoms; i += L.nthr) {
             const R3<real> F = L.force(i);
             const int o = S.orig ? S.orig[i] : i;
             f[3 * o] = (double)F.x; f[3 * o + 1] = (double)F.y; f[3 * o + 2] = (double)F.z;
@@ -1532,11 +1597,11 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
     real* gp = pos + (size_t)rep * 3 * natoms;
     real* gv = vel + (size_t)rep * 3 * natoms;
     load_positions(gp, L, natoms);
-    for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {   // velocities live in LDS for the massive particles only, by massive index
+    for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) {   // velocities live in LDS for the massive particles only, by massive index
         const int i = S.massive[k].atom;
         L.set_vel(k, R3<real>{gv[i], gv[natoms + i], gv[2 * natoms + i]});
     }
-    for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
+    for (int i = threadIdx.x; i < S.max_contact_sites; i += L.nthr) L.rho[i] = 0;
     const double a_d = ::exp(-friction * dt);
     const real a = (real)a_d, fs = (real)(friction == 0.0 ? dt : (1.0 - a_d) / friction);
     const real ns = (real)::sqrt(AWSEM_KB * T[rep] * (1.0 - a_d * a_d)), dtr = (real)dt;
@@ -1549,7 +1614,7 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
     const bool cmr = S.remove_cm != 0;
     if (cmr) {   // momentum of the incoming velocities: what the first step removes (L.cm[0..2]; zeroed at the carve-up, a barrier ago)
         CmAcc<real> acc;
-        for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) acc.add(M<real>::rcp(S.massive[k].inv_mass), L.vel(k));
+        for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) acc.add(M<real>::rcp(S.massive[k].inv_mass), L.vel(k));
         acc.flush(L.cm);
     }
     __syncthreads();
@@ -1574,9 +1639,10 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
         }
         if (rebuild) {
             if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
-            for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) { const int i = S.massive[k].atom; L.set_ref(i, L.pos(i)); }
+            for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) { const int i = S.massive[k].atom; L.set_ref(i, L.pos(i)); }
             __syncthreads();
             build_lists(S, L, 0xffffffffu);
+            AWSEM_ARRIVE(2);
             __syncthreads();
             AWSEM_STAMP(S, 2);
 #ifdef AWSEM_PROF
@@ -1587,11 +1653,11 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
         // (for up to two particles per lane; larger systems draw them in the integrator as before)
         real g_pre[2][3] = {{0, 0, 0}, {0, 0, 0}}, im_pre[2] = {0, 0}, ms_pre[2] = {0, 0};
         int at_pre[2] = {0, 0};
-        const bool pre = S.nmassive <= 2 * (int)blockDim.x;
+        const bool pre = S.nmassive <= 2 * L.nthr;
         if (pre) {
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                const int k = (int)threadIdx.x + q * (int)blockDim.x;
+                const int k = (int)threadIdx.x + q * L.nthr;
                 if (k < S.nmassive) {   // the particle's static record is consumed here too: noise amplitude, force factor, atom
                     const MassiveItem<real> mi = S.massive[k];
                     gauss3<real>(seed, AWSEM_STREAM_LANGEVIN, rep, step0 + s, mi.id, g_pre[q]);
@@ -1609,9 +1675,9 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
             R3<real> vcm{0, 0, 0};
             if (cmr) { const real* q = (const real*)(L.cm + 6) + cur * 4; vcm = R3<real>{q[0], q[1], q[2]}; }   // the momentum the previous step (or the launch start) left
             CmAcc<real> acc;
-            for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {   // compact list: no lane idles on a virtual site
+            for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) {   // compact list: no lane idles on a virtual site
                 const GatherItem<real> gi = S.gather[k];
-                const bool second = k >= (int)blockDim.x;
+                const bool second = k >= L.nthr;
                 real g[3], im, ms = 0;
                 int i;
                 if (pre) {
@@ -1645,21 +1711,22 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
                 if (cmr) acc.add(ms, v);
                 m = fmaxf(m, (float)dist2(x - L.refpos(i)));
             }
-            for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;   // last read in the per-site pass
+            for (int i = threadIdx.x; i < S.max_contact_sites; i += L.nthr) L.rho[i] = 0;   // last read in the per-site pass
             if (cmr) acc.flush(&L.cm[(cur ^ 1) * 3]);
             book_displacement(&L.flag[cur ^ 1], m);
         }
+        AWSEM_ARRIVE(9);
         __syncthreads();
         AWSEM_STAMP(S, 9);
     }
     compute_virtual_sites(S, L);   // the sites of the final coordinates (a third inlined copy of update_virtual_sites here tips the
     __syncthreads();               // compiler into spilling the kernarg block: __graft_entry__.build() checks for that)
     AWSEM_STAMP_FLUSH(S);
-    for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
+    for (int i = threadIdx.x; i < natoms; i += L.nthr) {
         const R3<real> x = L.pos(i);
         gp[i] = x.x; gp[natoms + i] = x.y; gp[2 * natoms + i] = x.z;
     }
-    for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {
+    for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) {
         const int i = S.massive[k].atom;
         const R3<real> v = L.vel(k);
         gv[i] = v.x; gv[natoms + i] = v.y; gv[2 * natoms + i] = v.z;
@@ -1683,8 +1750,8 @@ __global__ void awsem_minimize_kernel(const DevSys<real> S, real* __restrict__ p
     L.lists = S.lists + (size_t)rep * S.list_stride;
     real* gp = pos + (size_t)rep * 3 * natoms;
     load_positions(gp, L, natoms);
-    for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) L.set_vel(k, R3<real>{0, 0, 0});
-    for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
+    for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) L.set_vel(k, R3<real>{0, 0, 0});
+    for (int i = threadIdx.x; i < S.max_contact_sites; i += L.nthr) L.rho[i] = 0;
     stage_tables(S, L);
     if (threadIdx.x < 2) L.flag[threadIdx.x] = 0;
     __syncthreads();
@@ -1700,7 +1767,7 @@ __global__ void awsem_minimize_kernel(const DevSys<real> S, real* __restrict__ p
         const int cur = it & 1;
         if (it == 0 || __uint_as_float(L.flag[cur]) > (float)S.skin_half2) {   // uniform across the workgroup
             if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
-            for (int i = threadIdx.x; i < natoms; i += blockDim.x) L.set_ref(i, L.pos(i));
+            for (int i = threadIdx.x; i < natoms; i += L.nthr) L.set_ref(i, L.pos(i));
             __syncthreads();
             build_lists(S, L, 0xffffffffu);
             __syncthreads();
@@ -1710,7 +1777,7 @@ __global__ void awsem_minimize_kernel(const DevSys<real> S, real* __restrict__ p
         if (threadIdx.x == 0) L.flag[cur] = 0;
         {   // pass 1: the sums
             Energy eP, eF, eV;
-            for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {
+            for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) {
                 const GatherItem<real> gi = S.gather[k];
                 const int i = S.massive[k].atom;
                 R3<real> F = L.force(i);
@@ -1738,7 +1805,7 @@ __global__ void awsem_minimize_kernel(const DevSys<real> S, real* __restrict__ p
         } else { npos = 0; dt *= (real)0.5; alpha = (real)0.1; }
         {   // pass 2: velocity mixing, Euler step with the displacement clamp
             float m = 0;
-            for (int k = threadIdx.x; k < S.nmassive; k += blockDim.x) {
+            for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) {
                 const GatherItem<real> gi = S.gather[k];
                 const int i = S.massive[k].atom;
                 R3<real> F = L.force(i);
@@ -1765,7 +1832,7 @@ __global__ void awsem_minimize_kernel(const DevSys<real> S, real* __restrict__ p
         __syncthreads();
         {
             float m = 0;
-            for (int i = threadIdx.x; i < S.nvs; i += blockDim.x) {
+            for (int i = threadIdx.x; i < S.nvs; i += L.nthr) {
                 const Int4 v = S.vs[i];
                 const real w0 = S.vs_w[3 * i], w1 = S.vs_w[3 * i + 1], w2 = S.vs_w[3 * i + 2];
                 const R3<real> pa = L.pos(v.y), pb = L.pos(v.z), pc = L.pos(v.w);
@@ -1774,13 +1841,13 @@ __global__ void awsem_minimize_kernel(const DevSys<real> S, real* __restrict__ p
                 L.zero_force(v.x);
                 m = fmaxf(m, (float)dist2(x - L.refpos(v.x)));
             }
-            for (int i = threadIdx.x; i < S.nfixed; i += blockDim.x) L.zero_force(S.fixed[i]);
-            for (int i = threadIdx.x; i < S.max_contact_sites; i += blockDim.x) L.rho[i] = 0;
+            for (int i = threadIdx.x; i < S.nfixed; i += L.nthr) L.zero_force(S.fixed[i]);
+            for (int i = threadIdx.x; i < S.max_contact_sites; i += L.nthr) L.rho[i] = 0;
             book_displacement(&L.flag[cur ^ 1], m);
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < natoms; i += blockDim.x) {
+    for (int i = threadIdx.x; i < natoms; i += L.nthr) {
         const R3<real> x = L.pos(i);
         gp[i] = x.x; gp[natoms + i] = x.y; gp[2 * natoms + i] = x.z;
     }
