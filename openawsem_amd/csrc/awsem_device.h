@@ -93,8 +93,18 @@ template <class real> struct HbFn {
     real cc[5][3], g[3];
     real t1[400], t2[400], ob[20];
 };
+// Pair-list entry of the hydrogen-bond terms on the replica-resident path: everything the pair needs -- its atoms (15 bits each; the
+// term's two_theta flag in bit 15 of w0) and the coefficient -k lambda / -k gamma -- so that a walk reads one record per pair instead of
+// chasing list word -> acceptor / donor records -> table entry through three dependent loads, and terms of one shape and force group
+// (beta_term_1/2/3; pap_term_1/2) share ONE list and one walk.
+//   w0 = a1 | flag << 15 | d1 << 16,   w1 = a2 | a3 << 16,   w2 = d2 | d3 << 16
+template <class real> struct HbEntry;
+template <> struct HbEntry<float> { unsigned w0, w1, w2; float c; };
+template <> struct HbEntry<double> { unsigned w0, w1, w2, pad; double c; };
 template <class real> struct BetaD {
     static constexpr int res_slot = 3;    // acc/don records carry the residue index in .w
+    __host__ __device__ const real* table() const { return lambda; }
+    __host__ __device__ unsigned entry_flag() const { return (unsigned)two_theta; }
     int group, two_theta, nacc, ndon, nres;
     const Int4* acc;                      // a1, a2, a3, residue
     const Int4* don;                      // d1, d2, d3, residue
@@ -105,10 +115,13 @@ template <class real> struct BetaD {
     real r_ON, r_OH, inv_sNO2, inv_sHO2, cutoff2;   // inv_s*2 = 1/sigma^2
     real screen2, max_expo;               // fp32 pre-screen: r_ON^2 bound and largest Gaussian exponent evaluated
     int band_lo, band_hi;                 // lambda[q][p] == 0 whenever band_lo < q - p < band_hi (zero band around the diagonal)
-    ListSlot ls; real list_rc2;           // entry = acceptor index << 16 | donor index
+    ListSlot ls; real list_rc2;           // HbEntry records; terms of one force group with the same constants share the slot
+    int list_owner;                       // this term walks the shared list (the first of its members)
 };
 template <class real> struct PapD {
     static constexpr int res_slot = 2;    // acc/don records carry the residue index in .z
+    __host__ __device__ const real* table() const { return gamma; }
+    __host__ __device__ unsigned entry_flag() const { return 0u; }
     int group, nacc, ndon, nres;
     const Int4* acc;                      // a1, a2, residue, -
     const Int4* don;                      // d1, d2, residue, -
@@ -119,7 +132,8 @@ template <class real> struct PapD {
     real eta2, r0, d_i4, cutoff2;
     real min_arg;                         // fp32 pre-screen: switches with argument below this are treated as 0
     int band_lo, band_hi;                 // gamma[q][p] == 0 whenever band_lo < q - p < band_hi
-    ListSlot ls; real list_rc2;           // entry = acceptor index << 16 | donor index
+    ListSlot ls; real list_rc2;           // HbEntry records, shared like BetaD's
+    int list_owner;
 };
 template <class real> struct HelicalD { int group, n; const HelicalItem<real>* items; real r_ON, r_OH, inv_sNO2, inv_sHO2; };
 // table2[b][i] = (t[b][i], t[b][i+1]) for i < ntab-1: the two interpolation nodes of a bin in one aligned load

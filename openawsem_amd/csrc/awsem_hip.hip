@@ -1212,18 +1212,38 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
             d.ls = slot(cap);
             d.list_rc2 = rc2(H.excl[t].r0, amp_max(H.excl[t].atom, 1));
         }
+        // hydrogen-bond terms: HbEntry records (atoms in 15 bits).  Terms of one force group with the same constants share a list and a walk.
+        if ((S.n_beta || S.n_pap) && natoms_ > 32767) throw std::string("hydrogen-bond terms on the replica-resident path address atoms with 15 bits: at most 32767 atoms");
+        const long long ewords = (long long)(sizeof(HbEntry<real>) / sizeof(unsigned));
         for (int t = 0; t < S.n_beta; t++) {
             BetaD<real>& d = S.beta[t];
             if (d.nacc > 65535 || d.ndon > 65535) throw std::string("hydrogen-bond term: at most 65535 acceptors / donors");
-            d.ls = slot((long long)d.nacc * d.ndon);
             d.list_rc2 = rc2(std::sqrt((double)d.screen2), 0.5 * (amp_max(H.beta[t].acc_atoms, 3) + amp_max(H.beta[t].don_atoms, 3)));
         }
         for (int t = 0; t < S.n_pap; t++) {
             PapD<real>& d = S.pap[t];
             if (d.nacc > 65535 || d.ndon > 65535) throw std::string("hydrogen-bond term: at most 65535 acceptors / donors");
-            d.ls = slot((long long)d.nacc * d.ndon);
             d.list_rc2 = rc2(H.pap[t].cutoff, 0.5 * (amp_max(H.pap[t].acc_atoms, 2) + amp_max(H.pap[t].don_atoms, 2)));
         }
+        const bool share = !(getenv("AWSEM_HB_SHARE") && atoi(getenv("AWSEM_HB_SHARE")) == 0);   // 0: one list per term (A/B runs)
+        auto share_lists = [&](auto* terms, int n, auto same) {
+            for (int t = 0; t < n; t++) {
+                int first = t;
+                for (int u = 0; u < t && share; u++) if (terms[u].list_owner && same(terms[u], terms[t])) { first = u; break; }
+                if (first != t) continue;
+                long long cap = 0;
+                for (int u = t; u < n; u++) if (u == t || (share && same(terms[t], terms[u]))) cap += (long long)terms[u].nacc * terms[u].ndon;
+                if (cap > 0x7fffffffLL / ewords) throw std::string("hydrogen-bond pair lists of one replica exceed 2^31 words");
+                ListSlot ls = slot(cap * ewords);
+                ls.list_cap = (int)cap;   // in records
+                for (int u = t; u < n; u++) if (u == t || (share && same(terms[t], terms[u]))) { terms[u].ls = ls; terms[u].list_owner = u == t; }
+            }
+        };
+        share_lists(S.beta, S.n_beta, [](const BetaD<real>& a, const BetaD<real>& b) {
+            return a.group == b.group && a.r_ON == b.r_ON && a.r_OH == b.r_OH && a.inv_sNO2 == b.inv_sNO2 && a.inv_sHO2 == b.inv_sHO2 && a.cutoff2 == b.cutoff2 &&
+                   a.screen2 == b.screen2 && a.max_expo == b.max_expo; });
+        share_lists(S.pap, S.n_pap, [](const PapD<real>& a, const PapD<real>& b) {
+            return a.group == b.group && a.eta2 == b.eta2 && a.r0 == b.r0 && a.d_i4 == b.d_i4 && a.cutoff2 == b.cutoff2 && a.min_arg == b.min_arg; });
         {   // may the step kernel place the virtual sites inside the first force phase?  Only if that phase reads massive particles only
             bool ok = true;
             auto massive = [&](const std::vector<int>& atoms) { for (int a : atoms) if (a >= 0 && !(H.mass[a] > 0)) ok = false; };
@@ -1302,10 +1322,14 @@ template <class real> int Engine<real>::neighbors(int rep, int kind, int index, 
         ls = S.contact[index].ls; group = S.contact[index].group; break;
     case AWSEM_LIST_BETA:
         if (index < 0 || index >= S.n_beta) throw std::string("neighbors: no such beta term");
-        S.beta[index].list_rc2 = rc2(std::sqrt((double)S.beta[index].screen2)); ls = S.beta[index].ls; group = S.beta[index].group; break;
+        S.beta[index].list_rc2 = rc2(std::sqrt((double)S.beta[index].screen2)); ls = S.beta[index].ls; group = S.beta[index].group;
+        for (int t = 0; t < S.n_beta; t++) if (t != index) S.beta[t].nacc = S.beta[t].ndon = 0;   // the terms that share the list stay out of it
+        break;
     case AWSEM_LIST_PAP:
         if (index < 0 || index >= S.n_pap) throw std::string("neighbors: no such pap term");
-        S.pap[index].list_rc2 = rc2(Hs.pap[index].cutoff); ls = S.pap[index].ls; group = S.pap[index].group; break;
+        S.pap[index].list_rc2 = rc2(Hs.pap[index].cutoff); ls = S.pap[index].ls; group = S.pap[index].group;
+        for (int t = 0; t < S.n_pap; t++) if (t != index) S.pap[t].nacc = S.pap[t].ndon = 0;
+        break;
     default: throw std::string("neighbors: kind must be AWSEM_LIST_EXCL, _CONTACT, _BETA or _PAP");
     }
     hipLaunchKernelGGL(awsem_list_kernel<real>, dim3(nrep_), dim3(block_), lds_eval_, stream_, S, pos_, 1u << group, dcounts_);
@@ -1314,10 +1338,22 @@ template <class real> int Engine<real>::neighbors(int rep, int kind, int index, 
     check_status();
     unsigned n = 0;
     HIP_TRY(hipMemcpy(&n, dcounts_ + (size_t)rep * AWSEM_MAX_LISTS + ls.list_id, sizeof n, hipMemcpyDeviceToHost));
-    std::vector<unsigned> e(n);
-    if (n) HIP_TRY(hipMemcpy(e.data(), S.lists + (size_t)rep * S.list_stride + ls.list_off, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost));
     std::vector<std::pair<int, int>> out(n);
-    for (unsigned k = 0; k < n; k++) {
+    std::vector<unsigned> e(kind == AWSEM_LIST_BETA || kind == AWSEM_LIST_PAP ? 0 : n);
+    if (!e.empty()) HIP_TRY(hipMemcpy(e.data(), S.lists + (size_t)rep * S.list_stride + ls.list_off, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (e.empty() && n) {   // HbEntry records: the pair is named by its first acceptor and donor atoms
+        std::vector<HbEntry<real>> he(n);
+        HIP_TRY(hipMemcpy(he.data(), S.lists + (size_t)rep * S.list_stride + ls.list_off, (size_t)n * sizeof(HbEntry<real>), hipMemcpyDeviceToHost));
+        const int nacc = kind == AWSEM_LIST_BETA ? dsys_.beta[index].nacc : dsys_.pap[index].nacc, ndon = kind == AWSEM_LIST_BETA ? dsys_.beta[index].ndon : dsys_.pap[index].ndon;
+        std::vector<Int4> acc(nacc), don(ndon);
+        HIP_TRY(hipMemcpy(acc.data(), kind == AWSEM_LIST_BETA ? dsys_.beta[index].acc : dsys_.pap[index].acc, sizeof(Int4) * nacc, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(don.data(), kind == AWSEM_LIST_BETA ? dsys_.beta[index].don : dsys_.pap[index].don, sizeof(Int4) * ndon, hipMemcpyDeviceToHost));
+        std::map<int, int> ia, id;
+        for (int i = 0; i < nacc; i++) ia[acc[i].x] = i;
+        for (int i = 0; i < ndon; i++) id[don[i].x] = i;
+        for (unsigned k = 0; k < n; k++) out[k] = {ia.at((int)(he[k].w0 & 0x7fffu)), id.at((int)((he[k].w0 >> 16) & 0x7fffu))};
+    }
+    for (unsigned k = 0; k < n && !e.empty(); k++) {
         if (kind == AWSEM_LIST_CONTACT) out[k] = {(int)(e[k] & 0x3ff), (int)((e[k] >> 10) & 0x3ff)};
         else out[k] = {(int)(e[k] >> 16), (int)(e[k] & 0xffff)};
         if (kind == AWSEM_LIST_EXCL && !to_orig_.empty()) out[k] = {to_orig_[out[k].first], to_orig_[out[k].second]};

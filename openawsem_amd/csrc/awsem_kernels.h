@@ -647,6 +647,21 @@ __device__ __forceinline__ void list_append(unsigned* __restrict__ e, unsigned* 
     }
 }
 
+// the same for the hydrogen-bond lists' records
+template <class real> __device__ __forceinline__ void list_append_entry(HbEntry<real>* __restrict__ e, unsigned* cnt, int cap, int* status, bool pass, const HbEntry<real>& ent) {
+    const u64 m = __ballot(pass);
+    if (m == 0) return;   // wave-uniform
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(cnt, (unsigned)__popcll(m));
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+    const unsigned off = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (pass) {
+        if (base + off < (unsigned)cap) e[base + off] = ent;
+        else *status = 1;
+    }
+}
+
 #define AWSEM_WAVE_VARS const int nw = L.nthr >> 6, wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63
 // list chunks of 64 entries are dealt to the waves round-robin, starting at a different wave for every list so
 // that short lists do not all land on wave 0
@@ -964,7 +979,7 @@ template <class real> __device__ __forceinline__ real hb_fn_value(const HbFn<rea
 template <class V, class Desc> __device__ __forceinline__ void build_hbond(const Desc& d, const V& L, int* status) {
     typedef typename V::real_t real;
     AWSEM_WAVE_VARS;
-    unsigned* e = L.lists + d.ls.list_off;
+    HbEntry<real>* e = (HbEntry<real>*)(L.lists + d.ls.list_off);
     unsigned* cnt = &L.lcount[d.ls.list_id];
     const int resw = Desc::res_slot;   // which Int4 component carries the residue index
     // staged words: screening atom (a1 / d1) | residue << 16
@@ -1006,20 +1021,33 @@ template <class V, class Desc> __device__ __forceinline__ void build_hbond(const
                 const int dres = (int)(D[u] >> 16), dq = dres - ares;
                 const real r2 = dist2(pa - L.pos((int)(D[u] & 0xffffu)));
                 pass[u] = pass[u] && r2 < d.list_rc2 && (dq <= d.band_lo || dq >= d.band_hi);
-                if (pass[u]) {
-                    if (d.fn) pass[u] = hb_fn_value(*d.fn, dres, ares) != (real)0;   // uniform branch
-                    else { const unsigned bit = (unsigned)(dres * d.nres + ares); pass[u] = (nz[bit >> 5] >> (bit & 31)) & 1u; }
+                HbEntry<real> ent;
+                ent.w0 = ent.w1 = ent.w2 = 0u; ent.c = (real)0;
+                if (pass[u]) {   // a surviving pair's record: the atoms of both sides and the coefficient, exactly as the pair bodies used to look them up
+                    if (d.fn) { const real v = hb_fn_value(*d.fn, dres, ares); pass[u] = v != (real)0; ent.c = d.fn->scale * v; }   // uniform branch
+                    else {
+                        const unsigned bit = (unsigned)(dres * d.nres + ares);
+                        pass[u] = (nz[bit >> 5] >> (bit & 31)) & 1u;
+                        if (pass[u]) ent.c = d.table()[(size_t)dres * d.nres + ares];
+                    }
+                    if (pass[u]) {
+                        const Int4 A = d.acc[ia], Dn = d.don[q[u]];
+                        ent.w0 = (unsigned)A.x | (d.entry_flag() << 15) | ((unsigned)Dn.x << 16);
+                        if (resw == 3) { ent.w1 = ((unsigned)A.y & 0xffffu) | ((unsigned)A.z << 16); ent.w2 = ((unsigned)Dn.y & 0xffffu) | ((unsigned)Dn.z << 16); }
+                        else { ent.w1 = (unsigned)A.y & 0xffffu; ent.w2 = (unsigned)Dn.y & 0xffffu; }
+                    }
                 }
+                list_append_entry(e, cnt, d.ls.list_cap, status, pass[u], ent);
             }
-#pragma unroll
-            for (int u = 0; u < U; u++) list_append(e, cnt, d.ls.list_cap, status, pass[u], ((unsigned)ia << 16) | (unsigned)q[u]);
         }
     }
     __syncthreads();
 }
 
 // one (acceptor, donor) pair of a beta term; shared by the pair-list walk below and the cell-list rows (awsem_cell.h)
-template <bool ENERGY, class V> __device__ __forceinline__ void beta_pair(const BetaD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e) {
+// LISTED: the pair comes from an HbEntry record, which carries its coefficient and the two_theta flag of its term
+template <bool ENERGY, bool LISTED = false, class V> __device__ __forceinline__ void beta_pair(const BetaD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e,
+                                                                                           typename V::real_t c_listed = 0, bool two_theta_listed = false) {
     typedef typename V::real_t real;
     const R3<real> po = L.pos(A.x), a = po - L.pos(D.x);
     const real r1s = dist2(a);
@@ -1030,9 +1058,9 @@ template <bool ENERGY, class V> __device__ __forceinline__ void beta_pair(const 
     const real da = r1s * i1 - d.r_ON, db = r2s * i2 - d.r_OH;
     const real ex1 = (real)0.5 * (da * da * d.inv_sNO2 + db * db * d.inv_sHO2);
     if (ex1 > d.max_expo) return;
-    const real c = d.fn ? d.fn->scale * hb_fn_value(*d.fn, D.w, A.w) : d.lambda[(size_t)D.w * d.nres + A.w];   // -k * lambda[don_res][acc_res]
+    const real c = LISTED ? c_listed : (d.fn ? d.fn->scale * hb_fn_value(*d.fn, D.w, A.w) : d.lambda[(size_t)D.w * d.nres + A.w]);   // -k * lambda[don_res][acc_res]
     const real th1 = M<real>::exp(-ex1), g1 = -th1 * da * d.inv_sNO2, g2 = -th1 * db * d.inv_sHO2;
-    if (!d.two_theta) {
+    if (!(LISTED ? two_theta_listed : d.two_theta != 0)) {
         if (ENERGY) e += (double)(c * th1);
         L.pair_force(A.x, D.x, a.x, a.y, a.z, -c * g1 * i1);
         L.pair_force(A.x, D.y, b.x, b.y, b.z, -c * g2 * i2);
@@ -1053,16 +1081,19 @@ template <bool ENERGY, class V> __device__ __forceinline__ void eval_beta(const 
     AWSEM_WAVE_VARS;
     Energy e;
     const ListView lv = list_view(L, d.ls);
+    const HbEntry<typename V::real_t>* ent = (const HbEntry<typename V::real_t>*)lv.e;
     AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id) {
         const int idx = c0 + lane;
         if (idx >= lv.count) continue;
-        const unsigned ent = lv.e[idx];
-        beta_pair<ENERGY>(d, L, d.acc[ent >> 16], d.don[ent & 0xffff], e);
+        const HbEntry<typename V::real_t> E = ent[idx];
+        const Int4 A{(int)(E.w0 & 0x7fffu), (int)(E.w1 & 0xffffu), (int)(E.w1 >> 16), 0}, D{(int)((E.w0 >> 16) & 0x7fffu), (int)(E.w2 & 0xffffu), (int)(E.w2 >> 16), 0};
+        beta_pair<ENERGY, true>(d, L, A, D, e, E.c, ((E.w0 >> 15) & 1u) != 0);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
 
-template <bool ENERGY, class V> __device__ __forceinline__ void pap_pair(const PapD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e) {
+template <bool ENERGY, bool LISTED = false, class V> __device__ __forceinline__ void pap_pair(const PapD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e,
+                                                                                          typename V::real_t c_listed = 0) {
     typedef typename V::real_t real;
     const real one = (real)1;
     const R3<real> a1 = L.pos(A.x), a = a1 - L.pos(D.x);
@@ -1077,7 +1108,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void pap_pair(const P
     const real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s);
     const real arg2 = d.eta2 * (d.r0 - r2s * i2);
     if (arg2 < d.min_arg) return;
-    const real c = d.fn ? d.fn->scale * hb_fn_value(*d.fn, D.z, A.z) : d.gamma[(size_t)D.z * d.nres + A.z];   // -k * gamma[don_res][acc_res]
+    const real c = LISTED ? c_listed : (d.fn ? d.fn->scale * hb_fn_value(*d.fn, D.z, A.z) : d.gamma[(size_t)D.z * d.nres + A.z]);   // -k * gamma[don_res][acc_res]
     const real s1 = sigmoid(d.eta2 * (d.r0 - r1s * i1)), s2 = sigmoid(arg2), s3 = sigmoid(arg3);
     if (ENERGY) e += (double)(c * s1 * s2 * s3);
     L.pair_force(A.x, D.x, a.x, a.y, a.z, c * d.eta2 * s1 * (one - s1) * s2 * s3 * i1);
@@ -1088,11 +1119,13 @@ template <bool ENERGY, class V> __device__ __forceinline__ void eval_pap(const P
     AWSEM_WAVE_VARS;
     Energy e;
     const ListView lv = list_view(L, d.ls);
+    const HbEntry<typename V::real_t>* ent = (const HbEntry<typename V::real_t>*)lv.e;
     AWSEM_LIST_CHUNKS(c0, lv.count, d.ls.list_id) {
         const int idx = c0 + lane;
         if (idx >= lv.count) continue;
-        const unsigned ent = lv.e[idx];
-        pap_pair<ENERGY>(d, L, d.acc[ent >> 16], d.don[ent & 0xffff], e);
+        const HbEntry<typename V::real_t> E = ent[idx];
+        const Int4 A{(int)(E.w0 & 0x7fffu), (int)(E.w1 & 0xffffu), 0, 0}, D{(int)((E.w0 >> 16) & 0x7fffu), (int)(E.w2 & 0xffffu), 0, 0};
+        pap_pair<ENERGY, true>(d, L, A, D, e, E.c);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
@@ -1221,14 +1254,14 @@ template <bool ENERGY, bool STEP = false, class V> __device__ __forceinline__ vo
     // phase C
     if (threadIdx.x < S.n_cv) L.cv[threadIdx.x] = 0;   // read for the last time in phase B; the next evaluation starts from zero
     if (c0 && !(c0->flags & 2)) contact_pairs<ENERGY>(*c0, L, satom0);
-    for (int u = 0; u < S.n_beta; u++) if (AWSEM_ON(S.beta[u])) eval_beta<ENERGY>(S.beta[u], L);
+    for (int u = 0; u < S.n_beta; u++) if (AWSEM_ON(S.beta[u]) && S.beta[u].list_owner) eval_beta<ENERGY>(S.beta[u], L);   // one walk per shared list
     AWSEM_ARRIVE(6);
     if (bar) __syncthreads();
     AWSEM_STAMP(S, 6);
     // phase D
     if (c0) contact_chain_rule(*c0, L, satom0);
     for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) eval_excl<ENERGY>(S.excl[t], L);
-    for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) eval_pap<ENERGY>(S.pap[t], L);
+    for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t]) && S.pap[t].list_owner) eval_pap<ENERGY>(S.pap[t], L);
     // further contact terms (e.g. a standalone burial term next to the contact term) reuse the density scratch
     for (int t = first + 1; first >= 0 && t < S.n_contact; t++) {
         const ContactD<real>& d = S.contact[t];
