@@ -89,25 +89,39 @@ def _measured_valu(args, folded):
     if args.workload != "1r69" or args.replicas != 1024 or args.md_steps != 50 or args.precision != "fp32":
         return None, None
     natural = lambda f: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(f))]
-    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_sq.txt")), key=natural)
-             if f.endswith("_folded_pmc_sq.txt") == bool(folded)]
+    name = re.compile(r"r\d+_v\d+_folded_pmc_sq\.txt$" if folded else r"r\d+_v\d+_pmc_sq\.txt$")   # the 1r69 bench workload only (not *_t0958_*, *_2xov_*)
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_sq.txt")), key=natural) if name.match(os.path.basename(f))]
     if not files:
         return None, None
+    rows = {}
     for line in open(files[-1]):
-        if line.startswith("SQ_INSTS_VALU "):
-            return float(line.split()[1]), os.path.relpath(files[-1], ROOT)
-    return None, None
+        t = line.split()
+        if len(t) >= 2:
+            try:
+                rows[t[0]] = float(t[1])
+            except ValueError:
+                pass
+    if "SQ_INSTS_VALU" not in rows:
+        return None, None
+    return rows, os.path.relpath(files[-1], ROOT)
 
 
 def _valu_view(args, folded, kernel_ms):
     """The issue-rate view of the step kernel: a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles, a CU has 4 SIMDs
     and holds R / 256 replicas, 2.4 GHz; busy_frac = VALU issue cycles per CU per MD step / CU cycles per MD step."""
-    valu, src = _measured_valu(args, folded)
-    if valu is None:
+    rows, src = _measured_valu(args, folded)
+    if rows is None:
         return None
+    valu = rows["SQ_INSTS_VALU"]
+    per_cu = args.replicas / 256.0
     cu_cycles_per_step = kernel_ms * 1e-3 / args.md_steps * 2.4e9
-    return {"insts_per_replica_step": valu, "busy_frac": (args.replicas / 256.0) * valu * 4.0 / 4.0 / cu_cycles_per_step,
-            "source": src + " (rocprofv3 --pmc SQ_INSTS_VALU)"}
+    out = {"insts_per_replica_step": valu, "busy_frac": per_cu * valu * 4.0 / 4.0 / cu_cycles_per_step,
+           "source": src + " (rocprofv3 --pmc SQ_INSTS_VALU)", "clock_ghz_assumed": 2.4}
+    ghz = rows.get("DERIVED_CLOCK_GHZ")
+    if ghz:   # the clock the chip actually held under this kernel (GRBM_GUI_ACTIVE of the same counter pass): the 2.4 GHz figure is the boost ceiling
+        out["clock_ghz_measured"] = ghz
+        out["busy_frac_at_measured_clock"] = per_cu * valu * 4.0 / 4.0 / (kernel_ms * 1e-3 / args.md_steps * ghz * 1e9)
+    return out
 
 
 def main():
