@@ -98,7 +98,9 @@ enum {
     AWSEM_CONTACT_NOCUTOFF = 4,     /* burial_term never calls setNonbondedMethod -> NoCutoff */
     AWSEM_CONTACT_INDEX_BASED = 16, /* index_based_contact_term contactTerms.py:668-876: gamma is [3][nsites][nsites] and burial_gamma
                                        [nsites][3], both by site (= residue) index; the pair (i < j) reads gamma[kind][i][j];
-                                       restype is ignored; not combinable with the other flags */
+                                       restype is ignored; with AWSEM_CONTACT_ZDEP (:812-831) gamma is [2][3][nsites][nsites] -- the water
+                                       tables, then the membrane tables -- blended per pair with alpha_i alpha_j; not combinable with
+                                       BURIAL_ONLY / MEMBRANE_BURIAL */
     AWSEM_CONTACT_MEMBRANE_BURIAL = 8  /* hybrid_contact_term contactTerms.py:1283-1289: burial_gamma is [water, membrane][20][3] and
                                           the wells of site i are blended with (1 - alpha_i, alpha_i); needs AWSEM_CONTACT_ZDEP */
 };

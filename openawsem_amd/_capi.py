@@ -203,7 +203,7 @@ class Context:
         bg = None if burial_gamma is None else _f64(burial_gamma).reshape(-1)
         n = len(a)
         if int(flags) & 16:      # index based: tables by site
-            assert g is not None and len(g) == 3 * n * n and (bg is None or len(bg) == 3 * n)
+            assert g is not None and len(g) == (6 if int(flags) & 1 else 3) * n * n and (bg is None or len(bg) == 3 * n)   # z-dependent: water and membrane sets
         else:
             assert (g is None or len(g) == 2400) and (bg is None or len(bg) == (120 if int(flags) & 8 else 60))
         assert len(dp) == 20

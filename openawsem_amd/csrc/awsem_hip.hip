@@ -1970,15 +1970,15 @@ int awsem_add_contact(awsem_handle h, int group, int nsites, const int32_t* atom
     if ((flags & AWSEM_CONTACT_MEMBRANE_BURIAL) && (!(flags & AWSEM_CONTACT_ZDEP) || !bgamma))
         return fail(AWSEM_EINVAL, "add_contact: membrane burial wells need the z-dependent variant and a [2][20][3] burial table");
     const bool indexed = flags & AWSEM_CONTACT_INDEX_BASED;
-    if (indexed && (flags & (AWSEM_CONTACT_ZDEP | AWSEM_CONTACT_MEMBRANE_BURIAL | AWSEM_CONTACT_BURIAL_ONLY)))
-        return fail(AWSEM_EINVAL, "add_contact: the index-based variant has one environment and its own burial table");
+    if (indexed && (flags & (AWSEM_CONTACT_MEMBRANE_BURIAL | AWSEM_CONTACT_BURIAL_ONLY)))
+        return fail(AWSEM_EINVAL, "add_contact: the index-based variant has its own burial table and no burial-only form");
     for (int i = 0; i < nsites; i++) if (restype[i] < 0 || restype[i] >= 20) return fail(AWSEM_EINVAL, "add_contact: residue type out of range 0..19");
     HContact c;
     c.group = group; c.env = env; c.min_seq_sep = min_seq_sep; c.flags = flags; c.has_burial = bgamma != nullptr;
     c.atom = vec(atom, nsites); c.restype = vec(restype, nsites); c.resid = vec(resid, nsites); c.chain = vec(chain, nsites);
     memcpy(c.p, dparams, sizeof c.p);
-    if (indexed) {   // tables by site index: [3][nsites][nsites] and [nsites][3]
-        c.gamma = vec(gamma, 3 * (size_t)nsites * nsites);
+    if (indexed) {   // tables by site index: [3][nsites][nsites] ([2][3][nsites][nsites] for the z-dependent blend: water, membrane) and [nsites][3]
+        c.gamma = vec(gamma, ((flags & AWSEM_CONTACT_ZDEP) ? 6 : 3) * (size_t)nsites * nsites);
         c.bgamma = bgamma ? vec(bgamma, 3 * (size_t)nsites) : std::vector<double>(3 * (size_t)nsites, 0.0);
         if (c.gamma.empty()) c.gamma.assign(3, 0.0);
         if (c.bgamma.empty()) c.bgamma.assign(3, 0.0);

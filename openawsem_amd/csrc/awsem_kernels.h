@@ -853,15 +853,17 @@ template <bool ENERGY, class V> __device__ __forceinline__ void contact_single(c
 template <class real> struct PairTerms { real E, dEdr, dEdsw, MW; };
 // INDEXED (index_based_contact_term): g0 is the global [3][nsites][nsites] table and ty = site_i * nsites + site_j.
 template <bool INDEXED = false, class real> __device__ __forceinline__ PairTerms<real> contact_pair_math(const ContactD<real>& d, const real* g0, int ty, real r, real sw, real aa) {
-    const real* g1 = g0 + 1200;
+    // one environment is three planes (direct, protein, water) of 400 type pairs, or of nsites^2 site pairs (INDEXED); the membrane
+    // environment of a z-dependent term lies behind the water one
     const int plane = INDEXED ? d.nsites * d.nsites : 400;
+    const real* g1 = g0 + 3 * plane;
     const real one = (real)1;
     const real s1 = sigmoid(d.eta2 * (r - d.rmin)), s2 = sigmoid(d.eta2 * (d.rmax - r));
     const real s3 = sigmoid(d.eta2 * (r - d.rminII)), s4 = sigmoid(d.eta2 * (d.rmaxII - r));
     const real th1 = s1 * s2, dth1 = d.eta2 * th1 * (s2 - s1);
     const real th2 = s3 * s4, dth2 = d.eta2 * th2 * (s4 - s3);
     PairTerms<real> o;
-    if (INDEXED || !(d.flags & 1)) {
+    if (!(d.flags & 1)) {
         const real gd = g0[ty], gp = g0[plane + ty], gw = g0[2 * plane + ty];
         const real med = sw * gw + (one - sw) * gp;
         o.E = -d.k * (gd * th1 + th2 * med);
@@ -869,13 +871,13 @@ template <bool INDEXED = false, class real> __device__ __forceinline__ PairTerms
         o.dEdsw = -d.k * th2 * (gw - gp);
         o.MW = 0;
     } else {
-        const real med0 = sw * g0[800 + ty] + (one - sw) * g0[400 + ty];
-        const real med1 = sw * g1[800 + ty] + (one - sw) * g1[400 + ty];
+        const real med0 = sw * g0[2 * plane + ty] + (one - sw) * g0[plane + ty];
+        const real med1 = sw * g1[2 * plane + ty] + (one - sw) * g1[plane + ty];
         const real W = -d.k * (g0[ty] * th1 + th2 * med0), Mm = -d.k * (g1[ty] * th1 + th2 * med1);
         const real dW = -d.k * (g0[ty] * dth1 + dth2 * med0), dM = -d.k * (g1[ty] * dth1 + dth2 * med1);
         o.E = (one - aa) * W + aa * Mm;
         o.dEdr = (one - aa) * dW + aa * dM;
-        o.dEdsw = -d.k * th2 * ((one - aa) * (g0[800 + ty] - g0[400 + ty]) + aa * (g1[800 + ty] - g1[400 + ty]));
+        o.dEdsw = -d.k * th2 * ((one - aa) * (g0[2 * plane + ty] - g0[plane + ty]) + aa * (g1[2 * plane + ty] - g1[plane + ty]));
         o.MW = Mm - W;
     }
     return o;

@@ -186,11 +186,11 @@ def index_based_contact_term(oa, gamma_folder="ff_contact", k_contact=4.184, z_d
     """Contact term whose direct / water / protein gammas are nres x nres tables by residue index and whose burial wells are
     per residue (reference contactTerms.py:668-876): `gamma_folder` holds direct.dat, water.dat, protein.dat (nres x nres)
     and burial.dat (nres x 3); with inMembrane the pair tables come from *_mem.dat (766-773).  A pair reads
-    gamma[lower residue][upper residue].  The z-dependent blend of two index tables is not built."""
+    gamma[lower residue][upper residue].  z_dependent=True (812-831) blends the water tables (*.dat) and the membrane tables
+    (*_mem.dat) of a pair with alpha_i alpha_j, alpha(z) = 0.5 tanh(10 (z - center + z_m)) + 0.5 tanh(10 (z_m - (z - center)));
+    the burial wells stay those of burial.dat."""
     if periodic or getattr(oa, "periodic", False):
         raise NotImplementedError("periodic contact terms are not supported by the MI355X AWSEM engine")
-    if z_dependent:
-        raise NotImplementedError("index_based_contact_term(z_dependent=True) is not supported by the MI355X AWSEM engine")
     if isinstance(k_contact, (float, int)):
         k_contact = k_contact * oa.k_awsem
     elif _u.is_quantity(k_contact):
@@ -199,14 +199,14 @@ def index_based_contact_term(oa, gamma_folder="ff_contact", k_contact=4.184, z_d
         raise TypeError(f"Unknown input, {k_contact}, {type(k_contact)}")
     if _u.is_quantity(membrane_center):
         membrane_center = membrane_center.value_in_unit(_u.nanometer)
-    suffix = "_mem" if inMembrane else ""
     n = oa.nres
     tables = []
-    for name in ("direct", "protein", "water"):                 # this package's plane order
-        t = np.loadtxt(os.path.join(gamma_folder, f"{name}{suffix}.dat"))
-        if t.shape != (n, n):
-            raise ValueError(f"{gamma_folder}/{name}{suffix}.dat: expected a {n} x {n} table, found {t.shape}")
-        tables.append(t)
+    for suffix in (("", "_mem") if z_dependent else ("_mem",) if inMembrane else ("",)):   # z-dependent: water tables, then membrane tables
+        for name in ("direct", "protein", "water"):                 # this package's plane order
+            t = np.loadtxt(os.path.join(gamma_folder, f"{name}{suffix}.dat"))
+            if t.shape != (n, n):
+                raise ValueError(f"{gamma_folder}/{name}{suffix}.dat: expected a {n} x {n} table, found {t.shape}")
+            tables.append(t)
     f = ContactForce()
     f.atom, f.restype, f.resid, f.chain = _sites(oa)
     rid = np.asarray(f.resid)
@@ -219,7 +219,7 @@ def index_based_contact_term(oa, gamma_folder="ff_contact", k_contact=4.184, z_d
         f.burial_gamma = b[rid]
     f.env = 0
     f.min_seq_sep = 10
-    f.flags = CONTACT_INDEX_BASED
+    f.flags = CONTACT_INDEX_BASED | (CONTACT_ZDEP if z_dependent else 0)
     f.cutoff = 1.0
     f.dparams[:] = [k_contact, r_min, .65, .65, .95, 50, 7.0, 2.6, f.cutoff, 4.0,
                     0.0, 3.0, 6.0, 3.0, 6.0, 9.0, 10, z_m, membrane_center, k_contact]

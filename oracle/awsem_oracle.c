@@ -218,8 +218,9 @@ int awsem_oracle_add_contact(ctx_t* c, int group, int nsites, const int* atom, c
     memcpy(t->p, dparams, 20 * sizeof(double));
     t->has_burial = bgamma != NULL;
     if (flags & 16) {   /* index_based_contact_term: tables by site index */
-        if (flags & (1 | 2 | 8)) return fail(-1, "add_contact: the index-based variant has one environment and its own burial table");
-        t->gamma_idx = dup_mem(gamma, 3 * (size_t)nsites * nsites * sizeof(double));
+        if (flags & (2 | 8)) return fail(-1, "add_contact: the index-based variant has its own burial table and no burial-only form");
+        /* [3][n][n], or [2][3][n][n] (water, membrane) for the z-dependent blend, contactTerms.py:820-831 */
+        t->gamma_idx = dup_mem(gamma, ((flags & 1) ? 6 : 3) * (size_t)nsites * nsites * sizeof(double));
         if (bgamma) t->bgamma_idx = dup_mem(bgamma, 3 * (size_t)nsites * sizeof(double));
         return add_term(c, T_CONTACT, t);
     }
@@ -628,7 +629,22 @@ static double eval_contact(const contact_t* t, const double* x, double* f) {
         double dsi = -0.5 * eta_s * (1 - ti * ti), dsj = -0.5 * eta_s * (1 - tj * tj);
         int ty = t->restype[i] * 20 + t->restype[j];
         double E = 0, dEdr = 0, dEdsw = 0;
-        if (t->flags & 16) {   /* gamma_ijm(0, resId1, resId2) etc., contactTerms.py:853-860 */
+        if ((t->flags & 16) && zdep) {   /* water_part / membrane_part from gamma_ijm(0 / 1, resId1, resId2), contactTerms.py:820-831 */
+            const size_t n2 = (size_t)n * n, ij = (size_t)i * n + j;
+            const double *g0 = t->gamma_idx, *g1 = t->gamma_idx + 3 * n2;
+            double W = -kc * (g0[ij] * th1 + th2 * (sw * g0[2 * n2 + ij] + (1 - sw) * g0[n2 + ij]));
+            double M = -kc * (g1[ij] * th1 + th2 * (sw * g1[2 * n2 + ij] + (1 - sw) * g1[n2 + ij]));
+            double dW = -kc * (g0[ij] * dth1 + dth2 * (sw * g0[2 * n2 + ij] + (1 - sw) * g0[n2 + ij]));
+            double dM = -kc * (g1[ij] * dth1 + dth2 * (sw * g1[2 * n2 + ij] + (1 - sw) * g1[n2 + ij]));
+            double aa = alpha[i] * alpha[j];
+            E = (1 - aa) * W + aa * M;
+            dEdr = (1 - aa) * dW + aa * dM;
+            dEdsw = (1 - aa) * (-kc * th2 * (g0[2 * n2 + ij] - g0[n2 + ij])) + aa * (-kc * th2 * (g1[2 * n2 + ij] - g1[n2 + ij]));
+            if (f) {
+                f[3 * t->atom[i] + 2] -= (M - W) * dalpha[i] * alpha[j];
+                f[3 * t->atom[j] + 2] -= (M - W) * alpha[i] * dalpha[j];
+            }
+        } else if (t->flags & 16) {   /* gamma_ijm(0, resId1, resId2) etc., contactTerms.py:853-860 */
             const size_t n2 = (size_t)n * n, ij = (size_t)i * n + j;
             double gd = t->gamma_idx[ij], gp = t->gamma_idx[n2 + ij], gw = t->gamma_idx[2 * n2 + ij];
             E = -kc * (gd * th1 + th2 * (sw * gw + (1 - sw) * gp));

@@ -126,7 +126,19 @@ def test_gpu_matches_oracle(tmp_path, precision, etol, ftol, cell, water_pair_pa
 
 
 # ------------------------------------------------------------------ index_based_contact_term
-def _index_folder(tmp_path, oa, from_types=None, seed=11, membrane=False):
+def _index_folder_zdep(tmp_path, oa, from_types=None):
+    """Both table sets of the z-dependent blend in one folder: *.dat (water) and *_mem.dat (membrane)."""
+    _index_folder(tmp_path, oa, from_types=from_types, seed=11)
+    if from_types is None:
+        return _index_folder(tmp_path, oa, seed=12, membrane=True, keep_burial=True)
+    folder = tmp_path / "ff_contact"
+    ty = np.asarray(from_types.restype)
+    for plane, name in enumerate(("direct", "protein", "water")):
+        np.savetxt(folder / f"{name}_mem.dat", from_types.gamma[1, plane][np.ix_(ty, ty)])
+    return str(folder)
+
+
+def _index_folder(tmp_path, oa, from_types=None, seed=11, membrane=False, keep_burial=False):
     """ff_contact/ with nres x nres tables: random symmetric ones, or the type tables of a contact_term spread over the
     residues (gamma[type_i][type_j]), for which the index-based term must reproduce that contact term."""
     folder = tmp_path / "ff_contact"
@@ -138,7 +150,8 @@ def _index_folder(tmp_path, oa, from_types=None, seed=11, membrane=False):
         for name in ("direct", "protein", "water"):
             t = rng.normal(0.0, 0.7, (n, n))
             np.savetxt(folder / f"{name}{suffix}.dat", (t + t.T) / 2)
-        np.savetxt(folder / "burial.dat", rng.normal(0.0, 0.7, (n, 3)))
+        if not keep_burial:
+            np.savetxt(folder / "burial.dat", rng.normal(0.0, 0.7, (n, 3)))
     else:
         ty = np.asarray(from_types.restype)
         for plane, name in enumerate(("direct", "protein", "water")):
@@ -155,10 +168,10 @@ def test_index_based_factory(tmp_path, capsys):
     assert f.getForceGroup() == 22 and f.gamma.shape == (3, n, n) and f.burial_gamma.shape == (n, 3) and f.min_seq_sep == 10
     assert np.array_equal(f.gamma[2], np.loadtxt(f"{folder}/water.dat")) and np.array_equal(f.gamma[1], np.loadtxt(f"{folder}/protein.dat"))
     assert contactTerms.index_based_contact_term(oa, gamma_folder=folder, burialPartOn=False, forceGroup=5).burial_gamma is None
-    with pytest.raises(NotImplementedError):
-        contactTerms.index_based_contact_term(oa, gamma_folder=folder, z_dependent=True)
     with pytest.raises(OSError):
-        contactTerms.index_based_contact_term(oa, gamma_folder=folder, inMembrane=True)       # *_mem.dat are read then (766-773)
+        contactTerms.index_based_contact_term(oa, gamma_folder=folder, z_dependent=True)      # *_mem.dat are read as well (766-773)
+    with pytest.raises(OSError):
+        contactTerms.index_based_contact_term(oa, gamma_folder=folder, inMembrane=True)
     np.savetxt(f"{folder}/direct.dat", np.zeros((n - 1, n)))
     with pytest.raises(ValueError):
         contactTerms.index_based_contact_term(oa, gamma_folder=folder)
@@ -215,3 +228,73 @@ def test_index_based_gpu_matches_oracle_and_the_golden_contact_column(tmp_path, 
         fg, fc = gpu.forces(redistribute=False), cpu.forces(redistribute=False)
         assert np.abs(fg - fc).max() <= ftol * np.abs(fc).max() + (5e-3 if precision == 0 and cell == "0" else 1e-7 if precision else 1e-5)
         gpu.close()
+
+
+# ------------------------------------------------------------------ index_based_contact_term(z_dependent=True), reference :812-831
+def test_index_based_z_dependent_factory(tmp_path, capsys):
+    oa, _, _ = golden_system("1ubq")
+    folder = _index_folder_zdep(tmp_path, oa)
+    f = contactTerms.index_based_contact_term(oa, gamma_folder=folder, z_dependent=True, z_m=1.2, membrane_center=0.3 * u.nanometer)
+    n = oa.nres
+    assert f.gamma.shape == (6, n, n) and f.flags == contactTerms.CONTACT_INDEX_BASED | contactTerms.CONTACT_ZDEP
+    assert np.array_equal(f.gamma[0], np.loadtxt(f"{folder}/direct.dat")) and np.array_equal(f.gamma[5], np.loadtxt(f"{folder}/water_mem.dat"))
+    assert f.dparams[17] == 1.2 and abs(f.dparams[18] - 0.3) < 1e-12 and f.dparams[16] == 10
+
+
+def test_index_based_z_dependent_reduces_to_the_z_dependent_contact_term(tmp_path, oracle_api, capsys):
+    """Index tables spread from the type tables of contact_term(z_dependent=True) must give that term back (energy and forces,
+    alpha taking its whole range over the sites); far outside the slab the blend is the water tables alone, i.e. the plain
+    index-based term, which reproduces the golden Contact column (test above)."""
+    oa, traj, _ = golden_system("1ubq")
+    plain = contactTerms.contact_term(oa, z_dependent=True, z_m=1.0)
+    indexed = contactTerms.index_based_contact_term(oa, gamma_folder=_index_folder_zdep(tmp_path, oa, from_types=plain), z_dependent=True, z_m=1.0)
+    water_only = contactTerms.index_based_contact_term(oa, gamma_folder=str(tmp_path / "ff_contact"))
+    a = awsem_oracle.make_context(_system_of(oa, plain), n_replicas=1)
+    b = awsem_oracle.make_context(_system_of(oa, indexed), n_replicas=1)
+    c = awsem_oracle.make_context(_system_of(oa, water_only), n_replicas=1)
+    for frame in (0, 9):
+        x = _centred(traj[frame], oa)
+        a.set_positions(x, replica=0)
+        b.set_positions(x, replica=0)
+        ea, eb = a.energy_by_group()[0, 22], b.energy_by_group()[0, 22]
+        assert abs(ea) > 1.0 and abs(ea - eb) < 1e-9 * abs(ea)
+        assert np.abs(a.forces()[0] - b.forces()[0]).max() < 1e-8
+        far = x + np.array([0.0, 0.0, 50.0])
+        b.set_positions(far, replica=0)
+        c.set_positions(far, replica=0)
+        assert abs(b.energy_by_group()[0, 22] - c.energy_by_group()[0, 22]) < 1e-9 * abs(ea)
+
+
+def test_index_based_z_dependent_oracle_forces_match_finite_differences(tmp_path, oracle_api, capsys):
+    oa, traj, _ = golden_system("1ubq")
+    f = contactTerms.index_based_contact_term(oa, gamma_folder=_index_folder_zdep(tmp_path, oa), z_dependent=True, z_m=0.8)
+    ctx = awsem_oracle.make_context(_system_of(oa, f), n_replicas=1)
+    atoms = np.random.default_rng(6).choice(np.array(f.atom), size=24, replace=False)
+    got, fd = _fd_check(ctx, _centred(traj[5], oa), 1 << 22, atoms)
+    assert np.abs(fd).max() > 1.0
+    assert np.abs(got - fd).max() / max(1.0, np.abs(fd).max()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,etol,ftol", [(0, 1e-4, 1e-3), (1, 1e-9, 1e-7)])
+@pytest.mark.parametrize("cell", ["0", "1"])
+def test_index_based_z_dependent_gpu_matches_oracle(tmp_path, precision, etol, ftol, cell, monkeypatch, capsys):
+    """Parity unpinned (no reference fixture): the HIP kernels on both paths against the oracle, whose blend is tied to the
+    golden-pinned contact term by the reduction test above."""
+    monkeypatch.setenv("AWSEM_FORCE_CELL", cell)
+    oa, traj, _ = golden_system("1ubq")
+    force = contactTerms.index_based_contact_term(oa, gamma_folder=_index_folder_zdep(tmp_path, oa), z_dependent=True, z_m=0.8, forceGroup=5)
+    frames = (0, 5, 11)
+    system = _system_of(oa, force)
+    gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=len(frames), precision=precision)
+    system.upload(gpu)
+    cpu = awsem_oracle.make_context(system, n_replicas=len(frames))
+    for r, k in enumerate(frames):
+        gpu.set_positions(_centred(traj[k], oa), replica=r)
+        cpu.set_positions(_centred(traj[k], oa), replica=r)
+    eg, ec = gpu.energy_by_group()[:, 5], cpu.energy_by_group()[:, 5]
+    assert np.abs(ec).min() > 1.0
+    assert (np.abs(eg - ec) <= etol * np.abs(ec) + 2e-7).all()
+    fg, fc = gpu.forces(redistribute=False), cpu.forces(redistribute=False)
+    assert np.abs(fc[:, :, 2]).max() > 1.0
+    assert np.abs(fg - fc).max() <= ftol * np.abs(fc).max()
