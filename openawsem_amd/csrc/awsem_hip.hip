@@ -566,7 +566,7 @@ private:
         if (cell_mode_ || skin_fixed_ || list_params_.empty()) return;
         double tmax = T ? 0 : remd_tmax_;   // null: a replica-exchange launch, any replica may hold the hottest rung
         for (int r = 0; T && r < nrep_; r++) tmax = std::max(tmax, T[r]);
-        static const double sa = getenv("AWSEM_SKIN_A") ? atof(getenv("AWSEM_SKIN_A")) : 0.028, sb = getenv("AWSEM_SKIN_B") ? atof(getenv("AWSEM_SKIN_B")) : 0.00024;   // tuning knobs
+        static const double sa = getenv("AWSEM_SKIN_A") ? atof(getenv("AWSEM_SKIN_A")) : -0.0125, sb = getenv("AWSEM_SKIN_B") ? atof(getenv("AWSEM_SKIN_B")) : 0.000375;   // tuning knobs
         const double skin = std::min(0.25, std::max(0.07, sa + sb * tmax));
         if (std::fabs(skin - skin_) < 2e-3) return;
         skin_ = skin;
