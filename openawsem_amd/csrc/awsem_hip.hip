@@ -856,11 +856,24 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     }
     {   // harmonic
         std::vector<HarmD<real>> D;
-        for (auto& h : H.harm) {
-            std::vector<HarmItem<real>> it(h.r0.size());
-            const std::vector<int> perm = item_order((int)it.size(), 2, h.pairs.data());
-            for (size_t b = 0; b < it.size(); b++) { int o = perm[b]; it[b] = HarmItem<real>{h.pairs[2 * o], h.pairs[2 * o + 1], (real)h.r0[o], (real)h.k[o]}; }
-            D.push_back(HarmD<real>{h.group, (int)it.size(), upload(it)});
+        // Replica-resident path: the harmonic terms of one force group (con_term and chain_term of the default set-up) walk as ONE item
+        // list -- an item carries its own r0 and k, and every pass a step makes costs its set-up whether or not it finds work
+        // (AWSEM_HARM_MERGE=0: term by term).  The cell-list path keeps them apart (its window tables are per term).
+        const bool merge = !cell_mode_ && !(getenv("AWSEM_HARM_MERGE") && atoi(getenv("AWSEM_HARM_MERGE")) == 0);
+        std::vector<char> done(H.harm.size(), 0);
+        for (size_t t = 0; t < H.harm.size(); t++) {
+            if (done[t]) continue;
+            std::vector<int> pairs; std::vector<double> r0, k;
+            for (size_t u = t; u < H.harm.size(); u++) {
+                if (done[u] || (u != t && !(merge && H.harm[u].group == H.harm[t].group))) continue;
+                done[u] = 1;
+                const auto& h = H.harm[u];
+                pairs.insert(pairs.end(), h.pairs.begin(), h.pairs.end()); r0.insert(r0.end(), h.r0.begin(), h.r0.end()); k.insert(k.end(), h.k.begin(), h.k.end());
+            }
+            std::vector<HarmItem<real>> it(r0.size());
+            const std::vector<int> perm = item_order((int)it.size(), 2, pairs.data());
+            for (size_t b = 0; b < it.size(); b++) { int o = perm[b]; it[b] = HarmItem<real>{pairs[2 * o], pairs[2 * o + 1], (real)r0[o], (real)k[o]}; }
+            D.push_back(HarmD<real>{H.harm[t].group, (int)it.size(), upload(it)});
         }
         if (D.size() > AWSEM_MAX_HARM) throw std::string("too many harm terms: at most " + std::to_string(AWSEM_MAX_HARM) + " per system");
         S.n_harm = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.harm[t] = D[t];
