@@ -1023,6 +1023,47 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     }
     {   // beta
         std::vector<BetaD<real>> D;
+        // fp32: the exponent X beyond which a pair is not evaluated (and the radius r_ON + sqrt(2X) sigma beyond which it is not listed).
+        // Chosen so that what is dropped is EXACTLY zero in the fp32 force accumulators: a force component of such a pair is at most
+        // |c| e^-X sqrt(2X) / sigma (c = -k lambda; x e^{-x^2 / 2 sigma^2} / sigma^2 under the constraint that the exponent is >= X),
+        // and Q19.12 rounds anything below 2^-13 kJ/mol/nm to zero -- X solves |c|max e^-X sqrt(2X) / sigma_min = 2^-16, a factor 8 inside
+        // that.  Round 1 used X = 30 throughout; with the reference's tables X is about 18 and the lists are a third shorter.  The oracle's
+        // fp32 list mirror (awsem_oracle_neighbors) computes the same number.  Functional tables of more than 4096 residues: X = 30 as before.
+        double beta_X = 30.0;
+        {
+            double cmax = 0, smin = 1e300;
+            bool dense = !H.beta.empty();
+            for (auto& h : H.beta) {
+                double m = 0;
+                if (h.fn.kind) {   // the same maximum from the functional form (it reproduces the dense table to the last bit); huge systems: X = 30
+                    if (h.nres > 4096) { dense = false; break; }
+                    std::vector<int> rinfo(h.nres);
+                    for (int i = 0; i < h.nres; i++) {
+                        const int* q = &h.fn.info[4 * (size_t)i];
+                        const bool edge = q[2] != 0;
+                        const int prev = (i > 0 && !edge) ? h.fn.info[4 * (size_t)(i - 1)] : 0, next = (i + 1 < h.nres && !edge) ? h.fn.info[4 * (size_t)(i + 1)] : 0;
+                        rinfo[i] = q[0] | (prev << 5) | (next << 10) | (edge ? 1 << 15 : 0) | (q[3] ? 1 << 16 : 0) | (q[1] << 17);
+                    }
+                    std::vector<HbFn<double>> one(1);
+                    HbFn<double>& f = one[0];
+                    memset(&f, 0, sizeof f);
+                    f.kind = h.fn.kind; f.rinfo = rinfo.data(); f.scale = 1.0;
+                    const double* c = h.fn.coef.data();
+                    for (int a = 0; a < 5; a++) for (int b = 0; b < 3; b++) f.cc[a][b] = c[3 * a + b];
+                    for (int a = 0; a < 3; a++) f.g[a] = c[15 + a];
+                    for (int a = 0; a < 400; a++) { f.t1[a] = c[18 + a]; f.t2[a] = c[418 + a]; }
+                    for (int a = 0; a < 20; a++) f.ob[a] = c[818 + a];
+                    for (int i = 0; i < h.nres; i++) for (int j = 0; j < h.nres; j++) m = std::max(m, std::fabs(hb_fn_value(f, i, j)));
+                } else
+                    for (double v : h.lambda) m = std::max(m, std::fabs(v));
+                cmax = std::max(cmax, std::fabs(h.k) * m); smin = std::min(smin, std::min(h.s_NO, h.s_HO));
+            }
+            if (dense && cmax > 0 && !(getenv("AWSEM_BETA_SCREEN") && atoi(getenv("AWSEM_BETA_SCREEN")) == 30)) {
+                double X = 20.0;
+                for (int it = 0; it < 8; it++) X = std::log(cmax * 65536.0 * std::sqrt(2.0 * X) / smin);
+                beta_X = std::min(30.0, std::max(8.0, X));
+            }
+        }
         for (auto& h : H.beta) {
             BetaD<real> d;
             memset(&d, 0, sizeof d);
@@ -1042,10 +1083,10 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
             }
             d.r_ON = (real)h.r_ON; d.r_OH = (real)h.r_OH; d.inv_sNO2 = (real)(1.0 / (h.s_NO * h.s_NO)); d.inv_sHO2 = (real)(1.0 / (h.s_HO * h.s_HO));
             d.cutoff2 = (real)(h.cutoff * h.cutoff);
-            if (sizeof(real) == 4) {   // conservative fp32 pre-screen: Gaussian factors below e^-30 are dropped
-                double rs = h.r_ON + std::sqrt(60.0) * h.s_NO;
+            if (sizeof(real) == 4) {   // fp32 pre-screen: Gaussian factors below e^-X are dropped (X: beta_screen_exponent above)
+                double rs = h.r_ON + std::sqrt(2.0 * beta_X) * h.s_NO;
                 d.screen2 = (real)std::min(h.cutoff * h.cutoff, rs * rs);
-                d.max_expo = (real)30;
+                d.max_expo = (real)beta_X;
             } else {
                 d.screen2 = d.cutoff2;
                 d.max_expo = (real)1e300;

@@ -950,7 +950,7 @@ template <class V> __device__ __forceinline__ void contact_chain_rule(const Cont
 // Entry (donor residue i, acceptor residue j) of a lambda / gamma table in its functional form, WITHOUT the -k factor; the
 // formulas and their order of operations are those of the reference's table builders (hydrogenBondTerms.py:160-359), so the
 // fp64 instantiation reproduces the dense tables to the last bits.
-template <class real> __device__ __forceinline__ real hb_fn_value(const HbFn<real>& f, int i, int j) {
+template <class real> __host__ __device__ __forceinline__ real hb_fn_value(const HbFn<real>& f, int i, int j) {
     const int ri = f.rinfo[i], rj = f.rinfo[j];
     if (f.kind <= 3) {
         const int d = i > j ? i - j : j - i;

@@ -1114,7 +1114,25 @@ int awsem_oracle_neighbors(ctx_t* c, int rep, int kind, int index, double skin, 
         const beta_t* t = term;
         double base = t->cutoff;
         if (c->precision == 0) {
-            double rs = t->r_ON + sqrt(60.0) * t->s_NO, s2 = t->cutoff * t->cutoff < rs * rs ? t->cutoff * t->cutoff : rs * rs;
+            /* the engine's fp32 screening exponent (awsem_hip.hip, beta block): X with |c|max e^-X sqrt(2X) / sigma_min = 2^-16 over all
+             * beta terms, 30 when a term carries the functional form for more than 4096 residues */
+            double X = 30.0, cmax = 0, smin = 1e300;
+            int dense = 1;
+            for (int u = 0; u < c->nterms; u++) if (c->terms[u].kind == T_BETA) {
+                const beta_t* b = c->terms[u].p;
+                if (b->fn && b->nres > 4096) { dense = 0; break; }
+                double m = 0;
+                for (int q = 0; q < b->nres; q++) for (int p = 0; p < b->nres; p++) { double v = fabs(beta_lambda(b, q, p)); if (v > m) m = v; }
+                if (fabs(b->k) * m > cmax) cmax = fabs(b->k) * m;
+                if (b->s_NO < smin) smin = b->s_NO;
+                if (b->s_HO < smin) smin = b->s_HO;
+            }
+            if (dense && cmax > 0 && !(getenv("AWSEM_BETA_SCREEN") && atoi(getenv("AWSEM_BETA_SCREEN")) == 30)) {
+                X = 20.0;
+                for (int it = 0; it < 8; it++) X = log(cmax * 65536.0 * sqrt(2.0 * X) / smin);
+                X = X > 30.0 ? 30.0 : (X < 8.0 ? 8.0 : X);
+            }
+            double rs = t->r_ON + sqrt(2.0 * X) * t->s_NO, s2 = t->cutoff * t->cutoff < rs * rs ? t->cutoff * t->cutoff : rs * rs;
             base = sqrt((double)(float)s2);
         } else base = sqrt(t->cutoff * t->cutoff);
         SCAN
