@@ -188,7 +188,9 @@ template <class real> struct DevSys {
     int remove_cm;                        // CMMotionRemover: subtract the mass-weighted mean velocity at the top of every step
     real inv_total_mass;                  // 1 / sum of the masses
     int prio;                             // step kernel: how the replicas sharing a CU take turns at issue priority (0: hardware default, oldest wave first;
-                                          // 1: rotating with the step count; 2: rotating with the clock)
+                                          // 1: rotating with the step count; 2: rotating with the clock; 3 | gain*16 << 8: rotation shifted by a
+                                          // per-replica bias learnt from launch to launch, see pace_bias)
+    int pace_group;                       // number of CUs: workgroups b, b + pace_group, ... of a one-wave grid share a CU
     int* status;                          // device error word: bit 0 = a pair list overflowed
     long long* prof;                      // 16 phase-cycle accumulators (written by -DAWSEM_PROF builds only)
 };

@@ -160,7 +160,13 @@ public:
                         "(%.1f %% of the span), min %.1f, median %.1f, p90 %.1f, max %.1f\n", (e1 - s0) * 0.01, (s1 - s0) * 0.01, (e1 - e0) * 0.01, dsum / nrep_ * 0.01,
                         100.0 * dsum / nrep_ / (double)(e1 - s0), dur[0] * 0.01, dur[nrep_ / 2] * 0.01, dur[(size_t)nrep_ * 9 / 10] * 0.01, dur[nrep_ - 1] * 0.01);
                 if (FILE* f = strlen(getenv("AWSEM_PROF_DUMP")) > 1 ? fopen(getenv("AWSEM_PROF_DUMP"), "w") : nullptr) {   // raw stamps for offline analysis
-                    for (int r = 0; r < nrep_; r++) fprintf(f, "%d %lld %lld %llx\n", r, w[3 * r] - s0, w[3 * r + 1] - s0, (unsigned long long)w[3 * r + 2]);
+                    std::vector<long long> lc((size_t)nrep_ * AWSEM_MAX_LISTS, 0);   // list lengths at the end of the launch (-DAWSEM_WALL builds)
+                    (void)hipMemcpy(lc.data(), dsys_.prof + 16 + 7 * (size_t)nrep_ + 16 * 20, lc.size() * sizeof(long long), hipMemcpyDeviceToHost);
+                    for (int r = 0; r < nrep_; r++) {
+                        fprintf(f, "%d %lld %lld %llx", r, w[3 * r] - s0, w[3 * r + 1] - s0, (unsigned long long)w[3 * r + 2]);
+                        for (int l = 0; l < dsys_.n_lists; l++) fprintf(f, " %lld", lc[(size_t)r * AWSEM_MAX_LISTS + l]);
+                        fprintf(f, "\n");
+                    }
                     fclose(f);
                 }
                 std::vector<double> cu_max, cu_spread, cu_n;
@@ -321,8 +327,10 @@ public:
         HIP_TRY(hipSetDevice(device_));
         apply_skin(T);
         begin_async(T);
+        if ((dsys_.prio & 0xff) == 3 && place_every_ > 0 && launch_ > 0 && launch_ % place_every_ == 0 && nrep_ <= 8192)   // deal the replicas to the CUs anew
+            hipLaunchKernelGGL(awsem_place_kernel, dim3(1), dim3(1024), (size_t)nrep_ * sizeof(int), stream_, dsys_.prof, nrep_, dsys_.pace_group);
         hipLaunchKernelGGL(awsem_step_kernel<real>, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, (const double*)dT_, nsteps, dt, friction,
-                           (unsigned long long)seed, (long long)step0);
+                           (unsigned long long)seed, (long long)step0, launch_++);
         HIP_TRY(hipGetLastError());
         end_async();   // asynchronous: resolved by synchronize() / last_kernel_ms
     }
@@ -581,6 +589,8 @@ private:
     }
     double skin_ = 0.2;    // nm; AWSEM_SKIN overrides (0.15-0.3 measured: 0.2 and above rebuild rarely enough on the hot, extended stage of an annealing run)
     size_t lds_list_ = 0, lds_max_ = 0, n_cu_ = 256;
+    int launch_ = 0;        // step launches so far (parity of the pacing records)
+    int place_every_ = 16;  // launches between two placements of the replicas on the CUs (0: never), AWSEM_PLACE_EVERY
     bool step_ok_ = false;
 
     // ---- cell-list path (awsem_cell.h): systems that do not fit one CU's LDS
@@ -822,7 +832,9 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         for (int i = 0; i < natoms_; i++) mtot += H.mass[i];
         S.remove_cm = H.remove_cm && mtot > 0 ? 1 : 0;
         S.inv_total_mass = mtot > 0 ? (real)(1.0 / mtot) : (real)0;
-        S.prio = getenv("AWSEM_PRIO") ? atoi(getenv("AWSEM_PRIO")) : 1;   // 0 switches the rotation off (A/B runs)
+        S.prio = getenv("AWSEM_PRIO") ? atoi(getenv("AWSEM_PRIO")) : 3;   // 0 switches the rotation off, 1 is the plain rotation (A/B runs)
+        if (S.prio == 3) S.prio |= (int)lround(16.0 * (getenv("AWSEM_PACE_GAIN") ? atof(getenv("AWSEM_PACE_GAIN")) : 10.0)) << 8;
+        S.pace_group = (int)n_cu_;
         std::vector<MassiveItem<real>> mv;
         for (int i = 0; i < natoms_; i++) if (H.mass[i] > 0) mv.push_back(MassiveItem<real>{i, im[i], sim[i], to_orig_.empty() ? i : to_orig_[i]});
         S.massive = upload(mv);
@@ -1228,8 +1240,15 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     dstatus_ = dalloc<int>(1);
     HIP_TRY(hipMemset(dstatus_, 0, sizeof(int)));
     S.status = dstatus_;
-    S.prof = dalloc<long long>(16 + 3 * (size_t)nrep_ + 16 * 20);   // phase cycles, then (start, end, hardware id) per replica (experiment builds)
-    HIP_TRY(hipMemset(S.prof, 0, (16 + 3 * (size_t)nrep_ + 16 * 20) * sizeof(long long)));
+    // phase cycles, then (start, end, hardware id) per replica (experiment builds), then the pacing records (two launch parities)
+    S.prof = dalloc<long long>(pace_perm_offset(nrep_) + (size_t)nrep_);
+    HIP_TRY(hipMemset(S.prof, 0, (pace_perm_offset(nrep_) + (size_t)nrep_) * sizeof(long long)));
+    {
+        std::vector<int> ident(nrep_);
+        for (int r = 0; r < nrep_; r++) ident[r] = r;
+        HIP_TRY(hipMemcpy(S.prof + pace_perm_offset(nrep_), ident.data(), (size_t)nrep_ * sizeof(int), hipMemcpyHostToDevice));
+        if (const char* env = getenv("AWSEM_PLACE_EVERY")) place_every_ = atoi(env);
+    }
     const size_t lds_max = lds_max_;
     lds_eval_ = lds_bytes<real>(lds_shape(S), false);
     lds_step_ = lds_bytes<real>(lds_shape(S), true);

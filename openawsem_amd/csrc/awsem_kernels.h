@@ -1603,6 +1603,54 @@ template <> struct CmAcc<double> {
         }
     }
 };
+// Pacing (DevSys::prio mode 3): the replicas that share a CU should END a launch together -- a replica that ends early leaves its
+// issue slots to fewer and fewer waves, and the launch waits for the slowest replica on the chip.  How long a replica takes is
+// mostly its own structure (compact chains: residency of consecutive launches correlates 0.94), so every replica keeps a priority
+// bias that the NEXT launch corrects by how far behind (ahead of) its CU's mean end it came in.  No communication inside a launch:
+// thread 0 reads the previous launch's records of the workgroups it shared the CU with (b, b + #CUs, ... for a grid of one
+// wave; the recorded CU id vouches for it) and writes its own at the end.  Records: [launch parity][replica] {end time, bias |
+// CU id << 32 | duration << 44} behind the profiling area of DevSys::prof, wall-clock ticks of 10 ns.
+__device__ __forceinline__ unsigned pace_cu_key() {
+    return ((unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 8) | (((unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 0xffu);   // XCC_ID, HW_ID's CU/SH/SE bits
+}
+template <class real> __device__ __forceinline__ long long* pace_area(const DevSys<real>& S, int nrep, int parity) {
+    return S.prof + 16 + 3 * (size_t)nrep + 16 * 20 + (size_t)parity * 2 * nrep;
+}
+// Placement: which replica a workgroup takes (perm) and what a replica cost last time (the lengths of its pair lists at the end of
+// the launch: they explain 84 % of the variance of a compact replica's residency) -- awsem_place_kernel deals the replicas to the
+// CUs so that every CU gets the same total, every few launches.
+__host__ __device__ inline size_t pace_perm_offset(int nrep) { return 16 + (7 + (size_t)AWSEM_MAX_LISTS) * nrep + 16 * 20; }   // in long longs from DevSys::prof
+template <class real> __device__ __forceinline__ int* pace_perm(const DevSys<real>& S, int nrep) { return (int*)(S.prof + pace_perm_offset(nrep)); }
+template <class real> __device__ __forceinline__ int* pace_cost(const DevSys<real>& S, int nrep) { return pace_perm(S, nrep) + nrep; }
+template <class real> __device__ __forceinline__ float pace_bias(const DevSys<real>& S, int rep, int nrep, int launch, unsigned cu) {
+    const long long* prev = pace_area(S, nrep, (launch & 1) ^ 1);
+    const int* perm = pace_perm(S, nrep);
+    const long long own_end = prev[2 * rep], own_w = prev[2 * rep + 1];
+    if (own_end == 0) return 0.f;                                      // first launch
+    float bias = __uint_as_float((unsigned)own_w);
+    const unsigned own_cu = (unsigned)(own_w >> 32) & 0xfffu;
+    const float dur = (float)(int)((unsigned long long)own_w >> 44);
+    if (own_cu != cu || dur <= 0.f) return bias;                       // dispatched elsewhere this time: keep, do not learn
+    const int group = S.pace_group;
+    long long sum = 0; int n = 0;
+    for (int b = (int)blockIdx.x % group; b < nrep; b += group) {       // a replica that was elsewhere last time fails the CU test
+        const int q = perm[b];
+        const long long w = prev[2 * q + 1];
+        if (((unsigned)(w >> 32) & 0xfffu) == own_cu && prev[2 * q] != 0) { sum += prev[2 * q] - own_end; n++; }
+    }
+    if (n < 2) return bias;
+    const float lag = -(float)sum / ((float)n * dur);                  // own end behind the CU's mean end, as a fraction of the launch
+    bias += (float)(S.prio >> 8) * 0.0625f * lag;
+    return bias < -3.f ? -3.f : bias > 3.f ? 3.f : bias;
+}
+template <class real> __device__ __forceinline__ void pace_record(const DevSys<real>& S, int rep, int nrep, int launch, unsigned cu, float bias, long long t0) {
+    long long* cur = pace_area(S, nrep, launch & 1);
+    const long long t1 = (long long)wall_clock64();
+    long long dur = t1 - t0;
+    dur = dur < 1 ? 1 : dur > 0xfffff ? 0xfffff : dur;
+    cur[2 * rep] = t1;
+    cur[2 * rep + 1] = (long long)(((unsigned long long)dur << 44) | ((unsigned long long)(cu & 0xfffu) << 32) | (unsigned long long)__float_as_uint(bias));
+}
 // Issue priority of a wave (s_setprio takes an immediate).  The SIMD arbiter serves the highest priority first and, among equals,
 // the OLDEST wave: left alone, the replica dispatched first on a CU runs at nearly its solo speed, the three behind it get what
 // is left, and the CU ends the launch with one, two, three of its four replicas already gone (measured with -DAWSEM_WALL: the
@@ -1623,10 +1671,11 @@ __device__ __forceinline__ void set_wave_priority(int p) {
 template <class real>
 __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, real* __restrict__ vel,
                                   const double* __restrict__ T, int nsteps, double dt, double friction, unsigned long long seed,
-                                  long long step0) {
+                                  long long step0, int launch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     AWSEM_STAMP_WALL(S, 0);
-    const int natoms = S.natoms, rep = blockIdx.x;
+    const long long pace_t0 = (S.prio & 0xff) == 3 ? (long long)wall_clock64() : 0;
+    const int natoms = S.natoms, rep = (S.prio & 0xff) == 3 ? uniform(pace_perm(S, (int)gridDim.x)[blockIdx.x]) : (int)blockIdx.x;
     Lds<real> L = carve_lds((real)0, smem, lds_shape(S), true);
     L.lists = S.lists + (size_t)rep * S.list_stride;
     real* gp = pos + (size_t)rep * 3 * natoms;
@@ -1643,8 +1692,12 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
     stage_tables(S, L);
     if (threadIdx.x < 2) L.flag[threadIdx.x] = 0;
     if (threadIdx.x == 0) L.flag[2] = __builtin_amdgcn_s_getreg((3 << 11) | 4);   // HW_ID[3:0]: wave 0's slot on its SIMD -- distinct among the replicas that share the CU (measured: 0..3 in dispatch order)
+    const bool paced = (S.prio & 0xff) == 3;
+    const unsigned pace_cu = paced ? pace_cu_key() : 0;
+    if (paced && threadIdx.x == 0) L.flag[3] = __float_as_uint(pace_bias(S, rep, (int)gridDim.x, launch, pace_cu));
     __syncthreads();
     const int prio_slot = uniform((int)L.flag[2]);
+    const float prio_bias = paced ? __uint_as_float(uniform((int)L.flag[3])) : 0.f;
     compute_virtual_sites(S, L);
     const bool cmr = S.remove_cm != 0;
     if (cmr) {   // momentum of the incoming velocities: what the first step removes (L.cm[0..2]; zeroed at the carve-up, a barrier ago)
@@ -1661,6 +1714,11 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
         const int cur = s & 1;
         const bool rebuild = s == 0 || __uint_as_float(L.flag[cur]) > (float)S.skin_half2;   // uniform across the workgroup
         if (S.prio == 1) set_wave_priority(prio_slot + s);   // this replica's turn at each of the four levels comes round every four steps
+        else if (paced) {   // the same rotation, shifted by the replica's bias (dithered step by step, so a fractional bias acts as such)
+            const int shift = (int)floorf(prio_bias + (float)(((unsigned)s * 2654435769u) >> 8) * (1.f / 16777216.f));
+            const int p = ((prio_slot + s) & 3) + shift;
+            set_wave_priority(p < 0 ? 0 : p > 3 ? 3 : p);
+        }
         else if (S.prio == 2) set_wave_priority(prio_slot + (int)(wall_clock64() >> 11));   // by the clock instead (100 MHz: turns of 20 us); measured equal
         if (cmr && threadIdx.x < 3) {
             L.cm[(cur ^ 1) * 3 + threadIdx.x] = 0;   // read for the last time in the previous step's integrator; this step's adds to it
@@ -1767,6 +1825,32 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
         gv[i] = v.x; gv[natoms + i] = v.y; gv[2 * natoms + i] = v.z;
     }
     AWSEM_STAMP_WALL(S, 1);
+#if defined(AWSEM_PROF) || defined(AWSEM_WALL)
+    if ((int)threadIdx.x < S.n_lists) S.prof[16 + 7 * (size_t)gridDim.x + 16 * 20 + (size_t)rep * AWSEM_MAX_LISTS + threadIdx.x] = L.lcount[threadIdx.x];
+#endif
+    if (paced && threadIdx.x == 0) {
+        pace_record(S, rep, (int)gridDim.x, launch, pace_cu, prio_bias, pace_t0);
+        int c = 0;
+        for (int l = 0; l < S.n_lists; l++) c += (int)L.lcount[l];
+        pace_cost(S, (int)gridDim.x)[rep] = c;
+    }
+}
+// One workgroup: rank the replicas by cost (heaviest first) and deal them to the CUs boustrophedon -- row 0 left to right, row 1 right
+// to left, ... -- so that the workgroups b, b + group, b + 2 group, ... of a CU hold one replica of every weight class.
+__global__ void awsem_place_kernel(long long* prof, int nrep, int group) {
+    extern __shared__ int place_cost[];
+    int* perm = (int*)(prof + pace_perm_offset(nrep));
+    const int* cost = perm + nrep;
+    for (int r = threadIdx.x; r < nrep; r += blockDim.x) place_cost[r] = cost[r];
+    __syncthreads();
+    for (int r = threadIdx.x; r < nrep; r += blockDim.x) {
+        const int c = place_cost[r];
+        int rank = 0;
+        for (int q = 0; q < nrep; q++) { const int cq = place_cost[q]; rank += (cq > c || (cq == c && q < r)) ? 1 : 0; }
+        const int row = rank / group, col = rank - row * group;
+        const int width = nrep - row * group < group ? nrep - row * group : group;
+        perm[row * group + ((row & 1) ? width - 1 - col : col)] = r;
+    }
 }
 
 // ------------------------------------------------------------------ energy minimiser (simulation.minimizeEnergy())

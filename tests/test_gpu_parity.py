@@ -292,6 +292,34 @@ def test_alternative_kernel_paths_give_the_same_trajectory(env, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_pacing_and_placement_leave_the_trajectories_alone(monkeypatch):
+    """fp32 step kernel: which workgroup takes which replica (dealt anew every few launches by list length) and the priority bias a
+    replica carries from launch to launch (csrc/awsem_kernels.h, pace_bias / awsem_place_kernel) decide WHEN a replica's instructions
+    issue, never what they compute: 300 replicas (two rows of workgroups, the second one partial) over six launches end bit for bit
+    where the plain rotation (AWSEM_PRIO=1) and the hardware's own order (AWSEM_PRIO=0) end."""
+    oa, traj, _ = golden_system("1ubq")
+    R = 300
+    T = np.linspace(250.0, 800.0, R)
+    out = []
+    for prio, every in (("1", "0"), ("3", "2"), ("3", "1"), ("0", "0")):
+        monkeypatch.setenv("AWSEM_PRIO", prio)
+        monkeypatch.setenv("AWSEM_PLACE_EVERY", every)
+        gpu = _gpu(oa, R, FP32)
+        for r in range(R):
+            gpu.set_positions(traj[r % len(traj)], replica=r)
+        gpu.set_velocities_to_temperature(T, 5)
+        for _ in range(6):
+            gpu.step(20, T, 0.002, 1.0, 6)
+        out.append(gpu.get_state())
+        gpu.close()
+    monkeypatch.delenv("AWSEM_PRIO", raising=False)
+    monkeypatch.delenv("AWSEM_PLACE_EVERY", raising=False)
+    for x, v in out[1:]:
+        assert np.array_equal(x, out[0][0]) and np.array_equal(v, out[0][1])
+    assert np.isfinite(out[0][0]).all()
+
+
+@pytest.mark.gpu
 def test_beta_screen_drops_only_exact_zeros(monkeypatch):
     """fp32: the beta terms skip a pair once its Gaussian factor is below e^-X, X chosen at finalize so that every force component of a
     skipped pair is under 2^-16 kJ/mol/nm, an eighth of what the Q19.12 accumulators round to zero (csrc/awsem_hip.hip, beta block;
