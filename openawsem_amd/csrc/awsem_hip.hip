@@ -1033,6 +1033,31 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         if (D.size() > AWSEM_MAX_CONTACT) throw std::string("too many contact terms: at most " + std::to_string(AWSEM_MAX_CONTACT) + " per system");
         S.n_contact = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.contact[t] = D[t];
     }
+    // largest |entry| of a lambda / gamma table, dense or in its functional form (which reproduces the dense table to the last bit);
+    // -1 for a functional table of more than 4096 residues (the caller then keeps the loose screen)
+    auto table_max = [&](const auto& fn, int nres, const std::vector<double>& dense_table) -> double {
+        double m = 0;
+        if (!fn.kind) { for (double v : dense_table) m = std::max(m, std::fabs(v)); return m; }
+        if (nres > 4096) return -1.0;
+        std::vector<int> rinfo(nres);
+        for (int i = 0; i < nres; i++) {
+            const int* q = &fn.info[4 * (size_t)i];
+            const bool edge = q[2] != 0;
+            const int prev = (i > 0 && !edge) ? fn.info[4 * (size_t)(i - 1)] : 0, next = (i + 1 < nres && !edge) ? fn.info[4 * (size_t)(i + 1)] : 0;
+            rinfo[i] = q[0] | (prev << 5) | (next << 10) | (edge ? 1 << 15 : 0) | (q[3] ? 1 << 16 : 0) | (q[1] << 17);
+        }
+        std::vector<HbFn<double>> one(1);
+        HbFn<double>& f = one[0];
+        memset(&f, 0, sizeof f);
+        f.kind = fn.kind; f.rinfo = rinfo.data(); f.scale = 1.0;
+        const double* c = fn.coef.data();
+        for (int a = 0; a < 5; a++) for (int b = 0; b < 3; b++) f.cc[a][b] = c[3 * a + b];
+        for (int a = 0; a < 3; a++) f.g[a] = c[15 + a];
+        for (int a = 0; a < 400; a++) { f.t1[a] = c[18 + a]; f.t2[a] = c[418 + a]; }
+        for (int a = 0; a < 20; a++) f.ob[a] = c[818 + a];
+        for (int i = 0; i < nres; i++) for (int j = 0; j < nres; j++) m = std::max(m, std::fabs(hb_fn_value(f, i, j)));
+        return m;
+    };
     {   // beta
         std::vector<BetaD<real>> D;
         // fp32: the exponent X beyond which a pair is not evaluated (and the radius r_ON + sqrt(2X) sigma beyond which it is not listed).
@@ -1046,28 +1071,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
             double cmax = 0, smin = 1e300;
             bool dense = !H.beta.empty();
             for (auto& h : H.beta) {
-                double m = 0;
-                if (h.fn.kind) {   // the same maximum from the functional form (it reproduces the dense table to the last bit); huge systems: X = 30
-                    if (h.nres > 4096) { dense = false; break; }
-                    std::vector<int> rinfo(h.nres);
-                    for (int i = 0; i < h.nres; i++) {
-                        const int* q = &h.fn.info[4 * (size_t)i];
-                        const bool edge = q[2] != 0;
-                        const int prev = (i > 0 && !edge) ? h.fn.info[4 * (size_t)(i - 1)] : 0, next = (i + 1 < h.nres && !edge) ? h.fn.info[4 * (size_t)(i + 1)] : 0;
-                        rinfo[i] = q[0] | (prev << 5) | (next << 10) | (edge ? 1 << 15 : 0) | (q[3] ? 1 << 16 : 0) | (q[1] << 17);
-                    }
-                    std::vector<HbFn<double>> one(1);
-                    HbFn<double>& f = one[0];
-                    memset(&f, 0, sizeof f);
-                    f.kind = h.fn.kind; f.rinfo = rinfo.data(); f.scale = 1.0;
-                    const double* c = h.fn.coef.data();
-                    for (int a = 0; a < 5; a++) for (int b = 0; b < 3; b++) f.cc[a][b] = c[3 * a + b];
-                    for (int a = 0; a < 3; a++) f.g[a] = c[15 + a];
-                    for (int a = 0; a < 400; a++) { f.t1[a] = c[18 + a]; f.t2[a] = c[418 + a]; }
-                    for (int a = 0; a < 20; a++) f.ob[a] = c[818 + a];
-                    for (int i = 0; i < h.nres; i++) for (int j = 0; j < h.nres; j++) m = std::max(m, std::fabs(hb_fn_value(f, i, j)));
-                } else
-                    for (double v : h.lambda) m = std::max(m, std::fabs(v));
+                const double m = table_max(h.fn, h.nres, h.lambda);
+                if (m < 0) { dense = false; break; }
                 cmax = std::max(cmax, std::fabs(h.k) * m); smin = std::min(smin, std::min(h.s_NO, h.s_HO));
             }
             if (dense && cmax > 0 && !(getenv("AWSEM_BETA_SCREEN") && atoi(getenv("AWSEM_BETA_SCREEN")) == 30)) {
@@ -1108,6 +1113,22 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         if (D.size() > AWSEM_MAX_BETA) throw std::string("too many beta terms: at most " + std::to_string(AWSEM_MAX_BETA) + " per system");
         S.n_beta = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.beta[t] = D[t];
     }
+    // The same argument for P-AP: its three forces are c eta2 s_k (1 - s_k) s_l s_m (unit vector), every switch s = sigmoid(arg) < e^arg,
+    // so once ANY of the three arguments is below A = log(2^-16 / (|c|max eta2)) all three forces round to zero in Q19.12.  Round 1 used
+    // A = -30 (which is also where the reference's 1.0 nm cutoff sits: 140 (0.8 - 1.0) = -28); with the reference's gammas A is about
+    // -16.6 and the first switch alone closes the list at r0 - A / eta2 = 0.92 nm.  Mirrored in the oracle's fp32 list scan.
+    double pap_A = -30.0;
+    {
+        double cmax = 0;
+        bool dense = !H.pap.empty();
+        for (auto& h : H.pap) {
+            const double m = table_max(h.fn, h.nres, h.gamma);
+            if (m < 0) { dense = false; break; }
+            cmax = std::max(cmax, std::fabs(h.k) * m * 2.0 * h.eta);
+        }
+        if (dense && cmax > 0 && !(getenv("AWSEM_PAP_SCREEN") && atoi(getenv("AWSEM_PAP_SCREEN")) == 30))
+            pap_A = std::min(-8.0, std::max(-30.0, std::log(1.0 / (65536.0 * cmax))));
+    }
     {   // pap
         std::vector<PapD<real>> D;
         for (auto& h : H.pap) {
@@ -1128,7 +1149,11 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
                 zero_band(h.gamma, h.nres, &d.band_lo, &d.band_hi);
             }
             d.eta2 = (real)(2 * h.eta); d.r0 = (real)h.r0; d.d_i4 = (real)h.d_i4; d.cutoff2 = (real)(h.cutoff * h.cutoff);
-            d.min_arg = sizeof(real) == 4 ? (real)-30 : (real)-1e300;
+            d.min_arg = sizeof(real) == 4 ? (real)pap_A : (real)-1e300;
+            if (sizeof(real) == 4) {   // fp32: the first switch's argument is below pap_A beyond this distance
+                const double rs = h.r0 - pap_A / (2.0 * h.eta);
+                d.cutoff2 = (real)std::min(h.cutoff * h.cutoff, rs * rs);
+            }
             D.push_back(d);
         }
         if (D.size() > AWSEM_MAX_PAP) throw std::string("too many pap terms: at most " + std::to_string(AWSEM_MAX_PAP) + " per system");
@@ -1296,7 +1321,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         for (int t = 0; t < S.n_pap; t++) {
             PapD<real>& d = S.pap[t];
             if (d.nacc > 65535 || d.ndon > 65535) throw std::string("hydrogen-bond term: at most 65535 acceptors / donors");
-            d.list_rc2 = rc2(H.pap[t].cutoff, 0.5 * (amp_max(H.pap[t].acc_atoms, 2) + amp_max(H.pap[t].don_atoms, 2)));
+            d.list_rc2 = rc2(std::sqrt((double)d.cutoff2), 0.5 * (amp_max(H.pap[t].acc_atoms, 2) + amp_max(H.pap[t].don_atoms, 2)));
         }
         const bool share = !(getenv("AWSEM_HB_SHARE") && atoi(getenv("AWSEM_HB_SHARE")) == 0);   // 0: one list per term (A/B runs)
         auto share_lists = [&](auto* terms, int n, auto same) {
@@ -1400,7 +1425,7 @@ template <class real> int Engine<real>::neighbors(int rep, int kind, int index, 
         break;
     case AWSEM_LIST_PAP:
         if (index < 0 || index >= S.n_pap) throw std::string("neighbors: no such pap term");
-        S.pap[index].list_rc2 = rc2(Hs.pap[index].cutoff); ls = S.pap[index].ls; group = S.pap[index].group;
+        S.pap[index].list_rc2 = rc2(std::sqrt((double)S.pap[index].cutoff2)); ls = S.pap[index].ls; group = S.pap[index].group;
         for (int t = 0; t < S.n_pap; t++) if (t != index) S.pap[t].nacc = S.pap[t].ndon = 0;
         break;
     default: throw std::string("neighbors: kind must be AWSEM_LIST_EXCL, _CONTACT, _BETA or _PAP");
@@ -1443,7 +1468,7 @@ template <class real> void Engine<real>::cell_setup(DevSys<real>& S, const HostS
         throw std::string("cell-list path: the hydrogen-bond terms need the excluded-volume term in the system (its CA and O atoms drive the list rebuilds)");
     // rows of the hydrogen-bond terms: screening distance + 1.2 skin (the donor's N is a virtual site, see awsem_cell.h)
     for (int t = 0; t < S.n_beta; t++) { const double r = std::sqrt((double)S.beta[t].screen2) + 1.2 * skin_; cell_hb_rc2_beta_[t] = (real)(r * r); }
-    for (int t = 0; t < S.n_pap; t++) { const double r = H.pap[t].cutoff + 1.2 * skin_; cell_hb_rc2_pap_[t] = (real)(r * r); }
+    for (int t = 0; t < S.n_pap; t++) { const double r = std::sqrt((double)S.pap[t].cutoff2) + 1.2 * skin_; cell_hb_rc2_pap_[t] = (real)(r * r); }
     dsys_beta_n_ = S.n_beta; dsys_pap_n_ = S.n_pap;
     cell_hb_ = HbTerms<real>{};
     cell_hb_.n_beta = S.n_beta; cell_hb_.n_pap = S.n_pap;
@@ -1869,7 +1894,7 @@ template <class real> int Engine<real>::cell_neighbors(int rep, int kind, int in
     const real hb_saved = hb ? *hb_rc2 : (real)0;
     double r = (b ? cell_rc_excl_ : cell_rc_contact_) + skin;
     if (hb) {
-        r = (kind == AWSEM_LIST_BETA ? std::sqrt((double)dsys_.beta[index].screen2) : host_->pap[index].cutoff) + skin;
+        r = (kind == AWSEM_LIST_BETA ? std::sqrt((double)dsys_.beta[index].screen2) : std::sqrt((double)dsys_.pap[index].cutoff2)) + skin;
         *hb_rc2 = (real)(r * r);
         cell_hb_sync();
     }

@@ -1140,9 +1140,29 @@ int awsem_oracle_neighbors(ctx_t* c, int rep, int kind, int index, double skin, 
             if (beta_lambda(t, t->don_res[q], t->acc_res[a]) != 0.0 && below(c, x, t->acc_atoms[3 * a], t->don_atoms[3 * q], base + skin)) PUSH(a, q);
     } else {
         const pap_t* t = term;
+        double base = t->cutoff;
+        if (c->precision == 0) {
+            /* the engine's fp32 screen (awsem_hip.hip, pap block): switch arguments below A = log(2^-16 / (|c|max eta2)) give forces that
+             * round to zero, so the list closes where the first switch reaches A */
+            double A = -30.0, cmax = 0;
+            int dense = 1;
+            for (int u = 0; u < c->nterms; u++) if (c->terms[u].kind == T_PAP) {
+                const pap_t* b = c->terms[u].p;
+                if (b->fn && b->nres > 4096) { dense = 0; break; }
+                double m = 0;
+                for (int q = 0; q < b->nres; q++) for (int p = 0; p < b->nres; p++) { double v = fabs(pap_gamma(b, q, p)); if (v > m) m = v; }
+                if (fabs(b->k) * m * 2.0 * b->eta > cmax) cmax = fabs(b->k) * m * 2.0 * b->eta;
+            }
+            if (dense && cmax > 0 && !(getenv("AWSEM_PAP_SCREEN") && atoi(getenv("AWSEM_PAP_SCREEN")) == 30)) {
+                A = log(1.0 / (65536.0 * cmax));
+                A = A < -30.0 ? -30.0 : (A > -8.0 ? -8.0 : A);
+            }
+            double rs = t->r0 - A / (2.0 * t->eta), s2 = t->cutoff * t->cutoff < rs * rs ? t->cutoff * t->cutoff : rs * rs;
+            base = sqrt((double)(float)s2);
+        }
         SCAN
         for (int a = 0; a < t->nacc; a++) for (int q = 0; q < t->ndon; q++)
-            if (pap_gamma(t, t->don_res[q], t->acc_res[a]) != 0.0 && below(c, x, t->acc_atoms[2 * a], t->don_atoms[2 * q], t->cutoff + skin)) PUSH(a, q);
+            if (pap_gamma(t, t->don_res[q], t->acc_res[a]) != 0.0 && below(c, x, t->acc_atoms[2 * a], t->don_atoms[2 * q], base + skin)) PUSH(a, q);
     }
 #undef PUSH
 #undef SCAN

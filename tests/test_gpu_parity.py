@@ -320,18 +320,20 @@ def test_pacing_and_placement_leave_the_trajectories_alone(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_beta_screen_drops_only_exact_zeros(monkeypatch):
+@pytest.mark.parametrize("knob", ["AWSEM_BETA_SCREEN", "AWSEM_PAP_SCREEN"])
+def test_beta_screen_drops_only_exact_zeros(knob, monkeypatch):
     """fp32: the beta terms skip a pair once its Gaussian factor is below e^-X, X chosen at finalize so that every force component of a
     skipped pair is under 2^-16 kJ/mol/nm, an eighth of what the Q19.12 accumulators round to zero (csrc/awsem_hip.hip, beta block;
     X is about 18 with the reference's tables).  Round 1's X = 30 must therefore give the same forces and the same trajectory BIT FOR
-    BIT; the energies, which sum in Q31.32, may differ by the dropped tails (< 1e-6 kJ/mol here)."""
+    BIT; the energies, which sum in Q31.32, may differ by the dropped tails (< 1e-6 kJ/mol here).  P-AP likewise: a pair is skipped
+    once any of its three switches has an argument below A = log(2^-16 / (|c|max eta2)), about -16.6, where round 1 used -30."""
     oa, traj, _ = golden_system("1ubq")
     T = np.array([300.0, 700.0])
     out = []
     for screen in (None, "30"):
-        monkeypatch.delenv("AWSEM_BETA_SCREEN", raising=False)
+        monkeypatch.delenv(knob, raising=False)
         if screen:
-            monkeypatch.setenv("AWSEM_BETA_SCREEN", screen)
+            monkeypatch.setenv(knob, screen)
         gpu = _gpu(oa, 2, FP32)
         gpu.set_positions(traj[0], replica=0)
         gpu.set_positions(traj[9], replica=1)
@@ -341,7 +343,7 @@ def test_beta_screen_drops_only_exact_zeros(monkeypatch):
         gpu.step(300, T, 0.002, 1.0, 6)
         out.append((f0, e0, gpu.get_state()))
         gpu.close()
-    monkeypatch.delenv("AWSEM_BETA_SCREEN", raising=False)
+    monkeypatch.delenv(knob, raising=False)
     assert np.array_equal(out[0][0], out[1][0])                       # forces
     assert np.array_equal(out[0][2][0], out[1][2][0]) and np.array_equal(out[0][2][1], out[1][2][1])   # positions, velocities after 300 steps
-    assert np.abs(out[0][1] - out[1][1]).max() < 1e-6 and np.abs(out[0][1][:, 27]).min() > 1.0
+    assert np.abs(out[0][1] - out[1][1]).max() < 1e-6 and np.abs(out[0][1][:, 27 if "BETA" in knob else 28]).min() > 1.0
