@@ -326,7 +326,9 @@ def test_beta_screen_drops_only_exact_zeros(knob, monkeypatch):
     skipped pair is under 2^-16 kJ/mol/nm, an eighth of what the Q19.12 accumulators round to zero (csrc/awsem_hip.hip, beta block;
     X is about 18 with the reference's tables).  Round 1's X = 30 must therefore give the same forces and the same trajectory BIT FOR
     BIT; the energies, which sum in Q31.32, may differ by the dropped tails (< 1e-6 kJ/mol here).  P-AP likewise: a pair is skipped
-    once any of its three switches has an argument below A = log(2^-16 / (|c|max eta2)), about -16.6, where round 1 used -30."""
+    once any of its three switches has an argument below A = log(2^-16 / (|c|max eta2)), about -16.6, where round 1 used -30.
+    (The argument is about the replica-resident path's Q19.12 accumulators: the test pins that path.)"""
+    monkeypatch.delenv("AWSEM_FORCE_CELL", raising=False)
     oa, traj, _ = golden_system("1ubq")
     T = np.array([300.0, 700.0])
     out = []

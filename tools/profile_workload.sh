@@ -18,18 +18,20 @@ cat $O/${tag}_kernel_tail.json
 grep -o '"value": [0-9.e+]*\|"kernel_ms": [0-9.e+-]*' $O/prof_$tag.log | tr '\n' ' '; echo
 P="--steps 3 --warmup 1"
 div=$((reps * steps))
-timeout -s KILL 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq1_$tag -- $B $P "$@" > $O/pmc_sq1_$tag.log 2>&1 || { tail -5 $O/pmc_sq1_$tag.log; exit 5; }
+timeout -s KILL 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq1_$tag -- $B $P "$@" > $O/pmc_sq1_$tag.log 2>&1 || { tail -5 $O/pmc_sq1_$tag.log; exit 5; }
 timeout -s KILL 400 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS --output-format csv -d $O/pmc_sq2_$tag -- $B $P "$@" > $O/pmc_sq2_$tag.log 2>&1 || { tail -5 $O/pmc_sq2_$tag.log; exit 6; }
 { python3 $R/tools/pmc_tail.py pmc $O/pmc_sq1_$tag awsem_step_kernel 3 $div && python3 $R/tools/pmc_tail.py pmc $O/pmc_sq2_$tag awsem_step_kernel 3 $div; } | sed 's/per unit/per replica-step/' > $O/${tag}_pmc_sq.txt || exit 7
-# effective clock of the profiled launches: GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS note)
-python3 - $O/${tag}_pmc_sq.txt $O/${tag}_kernel_tail.json $div <<'PY' >> $O/${tag}_pmc_sq.txt
+# effective clock of the profiled launches: GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS note); the durations
+# are those of the SAME dispatches (kernel trace of the counter pass itself: the first launches of a run differ from the timed ones)
+python3 $R/tools/pmc_tail.py trace $O/pmc_sq1_$tag awsem_step_kernel 3 > $O/${tag}_pmc_tail.json || exit 7
+python3 - $O/${tag}_pmc_sq.txt $O/${tag}_pmc_tail.json $div <<'PY' >> $O/${tag}_pmc_sq.txt
 import json, sys
 rows = {l.split()[0]: float(l.split()[1]) for l in open(sys.argv[1]) if l.strip()}
 us = json.load(open(sys.argv[2]))["mean_us"]
 div = float(sys.argv[3])
 if "GRBM_GUI_ACTIVE" in rows:
     ghz = rows["GRBM_GUI_ACTIVE"] * div / 8.0 / (us * 1e3)
-    print(f"{'DERIVED_CLOCK_GHZ':28s} {ghz:14.3f}  GRBM_GUI_ACTIVE / 8 XCDs / mean launch duration of the kernel trace ({us:.1f} us)")
+    print(f"{'DERIVED_CLOCK_GHZ':28s} {ghz:14.3f}  GRBM_GUI_ACTIVE / 8 XCDs / mean duration of the same dispatches ({us:.1f} us)")
 PY
 cat $O/${tag}_pmc_sq.txt
 timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$tag -- $B $P "$@" > $O/pmc_fetch_$tag.log 2>&1 || { tail -5 $O/pmc_fetch_$tag.log; exit 8; }
