@@ -689,14 +689,17 @@ template <class V> __device__ __forceinline__ void build_excl(const ExclD<typena
     constexpr int U = AWSEM_BUILD_UNROLL;   // candidate chunks in flight: the LDS round trips of one chunk hide behind the others
     for (int c = 0; c < d.nclass; c++) {
         const int base = d.class_start[c], n = d.class_start[c + 1] - base;
-        for (int dd = 1 + wave; dd < n; dd += nw) {
-            for (int i0 = 0; i0 + dd < n; i0 += 64 * U) {
+        // diagonal dd (n - dd pairs) and diagonal n - dd (dd pairs) share an iteration: n candidates, every lane busy when n is near 64
+        for (int dd = 1 + wave; dd <= (n >> 1); dd += nw) {
+            const int n1 = n - dd, nboth = n1 + (n1 != dd ? dd : 0);
+            for (int i0 = 0; i0 < nboth; i0 += 64 * U) {
                 int a[U], b[U], si[U];
                 bool pass[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    const int i = i0 + 64 * u + lane, j = i + dd;
-                    const bool v = j < n;
+                    const int idx = i0 + 64 * u + lane;
+                    const bool v = idx < nboth;
+                    const int i = idx < n1 ? idx : idx - n1, j = idx < n1 ? idx + dd : idx;   // second part: (idx - n1, idx - n1 + n - dd)
                     si[u] = base + (v ? i : 0);
                     a[u] = (int)tab[si[u]]; b[u] = (int)tab[base + (v ? j : 0)];
                     pass[u] = v;
@@ -752,15 +755,17 @@ template <class V> __device__ __forceinline__ void build_contact(const ContactD<
     for (int i = threadIdx.x; i < n; i += L.nthr) tab[i] = (unsigned)d.info[i];
     __syncthreads();
     constexpr int U = AWSEM_BUILD_UNROLL;
-    for (int dd = 1 + wave; dd < n; dd += nw) {
-        for (int i0 = 0; i0 + dd < n; i0 += 64 * U) {
+    for (int dd = 1 + wave; dd <= (n >> 1); dd += nw) {   // diagonals dd and n - dd together, as in build_excl
+        const int n1 = n - dd, nboth = n1 + (n1 != dd ? dd : 0);
+        for (int i0 = 0; i0 < nboth; i0 += 64 * U) {
             int si[U], sj[U], info_i[U], info_j[U], a[U], b[U];
             bool v[U];
             real r2[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int i = i0 + 64 * u + lane, j = i + dd;
-                v[u] = j < n;
+                const int idx = i0 + 64 * u + lane;
+                const int i = idx < n1 ? idx : idx - n1, j = idx < n1 ? idx + dd : idx;
+                v[u] = idx < nboth;
                 si[u] = v[u] ? i : 0; sj[u] = v[u] ? j : 0;
                 info_i[u] = (int)tab[si[u]]; info_j[u] = (int)tab[sj[u]]; a[u] = satom[si[u]]; b[u] = satom[sj[u]];
             }
