@@ -106,6 +106,7 @@ template <class real> struct BetaD {
     __host__ __device__ const real* table() const { return lambda; }
     __host__ __device__ unsigned entry_flag() const { return (unsigned)two_theta; }
     int group, two_theta, nacc, ndon, nres;
+    int scan_mode;                        // 1: the members of this term's list share one distance scan (build_hbond_group); 0: build_hbond per term
     const Int4* acc;                      // a1, a2, a3, residue
     const Int4* don;                      // d1, d2, d3, residue
     const real* lambda;                   // nres x nres, row = donor residue, pre-multiplied by -k (null when fn is set)
@@ -123,6 +124,7 @@ template <class real> struct PapD {
     __host__ __device__ const real* table() const { return gamma; }
     __host__ __device__ unsigned entry_flag() const { return 0u; }
     int group, nacc, ndon, nres;
+    int scan_mode;                        // as BetaD's
     const Int4* acc;                      // a1, a2, residue, -
     const Int4* don;                      // d1, d2, residue, -
     const real* gamma;                    // nres x nres, row = donor residue, pre-multiplied by -k (null when fn is set)
@@ -187,6 +189,8 @@ template <class real> struct DevSys {
     real skin_half2;                      // (skin/2)^2: lists are rebuilt once an atom has moved further than skin/2
     int remove_cm;                        // CMMotionRemover: subtract the mass-weighted mean velocity at the top of every step
     real inv_total_mass;                  // 1 / sum of the masses
+    const BetaD<real>* beta_dev;          // copies of beta[] / pap[] in device memory (static fields only): build_hbond_group reads its members'
+    const PapD<real>* pap_dev;            // descriptors from there, in a loop, instead of unrolling over the kernarg block
     int prio;                             // step kernel: how the replicas sharing a CU take turns at issue priority (0: hardware default, oldest wave first;
                                           // 1: rotating with the step count; 2: rotating with the clock; 3 | gain*16 << 8: rotation shifted by a
                                           // per-replica bias learnt from launch to launch, see pace_bias)

@@ -1399,6 +1399,33 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         int b = atoi(env);
         if (b >= 64 && b <= 1024 && (b & (b - 1)) == 0) block_ = b;   // a power of two: the kernels deal work to waves with masks
     }
+    // One distance scan for the hydrogen-bond terms that share a list (build_hbond_group): the members must screen the same atoms
+    // against the same radius, and a wave's share of the donors must fit a 64-bit mask (ndon <= 64 waves = block size).
+    if (!(getenv("AWSEM_HB_SCAN") && atoi(getenv("AWSEM_HB_SCAN")) == 0)) {
+        auto group_scan = [&](auto* terms, int n, const auto& hterms, int stride) {
+            for (int t = 0; t < n; t++) {
+                if (!terms[t].list_owner) continue;
+                std::vector<int> members;
+                for (int u = t; u < n; u++) if (terms[u].ls.list_id == terms[t].ls.list_id) members.push_back(u);
+                bool ok = members.size() >= 2 && terms[t].ndon <= block_ && terms[t].nacc > 0;
+                for (int u : members) {
+                    if (!ok) break;
+                    ok = terms[u].nacc == terms[t].nacc && terms[u].ndon == terms[t].ndon && terms[u].nres == terms[t].nres && terms[u].list_rc2 == terms[t].list_rc2 &&
+                         hterms[u].acc_res == hterms[t].acc_res && hterms[u].don_res == hterms[t].don_res;
+                    for (int i = 0; ok && i < terms[t].nacc; i++) ok = hterms[u].acc_atoms[stride * i] == hterms[t].acc_atoms[stride * i];
+                    for (int i = 0; ok && i < terms[t].ndon; i++) ok = hterms[u].don_atoms[stride * i] == hterms[t].don_atoms[stride * i];
+                }
+                if (!ok) continue;
+                const size_t words = ((size_t)terms[t].nres * terms[t].nres + 31) / 32;
+                const bool fits = ((size_t)terms[t].nacc + terms[t].ndon + members.size() * words) * 4 <= (size_t)natoms_ * (sizeof(real) == 4 ? 16 : 24);
+                for (int u : members) { terms[u].scan_mode = 1; if (!fits) terms[u].nz_lds = 0; }
+            }
+        };
+        group_scan(dsys_.beta, dsys_.n_beta, H.beta, 3);
+        group_scan(dsys_.pap, dsys_.n_pap, H.pap, 2);
+        if (dsys_.n_beta) dsys_.beta_dev = upload(std::vector<BetaD<real>>(dsys_.beta, dsys_.beta + dsys_.n_beta));
+        if (dsys_.n_pap) dsys_.pap_dev = upload(std::vector<PapD<real>>(dsys_.pap, dsys_.pap + dsys_.n_pap));
+    }
 }
 
 // Pair set of one pair term: rebuild that term's list with cutoff + skin and decode the entries.
@@ -1420,11 +1447,13 @@ template <class real> int Engine<real>::neighbors(int rep, int kind, int index, 
         ls = S.contact[index].ls; group = S.contact[index].group; break;
     case AWSEM_LIST_BETA:
         if (index < 0 || index >= S.n_beta) throw std::string("neighbors: no such beta term");
+        for (int t = 0; t < S.n_beta; t++) S.beta[t].scan_mode = 0;   // this term alone, by its own scan
         S.beta[index].list_rc2 = rc2(std::sqrt((double)S.beta[index].screen2)); ls = S.beta[index].ls; group = S.beta[index].group;
         for (int t = 0; t < S.n_beta; t++) if (t != index) S.beta[t].nacc = S.beta[t].ndon = 0;   // the terms that share the list stay out of it
         break;
     case AWSEM_LIST_PAP:
         if (index < 0 || index >= S.n_pap) throw std::string("neighbors: no such pap term");
+        for (int t = 0; t < S.n_pap; t++) S.pap[t].scan_mode = 0;
         S.pap[index].list_rc2 = rc2(std::sqrt((double)S.pap[index].cutoff2)); ls = S.pap[index].ls; group = S.pap[index].group;
         for (int t = 0; t < S.n_pap; t++) if (t != index) S.pap[t].nacc = S.pap[t].ndon = 0;
         break;

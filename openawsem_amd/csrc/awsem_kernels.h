@@ -1051,6 +1051,80 @@ template <class V, class Desc> __device__ __forceinline__ void build_hbond(const
     __syncthreads();
 }
 
+// The terms that share a list (beta_term_1/2/3; pap_term_1/2) screen the same atom pair (a1, d1) against the same radius: ONE distance
+// scan serves them all.  A lane keeps its acceptor; wave w tests the donors w, w + nw, ... and records the survivors as bits of a 64-bit
+// mask in a register (so at most 64 nw donors); every member then walks the set bits only -- a handful per lane instead of every donor
+// -- for its zero band, its table and its records.  (Three earlier forms of a shared scan, which staged the survivors in LDS or in the
+// list, lost to the per-term scans: DESIGN.md, rejected (xvi).  This one adds nothing to the chain of a surviving pair.)
+template <class V, class Desc> __device__ __forceinline__ void build_hbond_group(const Desc& d0, const Desc* __restrict__ terms, int lead, int nterms, const V& L, int* status) {
+    typedef typename V::real_t real;
+    AWSEM_WAVE_VARS;
+    const int resw = Desc::res_slot, list_id = d0.ls.list_id;
+    HbEntry<real>* e = (HbEntry<real>*)(L.lists + d0.ls.list_off);
+    unsigned* cnt = &L.lcount[list_id];
+    unsigned* sa = L.scratch();
+    unsigned* sd = sa + d0.nacc;
+    unsigned* sm = sd + d0.ndon;
+    const int words = (d0.nres * d0.nres + 31) >> 5;
+    for (int i = threadIdx.x; i < d0.nacc; i += L.nthr) { const Int4 A = d0.acc[i]; sa[i] = (unsigned)A.x | ((unsigned)(resw == 3 ? A.w : A.z) << 16); }
+    for (int i = threadIdx.x; i < d0.ndon; i += L.nthr) { const Int4 D = d0.don[i]; sd[i] = (unsigned)D.x | ((unsigned)(resw == 3 ? D.w : D.z) << 16); }
+    for (int u = lead, k = 0; u < nterms; u++) {
+        if (terms[u].ls.list_id != list_id || !terms[u].scan_mode) continue;
+        const unsigned* src = terms[u].nzmask;
+        if (terms[u].nz_lds && !terms[u].fn) for (int i = threadIdx.x; i < words; i += L.nthr) sm[k * words + i] = src[i];
+        k++;
+    }
+    __syncthreads();
+    for (int a0 = 0; a0 < d0.nacc; a0 += 64) {
+        const int ia = a0 + lane;
+        const bool va = ia < d0.nacc;
+        const unsigned A = sa[va ? ia : 0];
+        const R3<real> pa = L.pos((int)(A & 0xffffu));
+        const int ares = (int)(A >> 16);
+        const int q0 = (va ? ia : 0) % d0.ndon;
+        u64 mask = 0;
+        for (int dd = wave, k = 0; dd < d0.ndon; dd += nw, k++) {
+            const int t = q0 + dd, q = t >= d0.ndon ? t - d0.ndon : t;
+            const unsigned D = sd[q];
+            if (va && dist2(pa - L.pos((int)(D & 0xffffu))) < d0.list_rc2) mask |= 1ull << k;
+        }
+        for (int u = lead, member = 0; u < nterms; u++) {
+            if (terms[u].ls.list_id != list_id || !terms[u].scan_mode) continue;
+            const Desc d = terms[u];   // uniform: scalar loads from device memory
+            const unsigned* nz = d.nz_lds && !d.fn ? sm + member * words : d.nzmask;
+            member++;
+            u64 mm = mask;
+            while (__ballot(mm != 0) != 0) {
+                bool pass = mm != 0;
+                const int k = pass ? __ffsll((long long)mm) - 1 : 0;
+                mm &= mm - 1;
+                const int t = q0 + wave + k * nw, q = t >= d0.ndon ? t - d0.ndon : t;
+                const unsigned D = sd[q];
+                const int dres = (int)(D >> 16), dq = dres - ares;
+                pass = pass && (dq <= d.band_lo || dq >= d.band_hi);
+                HbEntry<real> ent;
+                ent.w0 = ent.w1 = ent.w2 = 0u; ent.c = (real)0;
+                if (pass) {
+                    if (d.fn) { const real v = hb_fn_value(*d.fn, dres, ares); pass = v != (real)0; ent.c = d.fn->scale * v; }   // uniform branch
+                    else {
+                        const unsigned bit = (unsigned)(dres * d.nres + ares);
+                        pass = (nz[bit >> 5] >> (bit & 31)) & 1u;
+                        if (pass) ent.c = d.table()[(size_t)dres * d.nres + ares];
+                    }
+                    if (pass) {
+                        const Int4 Aq = d.acc[ia], Dn = d.don[q];
+                        ent.w0 = (unsigned)Aq.x | (d.entry_flag() << 15) | ((unsigned)Dn.x << 16);
+                        if (resw == 3) { ent.w1 = ((unsigned)Aq.y & 0xffffu) | ((unsigned)Aq.z << 16); ent.w2 = ((unsigned)Dn.y & 0xffffu) | ((unsigned)Dn.z << 16); }
+                        else { ent.w1 = (unsigned)Aq.y & 0xffffu; ent.w2 = (unsigned)Dn.y & 0xffffu; }
+                    }
+                }
+                list_append_entry(e, cnt, d.ls.list_cap, status, pass, ent);
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // one (acceptor, donor) pair of a beta term; shared by the pair-list walk below and the cell-list rows (awsem_cell.h)
 // LISTED: the pair comes from an HbEntry record, which carries its coefficient and the two_theta flag of its term
 template <bool ENERGY, bool LISTED = false, class V> __device__ __forceinline__ void beta_pair(const BetaD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e,
@@ -1196,8 +1270,14 @@ template <class V> __device__ __forceinline__ void stage_tables(const DevSys<typ
 template <class V> __device__ __forceinline__ void build_lists(const DevSys<typename V::real_t>& S, const V& L, unsigned mask) {
     for (int t = 0; t < S.n_contact; t++) if (AWSEM_ON(S.contact[t])) build_contact(S.contact[t], L, L.satom + t * S.max_contact_sites, S.status);
     for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) build_excl(S.excl[t], L, S.status);
-    for (int t = 0; t < S.n_beta; t++) if (AWSEM_ON(S.beta[t])) build_hbond(S.beta[t], L, S.status);
-    for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) build_hbond(S.pap[t], L, S.status);
+    for (int t = 0; t < S.n_beta; t++) if (AWSEM_ON(S.beta[t])) {
+        if (!S.beta[t].scan_mode) build_hbond(S.beta[t], L, S.status);
+        else if (S.beta[t].list_owner) build_hbond_group(S.beta[t], S.beta_dev, t, S.n_beta, L, S.status);
+    }
+    for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) {
+        if (!S.pap[t].scan_mode) build_hbond(S.pap[t], L, S.status);
+        else if (S.pap[t].list_owner) build_hbond_group(S.pap[t], S.pap_dev, t, S.n_pap, L, S.status);
+    }
     for (int i = threadIdx.x; i < S.natoms; i += L.nthr) L.zero_force(i);   // the builders staged their tables in the accumulators
 }
 
