@@ -189,6 +189,8 @@ template <class real> struct DevSys {
     real skin_half2;                      // (skin/2)^2: lists are rebuilt once an atom has moved further than skin/2
     int remove_cm;                        // CMMotionRemover: subtract the mass-weighted mean velocity at the top of every step
     real inv_total_mass;                  // 1 / sum of the masses
+    real* list_ref;                       // [R][nmassive][3]: where the massive particles stood when the replica's lists were last built, and
+    unsigned* list_counts;                // [R][AWSEM_MAX_LISTS]: the lists' lengths -- what a step launch needs to go on with its predecessor's lists
     const BetaD<real>* beta_dev;          // copies of beta[] / pap[] in device memory (static fields only): build_hbond_group reads its members'
     const PapD<real>* pap_dev;            // descriptors from there, in a loop, instead of unrolling over the kernarg block
     int prio;                             // step kernel: how the replicas sharing a CU take turns at issue priority (0: hardware default, oldest wave first;

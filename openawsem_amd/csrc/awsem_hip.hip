@@ -195,7 +195,7 @@ public:
 
     void finalize(const HostSystem& H) override;
 
-    void set_positions(int rep, const double* xyz) override { set_state(pos_, rep, xyz); cell_stale_ = true; }
+    void set_positions(int rep, const double* xyz) override { set_state(pos_, rep, xyz); cell_stale_ = true; lists_valid_ = false; }
     void get_positions(int rep, double* xyz) override { get_state(pos_, rep, xyz); }
     void set_velocities(int rep, const double* v) override { set_state(vel_, rep, v); }
     void get_velocities(int rep, double* v) override { get_state(vel_, rep, v); }
@@ -203,7 +203,7 @@ public:
     void compute_virtual_sites() override {
         HIP_TRY(hipSetDevice(device_));
         synchronize();
-        cell_stale_ = true;
+        cell_stale_ = true; lists_valid_ = false;
         if (cell_mode_) hipLaunchKernelGGL(cell_vsite_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, pos_);
         else hipLaunchKernelGGL(awsem_vsite_kernel<real>, dim3(nrep_), dim3(64), 0, stream_, dsys_, pos_);
         HIP_TRY(hipGetLastError());
@@ -229,7 +229,7 @@ public:
         HIP_TRY(hipSetDevice(device_));
         if (cell_mode_) { cell_evaluate(true, mask, 0, e, nullptr); return; }
         HIP_TRY(hipEventRecord(ev0_, stream_));
-        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, dsys_, pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr);
+        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1_, stream_));
         HIP_TRY(hipMemcpyAsync(e, dE_, sizeof(double) * nrep_ * AWSEM_NGROUPS, hipMemcpyDeviceToHost, stream_));
@@ -241,7 +241,7 @@ public:
         HIP_TRY(hipSetDevice(device_));
         if (cell_mode_) { cell_evaluate(false, mask, redistribute, nullptr, f); return; }
         HIP_TRY(hipEventRecord(ev0_, stream_));
-        hipLaunchKernelGGL((awsem_eval_kernel<false, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, dsys_, pos_, mask, redistribute, (double*)nullptr, dF_, (const double*)nullptr);
+        hipLaunchKernelGGL((awsem_eval_kernel<false, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, eval_sys(), pos_, mask, redistribute, (double*)nullptr, dF_, (const double*)nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1_, stream_));
         HIP_TRY(hipMemcpyAsync(f, dF_, sizeof(double) * 3 * natoms_ * nrep_, hipMemcpyDeviceToHost, stream_));
@@ -290,7 +290,7 @@ public:
             HIP_TRY(hipMemcpy(out, e.data(), sizeof(double) * nrep_, hipMemcpyHostToDevice));
             return;
         }
-        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, dsys_, pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr);
+        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr);
         hipLaunchKernelGGL(awsem_group_sum_kernel, dim3((nrep_ + 255) / 256), dim3(256), 0, stream_, (const double*)dE_, mask, out, nrep_);
         HIP_TRY(hipGetLastError());
     }
@@ -330,7 +330,9 @@ public:
         if ((dsys_.prio & 0xff) == 3 && place_every_ > 0 && launch_ > 0 && launch_ % place_every_ == 0 && nrep_ <= 8192)   // deal the replicas to the CUs anew
             hipLaunchKernelGGL(awsem_place_kernel, dim3(1), dim3(1024), (size_t)nrep_ * sizeof(int), stream_, dsys_.prof, nrep_, dsys_.pace_group);
         hipLaunchKernelGGL(awsem_step_kernel<real>, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, (const double*)dT_, nsteps, dt, friction,
-                           (unsigned long long)seed, (long long)step0, launch_++);
+                           (unsigned long long)seed, (long long)step0, launch_++, (int)(list_reuse_ && lists_valid_ && skin_ <= lists_skin_));
+        lists_valid_ = nsteps > 0;
+        lists_skin_ = skin_;
         HIP_TRY(hipGetLastError());
         end_async();   // asynchronous: resolved by synchronize() / last_kernel_ms
     }
@@ -340,6 +342,7 @@ public:
         HIP_TRY(hipSetDevice(device_));
         if (!dmin_it_) { dmin_it_ = dalloc<int>(nrep_); dmin_rms_ = dalloc<double>(nrep_); }
         HIP_TRY(hipEventRecord(ev0_, stream_));
+        lists_valid_ = false;
         hipLaunchKernelGGL(awsem_minimize_kernel<real>, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, tolerance,
                            max_iterations > 0 ? max_iterations : 100000, dmin_it_, dmin_rms_);
         HIP_TRY(hipGetLastError());
@@ -370,7 +373,7 @@ public:
             for (int r = 0; r < nrep_; r++) for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++)
                 t[r * n3 + (size_t)k * natoms_ + in_(i)] = (real)src[r * n3 + 3 * (size_t)i + k];
             HIP_TRY(hipMemcpy(pass ? vel_ : pos_, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
-            if (!pass) cell_stale_ = true;
+            if (!pass) cell_stale_ = true; lists_valid_ = false;
         }
     }
     void get_state_all(double* xyz, double* v) override {
@@ -488,7 +491,7 @@ private:
         if (st) {
             HIP_TRY(hipMemset(dstatus_, 0, sizeof st));
             if (st & 2) {
-                cell_stale_ = true;
+                cell_stale_ = true; lists_valid_ = false;
                 throw std::string("neighbour list overflow on the cell-list path outside a replayable launch sequence: raise AWSEM_CELL_NEIGHBORS (partners reserved per contact site, default 96, grown to twice the fullest row when dynamics start)");
             }
             if (st & 4) throw std::string("a force exceeded the range of the fp32 fixed-point accumulators (2.6e5 kJ/mol/nm): overlapping atoms or an exploding "
@@ -590,6 +593,14 @@ private:
     double skin_ = 0.2;    // nm; AWSEM_SKIN overrides (0.15-0.3 measured: 0.2 and above rebuild rarely enough on the hot, extended stage of an annealing run)
     size_t lds_list_ = 0, lds_max_ = 0, n_cu_ = 256;
     int launch_ = 0;        // step launches so far (parity of the pacing records)
+    // A step launch goes on with the pair lists its predecessor left (DevSys::list_ref / list_counts) unless something has touched the
+    // positions since (every place that sets cell_stale_), or the skin has grown: lists built with a larger skin stay valid under a
+    // smaller one (the rebuild test only gets stricter), not the other way round.  Energy / force / neighbour queries build their lists
+    // in a buffer of their own (lists_eval_), so a reporter between two launches costs the dynamics nothing.  AWSEM_LIST_REUSE=0: off.
+    bool lists_valid_ = false, list_reuse_ = true;
+    double lists_skin_ = 0;
+    unsigned* lists_eval_ = nullptr;
+    DevSys<real> eval_sys() const { DevSys<real> S = dsys_; if (lists_eval_) S.lists = lists_eval_; return S; }
     int place_every_ = 16;  // launches between two placements of the replicas on the CUs (0: never), AWSEM_PLACE_EVERY
     bool step_ok_ = false;
 
@@ -1353,12 +1364,16 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         S.n_lists = id;
         S.list_stride = off ? off : 64;
         const double bytes = (double)S.list_stride * 4.0 * nrep_;
-        if (bytes > 64e9) {
+        if (2 * bytes > 128e9) {   // two buffers: the dynamics' lists and the queries'
             char msg[256];
             snprintf(msg, sizeof msg, "pair lists need %.1f GB for %d replicas of this system; use fewer replicas per handle", bytes / 1e9, nrep_);
             throw std::string(msg);
         }
         S.lists = dalloc<unsigned>((size_t)S.list_stride * nrep_);
+        lists_eval_ = dalloc<unsigned>((size_t)S.list_stride * nrep_);
+        S.list_ref = dalloc<real>((size_t)nrep_ * 3 * std::max(1, S.nmassive));
+        S.list_counts = dalloc<unsigned>((size_t)nrep_ * AWSEM_MAX_LISTS);
+        list_reuse_ = !(getenv("AWSEM_LIST_REUSE") && atoi(getenv("AWSEM_LIST_REUSE")) == 0);
         S.skin_half2 = (real)(0.25 * skin_ * skin_ * 0.999);
         dcounts_ = dalloc<unsigned>((size_t)nrep_ * AWSEM_MAX_LISTS);
     }
@@ -1432,7 +1447,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
 template <class real> int Engine<real>::neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) {
     HIP_TRY(hipSetDevice(device_));
     if (cell_mode_) return cell_neighbors(rep, kind, index, skin, pairs, capacity);
-    DevSys<real> S = dsys_;
+    DevSys<real> S = eval_sys();
     ListSlot ls;
     int group;
     auto rc2 = [&](double cutoff) { double r = cutoff + skin; return (real)(r * r); };
@@ -1630,7 +1645,7 @@ template <class real> void Engine<real>::cell_alloc_lists() {
     for (int t = 0; t < dsys_pap_n_; t++) hb_alloc(cell_hb_pap_[t], cell_nacc_pap_[t]);
     cell_hb_sync();
     cell_rows_gen_++;
-    cell_stale_ = true;
+    cell_stale_ = true; lists_valid_ = false;
 }
 // member records, displacement test, bounding box (and, when asked, the virtual sites)
 template <class real> void Engine<real>::cell_pre(bool step) {
@@ -1775,7 +1790,7 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
         synchronize();
         for (int attempt = 0;; attempt++) {
             cell_pre(false);
-            cell_stale_ = true;
+            cell_stale_ = true; lists_valid_ = false;
             cell_refresh(cell_);
             HIP_TRY(hipStreamSynchronize(stream_));
             int st = 0;
@@ -1808,7 +1823,7 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
             cell_per_site_ = std::max(2 * cell_per_site_ * ((st & 2) ? 1 : 0), (int)std::ceil(headroom * fullest));
             cell_alloc_lists();
         }
-        cell_stale_ = true;   // the step sequence below rebuilds once more through the ordinary path (virtual sites placed first)
+        cell_stale_ = true; lists_valid_ = false;   // the step sequence below rebuilds once more through the ordinary path (virtual sites placed first)
     }
     if (T && cell_pending_.empty() && !cell_replaying_) {   // first launch since the last synchronisation: the state a replay would start from
         const size_t nstate = (size_t)nrep_ * 3 * natoms_;
@@ -1872,7 +1887,7 @@ template <class real> void Engine<real>::cell_minimize(double tolerance, int max
     HIP_TRY(hipMemsetAsync(sums, 0, 2 * 3 * R * sizeof(u64), stream_));
     HIP_TRY(hipMemsetAsync(cell_.f, 0, nstate * sizeof(u64), stream_));
     HIP_TRY(hipEventRecord(ev0_, stream_));
-    cell_stale_ = true;
+    cell_stale_ = true; lists_valid_ = false;
     const dim3 g = cell_grid(dsys_.nmassive), b(256);
     int it = 0;
     bool all_done = false;
@@ -1909,7 +1924,7 @@ template <class real> void Engine<real>::cell_minimize(double tolerance, int max
     HIP_TRY(hipMemcpy(h.data(), st + R * (it & 1), R * sizeof(FireState<real>), hipMemcpyDeviceToHost));
     for (size_t r = 0; r < R; r++) { if (iterations) iterations[r] = h[r].iters; if (rms) rms[r] = h[r].rms; }
     dfree(fv); dfree(st); dfree(sums);
-    cell_stale_ = true;
+    cell_stale_ = true; lists_valid_ = false;
 }
 template <class real> int Engine<real>::cell_neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) {
     const bool hb = kind == AWSEM_LIST_BETA || kind == AWSEM_LIST_PAP;
@@ -1934,9 +1949,9 @@ template <class real> int Engine<real>::cell_neighbors(int rep, int kind, int in
             C.bin[b].rc2 = (real)(r * r);
         }
         cell_pre(false);
-        cell_stale_ = true;
+        cell_stale_ = true; lists_valid_ = false;
         cell_refresh(C);
-        cell_stale_ = true;   // the rows now hold a non-standard cutoff: rebuild before the next evaluation
+        cell_stale_ = true; lists_valid_ = false;   // the rows now hold a non-standard cutoff: rebuild before the next evaluation
         HIP_TRY(hipStreamSynchronize(stream_));
         int st = 0;
         HIP_TRY(hipMemcpy(&st, dstatus_, sizeof st, hipMemcpyDeviceToHost));

@@ -1756,7 +1756,7 @@ __device__ __forceinline__ void set_wave_priority(int p) {
 template <class real>
 __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, real* __restrict__ vel,
                                   const double* __restrict__ T, int nsteps, double dt, double friction, unsigned long long seed,
-                                  long long step0, int launch) {
+                                  long long step0, int launch, int reuse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     AWSEM_STAMP_WALL(S, 0);
     const long long pace_t0 = (S.prio & 0xff) == 3 ? (long long)wall_clock64() : 0;
@@ -1784,6 +1784,20 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
     const int prio_slot = uniform((int)L.flag[2]);
     const float prio_bias = paced ? __uint_as_float(uniform((int)L.flag[3])) : 0.f;
     compute_virtual_sites(S, L);
+    // `reuse`: the previous launch left this replica's lists, their lengths and the positions they were built at (host: step_impl keeps
+    // track of what invalidates them) -- go on with them; the displacement since then decides about the first rebuild like any other.
+    if (reuse) {
+        if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = S.list_counts[(size_t)rep * AWSEM_MAX_LISTS + threadIdx.x];
+        const real* gr = S.list_ref + (size_t)rep * 3 * S.nmassive;
+        float m = 0;
+        for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) {
+            const int i = S.massive[k].atom;
+            const R3<real> r{gr[3 * k], gr[3 * k + 1], gr[3 * k + 2]};
+            L.set_ref(i, r);
+            m = fmaxf(m, (float)dist2(L.pos(i) - r));
+        }
+        book_displacement(&L.flag[0], m);
+    }
     const bool cmr = S.remove_cm != 0;
     if (cmr) {   // momentum of the incoming velocities: what the first step removes (L.cm[0..2]; zeroed at the carve-up, a barrier ago)
         CmAcc<real> acc;
@@ -1797,7 +1811,7 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
     const bool fuse = S.fuse_vs != 0;
     for (int s = 0; s < nsteps; s++) {
         const int cur = s & 1;
-        const bool rebuild = s == 0 || __uint_as_float(L.flag[cur]) > (float)S.skin_half2;   // uniform across the workgroup
+        const bool rebuild = (s == 0 && !reuse) || __uint_as_float(L.flag[cur]) > (float)S.skin_half2;   // uniform across the workgroup
         if (S.prio == 1) set_wave_priority(prio_slot + s);   // this replica's turn at each of the four levels comes round every four steps
         else if (paced) {   // the same rotation, shifted by the replica's bias (dithered step by step, so a fractional bias acts as such)
             const int shift = (int)floorf(prio_bias + (float)(((unsigned)s * 2654435769u) >> 8) * (1.f / 16777216.f));
@@ -1908,6 +1922,14 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
         const int i = S.massive[k].atom;
         const R3<real> v = L.vel(k);
         gv[i] = v.x; gv[natoms + i] = v.y; gv[2 * natoms + i] = v.z;
+    }
+    {   // for the next launch (see `reuse` above)
+        real* gr = S.list_ref + (size_t)rep * 3 * S.nmassive;
+        for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) {
+            const R3<real> r = L.refpos(S.massive[k].atom);
+            gr[3 * k] = r.x; gr[3 * k + 1] = r.y; gr[3 * k + 2] = r.z;
+        }
+        if (threadIdx.x < AWSEM_MAX_LISTS) S.list_counts[(size_t)rep * AWSEM_MAX_LISTS + threadIdx.x] = L.lcount[threadIdx.x];
     }
     AWSEM_STAMP_WALL(S, 1);
 #if defined(AWSEM_PROF) || defined(AWSEM_WALL)

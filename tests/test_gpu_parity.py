@@ -320,6 +320,47 @@ def test_pacing_and_placement_leave_the_trajectories_alone(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", [FP32, FP64])
+def test_lists_carried_from_launch_to_launch_change_nothing(precision, monkeypatch):
+    """A step launch goes on with the pair lists, list lengths and reference positions its predecessor left in device memory
+    (csrc/awsem_kernels.h, `reuse`) instead of rebuilding at its first step.  Lists are supersets of the interacting pairs and the sums
+    are fixed point, so WHEN a list is rebuilt cannot show: launches interleaved with everything that must invalidate the carried lists
+    (new positions for one replica, a minimisation, a warmer launch = larger skin) or must not (energies, forces, neighbour queries,
+    new velocities) end bit for bit where AWSEM_LIST_REUSE=0 ends."""
+    monkeypatch.delenv("AWSEM_FORCE_CELL", raising=False)
+    oa, traj, _ = golden_system("1ubq")
+    R = 6
+    out = []
+    for reuse in ("1", "0"):
+        monkeypatch.setenv("AWSEM_LIST_REUSE", reuse)
+        gpu = _gpu(oa, R, precision)
+        for r in range(R):
+            gpu.set_positions(traj[(3 * r) % len(traj)], replica=r)
+        T = np.linspace(300.0, 700.0, R)
+        gpu.set_velocities_to_temperature(T, 5)
+        log = []
+        for it in range(4):
+            gpu.step(15, T - 20.0 * it, 0.002, 1.0, 6)          # cooling: the skin shrinks, the lists stay
+        log.append(gpu.energy_by_group())                        # queries between launches: lists of their own
+        gpu.forces()
+        gpu.neighbors(_capi.LIST_CONTACT, 0, 1, 0.1)
+        gpu.step(15, T - 80.0, 0.002, 1.0, 6)
+        gpu.set_positions(traj[1], replica=2)                    # one replica moved from outside
+        gpu.step(15, T - 80.0, 0.002, 1.0, 6)
+        gpu.set_velocities_to_temperature(T + 100.0, 7)
+        gpu.step(15, T + 100.0, 0.002, 1.0, 6)                   # warmer: larger skin
+        gpu.step(15, T + 100.0, 0.002, 1.0, 6)
+        log.append(gpu.energy_by_group())
+        out.append((gpu.get_state(), log))
+        gpu.close()
+    monkeypatch.delenv("AWSEM_LIST_REUSE", raising=False)
+    assert np.array_equal(out[0][0][0], out[1][0][0]) and np.array_equal(out[0][0][1], out[1][0][1])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b)
+    assert np.isfinite(out[0][0][0]).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("knob", ["AWSEM_BETA_SCREEN", "AWSEM_PAP_SCREEN"])
 def test_beta_screen_drops_only_exact_zeros(knob, monkeypatch):
     """fp32: the beta terms skip a pair once its Gaussian factor is below e^-X, X chosen at finalize so that every force component of a
