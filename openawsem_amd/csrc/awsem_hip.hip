@@ -844,7 +844,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         S.remove_cm = H.remove_cm && mtot > 0 ? 1 : 0;
         S.inv_total_mass = mtot > 0 ? (real)(1.0 / mtot) : (real)0;
         S.prio = getenv("AWSEM_PRIO") ? atoi(getenv("AWSEM_PRIO")) : 3;   // 0 switches the rotation off, 1 is the plain rotation (A/B runs)
-        if (S.prio == 3) S.prio |= (int)lround(16.0 * (getenv("AWSEM_PACE_GAIN") ? atof(getenv("AWSEM_PACE_GAIN")) : 10.0)) << 8;
+        if (S.prio == 3) S.prio |= ((int)lround(16.0 * (getenv("AWSEM_PACE_GAIN") ? atof(getenv("AWSEM_PACE_GAIN")) : 10.0)) & 0xffff) << 8
+                                 | ((getenv("AWSEM_PACE_BOOST") ? atoi(getenv("AWSEM_PACE_BOOST")) : 4) & 15) << 24;
         S.pace_group = (int)n_cu_;
         std::vector<MassiveItem<real>> mv;
         for (int i = 0; i < natoms_; i++) if (H.mass[i] > 0) mv.push_back(MassiveItem<real>{i, im[i], sim[i], to_orig_.empty() ? i : to_orig_[i]});

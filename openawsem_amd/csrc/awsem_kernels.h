@@ -1725,7 +1725,7 @@ template <class real> __device__ __forceinline__ float pace_bias(const DevSys<re
     }
     if (n < 2) return bias;
     const float lag = -(float)sum / ((float)n * dur);                  // own end behind the CU's mean end, as a fraction of the launch
-    bias += (float)(S.prio >> 8) * 0.0625f * lag;
+    bias += (float)((S.prio >> 8) & 0xffff) * 0.0625f * lag;
     return bias < -3.f ? -3.f : bias > 3.f ? 3.f : bias;
 }
 template <class real> __device__ __forceinline__ void pace_record(const DevSys<real>& S, int rep, int nrep, int launch, unsigned cu, float bias, long long t0) {
@@ -1809,6 +1809,7 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
     // The lists are rebuilt when a MASSIVE particle has moved further than skin/2 since the last build; lists screened on a
     // virtual site carry a correspondingly larger margin (host: list_margin), so the sites need no displacement test.
     const bool fuse = S.fuse_vs != 0;
+    int boost_left = 0;
     for (int s = 0; s < nsteps; s++) {
         const int cur = s & 1;
         const bool rebuild = (s == 0 && !reuse) || __uint_as_float(L.flag[cur]) > (float)S.skin_half2;   // uniform across the workgroup
@@ -1816,7 +1817,11 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
         else if (paced) {   // the same rotation, shifted by the replica's bias (dithered step by step, so a fractional bias acts as such)
             const int shift = (int)floorf(prio_bias + (float)(((unsigned)s * 2654435769u) >> 8) * (1.f / 16777216.f));
             const int p = ((prio_slot + s) & 3) + shift;
-            set_wave_priority(p < 0 ? 0 : p > 3 ? 3 : p);
+            // a rebuild sets the replica back by about one step against its companions, which no earlier launch could foresee: it goes
+            // first for the next few steps
+            if (rebuild && s > 0) boost_left = (S.prio >> 24) & 15;
+            if (boost_left > 0) { boost_left--; set_wave_priority(3); }
+            else set_wave_priority(p < 0 ? 0 : p > 3 ? 3 : p);
         }
         else if (S.prio == 2) set_wave_priority(prio_slot + (int)(wall_clock64() >> 11));   // by the clock instead (100 MHz: turns of 20 us); measured equal
         if (cmr && threadIdx.x < 3) {
