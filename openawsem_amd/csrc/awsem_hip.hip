@@ -220,8 +220,9 @@ public:
     void scale_velocities(const double* scale) override {
         HIP_TRY(hipSetDevice(device_));
         synchronize();
-        upload_T(scale);   // reuses the per-replica double buffer
-        hipLaunchKernelGGL(awsem_scale_velocities_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, vel_, dT_, 3 * natoms_);
+        HIP_TRY(hipMemcpyAsync(dtmp_, scale, sizeof(double) * nrep_, hipMemcpyHostToDevice, stream_));   // not dT_: on a replica-exchange handle that holds the ladder's temperatures
+        HIP_TRY(hipStreamSynchronize(stream_));   // scale is a caller-owned pageable buffer
+        hipLaunchKernelGGL(awsem_scale_velocities_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, vel_, dtmp_, 3 * natoms_);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream_));
     }
@@ -329,7 +330,7 @@ public:
         begin_async(T);
         if ((dsys_.prio & 0xff) == 3 && place_every_ > 0 && launch_ > 0 && launch_ % place_every_ == 0 && nrep_ <= 8192)   // deal the replicas to the CUs anew
             hipLaunchKernelGGL(awsem_place_kernel, dim3(1), dim3(1024), (size_t)nrep_ * sizeof(int), stream_, dsys_.prof, nrep_, dsys_.pace_group);
-        hipLaunchKernelGGL(awsem_step_kernel<real>, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, (const double*)dT_, nsteps, dt, friction,
+        hipLaunchKernelGGL(awsem_step_kernel<real>, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, step_T_, nsteps, dt, friction,
                            (unsigned long long)seed, (long long)step0, launch_++, (int)(list_reuse_ && lists_valid_ && skin_ <= lists_skin_));
         lists_valid_ = nsteps > 0;
         lists_skin_ = skin_;
@@ -356,9 +357,9 @@ public:
     void kinetic_energy(double* ke) override {
         HIP_TRY(hipSetDevice(device_));
         synchronize();
-        hipLaunchKernelGGL(awsem_kinetic_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, vel_, dT_);   // dT_: per-replica double scratch
+        hipLaunchKernelGGL(awsem_kinetic_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, vel_, dtmp_);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(ke, dT_, sizeof(double) * nrep_, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipMemcpyAsync(ke, dtmp_, sizeof(double) * nrep_, hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
     }
     // whole ensemble at once: one copy of the SoA device array, transposed on the host
@@ -470,12 +471,18 @@ private:
         if (npend_ == NRING) synchronize();
         const int k = npend_;
         if (!ring0_[k]) { HIP_TRY(hipEventCreate(&ring0_[k])); HIP_TRY(hipEventCreate(&ring1_[k])); HIP_TRY(hipHostMalloc((void**)&ringT_[k], sizeof(double) * nrep_, hipHostMallocDefault)); }
-        if (T) {   // null: the temperatures are on the device already (replica exchange)
+        // null: the temperatures are on the device already (replica exchange).  Otherwise the kernel reads them from this launch's
+        // slot of pinned host memory itself (one double per workgroup): no copy between two launches on the stream
+        step_T_ = dT_;
+        if (T) {
             memcpy(ringT_[k], T, sizeof(double) * nrep_);
-            HIP_TRY(hipMemcpyAsync(dT_, ringT_[k], sizeof(double) * nrep_, hipMemcpyHostToDevice, stream_));
+            if (cell_mode_ || !zero_copy_T_) HIP_TRY(hipMemcpyAsync(dT_, ringT_[k], sizeof(double) * nrep_, hipMemcpyHostToDevice, stream_));
+            else step_T_ = ringT_[k];
         }
         HIP_TRY(hipEventRecord(ring0_[k], stream_));
     }
+    const double* step_T_ = nullptr;
+    bool zero_copy_T_ = !(getenv("AWSEM_ZERO_COPY_T") && atoi(getenv("AWSEM_ZERO_COPY_T")) == 0);
     void end_async() {
         HIP_TRY(hipEventRecord(ring1_[npend_], stream_));
         npend_++;
@@ -557,6 +564,7 @@ private:
     DevSys<real> dsys_;
     real *pos_ = nullptr, *vel_ = nullptr;
     double *dT_ = nullptr, *dE_ = nullptr, *dF_ = nullptr;
+    double* dtmp_ = nullptr;   // per-replica doubles for everything that is not a temperature (kinetic energies, velocity factors)
     const HostSystem* host_ = nullptr;   // the system as the kernels see it: the handle's, or hint_ when the atoms are renumbered
     HostSystem hint_;                    // the handle's system in the internal atom order (replica-resident path)
     std::vector<int> to_int_, to_orig_;  // caller's atom index <-> internal (empty: identical)
@@ -1385,7 +1393,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     pos_ = dalloc<real>(nstate); vel_ = dalloc<real>(nstate);
     HIP_TRY(hipMemset(pos_, 0, nstate * sizeof(real)));
     HIP_TRY(hipMemset(vel_, 0, nstate * sizeof(real)));
-    dT_ = dalloc<double>(nrep_); dE_ = dalloc<double>((size_t)nrep_ * AWSEM_NGROUPS); dF_ = dalloc<double>(nstate);
+    dT_ = dalloc<double>(nrep_); dtmp_ = dalloc<double>(nrep_); dE_ = dalloc<double>((size_t)nrep_ * AWSEM_NGROUPS); dF_ = dalloc<double>(nstate);
 
     if (cell_mode_) {   // the cell-list kernels use no dynamic LDS
         cell_.f = dalloc<u64>(nstate);

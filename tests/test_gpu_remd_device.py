@@ -59,6 +59,26 @@ def test_device_sweeps_equal_host_sweeps(precision, cell, monkeypatch):
     a.close(); b.close()
 
 
+def test_queries_between_sweeps_leave_the_ladder_temperatures_alone():
+    """The device keeps the ladder's temperatures between sweeps; kinetic-energy and velocity-factor calls use a buffer of their own
+    (they once shared it: a StateDataReporter between two sweeps would have turned kinetic energies into temperatures)."""
+    oa, traj, _ = golden_system("1ubq")
+    n = 6
+    T = np.linspace(300.0, 350.0, n)
+    rex = ensemble.ReplicaExchange(T, seed=5)
+    gpu = _start(oa, traj, n, 0)
+    gpu.set_velocities_to_temperature(rex.local_temperatures(), 3)
+    rex.attach(gpu)
+    gpu.step_remd(10, 0.002, 1.0, 9)
+    before = gpu.remd_state()[3].copy()
+    ke = gpu.kinetic_energy()
+    gpu.scale_velocities(np.ones(n))
+    assert np.array_equal(gpu.remd_state()[3], before) and np.array_equal(before, T) and np.all(ke > 0)
+    gpu.step_remd(10, 0.002, 1.0, 9)
+    assert np.isfinite(gpu.get_state()[0]).all()
+    gpu.close()
+
+
 def test_sharded_ladder_with_a_gather_index_takes_the_same_decisions():
     """Two handles play two ranks inside one process: each holds a block of the ladder (4 + 3 replicas) and writes its energies into
     its padded block of one shared device buffer, as two ranks would through the all-gather (shards padded to 4: replica r of rank 1
