@@ -187,6 +187,7 @@ public:
         }
         for (auto& G : cell_graph_) if (G.exec) (void)hipGraphExecDestroy(G.exec);
         for (void* p : allocs_) (void)hipFree(p);
+        if (h_lmean_) (void)hipHostFree(h_lmean_);
         for (int k = 0; k < NRING; k++) { if (ring0_[k]) (void)hipEventDestroy(ring0_[k]); if (ring1_[k]) (void)hipEventDestroy(ring1_[k]); if (ringT_[k]) (void)hipHostFree(ringT_[k]); }
         if (ev0_) (void)hipEventDestroy(ev0_);
         if (ev1_) (void)hipEventDestroy(ev1_);
@@ -334,6 +335,10 @@ public:
                            (unsigned long long)seed, (long long)step0, launch_++, (int)(list_reuse_ && lists_valid_ && skin_ <= lists_skin_));
         lists_valid_ = nsteps > 0;
         lists_skin_ = skin_;
+        if (skin_adapt_ && !skin_fixed_ && h_lmean_ && nsteps > 0 && launch_ % 8 == 1) {   // (launch_ was incremented above)
+            lmean_skin_ = skin_;
+            hipLaunchKernelGGL(awsem_list_mean_kernel, dim3(1), dim3(256), 0, stream_, (const long long*)dsys_.prof, nrep_, (double)++lmean_tag_, (volatile double*)h_lmean_);
+        }
         HIP_TRY(hipGetLastError());
         end_async();   // asynchronous: resolved by synchronize() / last_kernel_ms
     }
@@ -586,8 +591,24 @@ private:
         double tmax = T ? 0 : remd_tmax_;   // null: a replica-exchange launch, any replica may hold the hottest rung
         for (int r = 0; T && r < nrep_; r++) tmax = std::max(tmax, T[r]);
         static const double sa = getenv("AWSEM_SKIN_A") ? atof(getenv("AWSEM_SKIN_A")) : -0.0125, sb = getenv("AWSEM_SKIN_B") ? atof(getenv("AWSEM_SKIN_B")) : 0.000375;   // tuning knobs
-        const double skin = std::min(0.25, std::max(0.07, sa + sb * tmax));
+        double skin = std::min(0.25, std::max(0.07, sa + sb * tmax));
+        // Once the lists' lengths are known (every 8th launch asks for their mean, awsem_list_mean_kernel; the answer is picked up here
+        // without waiting for it) the skin follows what the optimum depends on: rebuilds cost ~ N^2 sqrt(T) / skin per step, walks
+        // ~ L (r + skin)^3, so skin_opt ~ N T^(1/4) / sqrt(L).  Calibrated on 1r69 (63 sites) in eight states -- the default schedule and
+        // one five times slower, 650 ... 300 K: the constant came out within 10 % in all of them -- where a rule in T alone is right
+        // for one schedule only (equilibrated chains at 500 K want 0.13 nm, the default schedule's 0.19).
+        if (skin_adapt_ && h_lmean_ && lmean_tag_ > 0 && h_lmean_[1] == (double)lmean_tag_) {
+            const double m = 1.3, r_eff = 0.8;   // the lists' mean cutoff and the mean factor on the skin (virtual-site margins)
+            const double f = (r_eff + 0.1 * m) / (r_eff + lmean_skin_ * m);
+            lhat_ = h_lmean_[0] * f * f * f;      // listed pairs per replica, referred to a skin of 0.1 nm
+        }
+        if (skin_adapt_ && lhat_ > 0) {
+            static const double c = getenv("AWSEM_SKIN_C") ? atof(getenv("AWSEM_SKIN_C")) : 0.91 / 63.0;
+            const double want = std::min(0.25, std::max(0.07, c * skin_sites_ * std::sqrt(std::sqrt(std::max(tmax, 1.0))) / std::sqrt(lhat_)));
+            skin = want > skin_ && want < skin_ + 0.01 ? skin_ : want;   // a growing skin costs a rebuild of everything: only for a real change
+        }
         if (std::fabs(skin - skin_) < 2e-3) return;
+        if (getenv("AWSEM_INFO")) fprintf(stderr, "[awsem] skin %.3f -> %.3f nm (T %.0f K, %.0f listed pairs per replica at 0.1 nm)\n", skin_, skin, tmax, lhat_);
         skin_ = skin;
         DevSys<real>& S = dsys_;
         size_t k = 0;
@@ -598,6 +619,10 @@ private:
         for (int t = 0; t < S.n_pap; t++) S.pap[t].list_rc2 = rc2();
         S.skin_half2 = (real)(0.25 * skin_ * skin_ * 0.999);
     }
+    bool skin_adapt_ = !(getenv("AWSEM_SKIN_ADAPT") && atoi(getenv("AWSEM_SKIN_ADAPT")) == 0);
+    double* h_lmean_ = nullptr;   // pinned: {mean listed pairs per replica, tag of the request}
+    long long lmean_tag_ = 0;
+    double lmean_skin_ = 0, lhat_ = 0, skin_sites_ = 63;
     double skin_ = 0.2;    // nm; AWSEM_SKIN overrides (0.15-0.3 measured: 0.2 and above rebuild rarely enough on the hot, extended stage of an annealing run)
     size_t lds_list_ = 0, lds_max_ = 0, n_cu_ = 256;
     int launch_ = 0;        // step launches so far (parity of the pacing records)
@@ -1383,6 +1408,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         S.list_ref = dalloc<real>((size_t)nrep_ * 3 * std::max(1, S.nmassive));
         S.list_counts = dalloc<unsigned>((size_t)nrep_ * AWSEM_MAX_LISTS);
         list_reuse_ = !(getenv("AWSEM_LIST_REUSE") && atoi(getenv("AWSEM_LIST_REUSE")) == 0);
+        if (!h_lmean_) { HIP_TRY(hipHostMalloc((void**)&h_lmean_, 2 * sizeof(double), hipHostMallocDefault)); h_lmean_[0] = h_lmean_[1] = 0; }
+        skin_sites_ = S.max_contact_sites > 0 ? (double)S.max_contact_sites : (double)natoms_ / 6.0;
         S.skin_half2 = (real)(0.25 * skin_ * skin_ * 0.999);
         dcounts_ = dalloc<unsigned>((size_t)nrep_ * AWSEM_MAX_LISTS);
     }

@@ -1940,12 +1940,24 @@ __global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __
 #if defined(AWSEM_PROF) || defined(AWSEM_WALL)
     if ((int)threadIdx.x < S.n_lists) S.prof[16 + 7 * (size_t)gridDim.x + 16 * 20 + (size_t)rep * AWSEM_MAX_LISTS + threadIdx.x] = L.lcount[threadIdx.x];
 #endif
-    if (paced && threadIdx.x == 0) {
-        pace_record(S, rep, (int)gridDim.x, launch, pace_cu, prio_bias, pace_t0);
+    if (threadIdx.x == 0) {
+        if (paced) pace_record(S, rep, (int)gridDim.x, launch, pace_cu, prio_bias, pace_t0);
         int c = 0;
         for (int l = 0; l < S.n_lists; l++) c += (int)L.lcount[l];
-        pace_cost(S, (int)gridDim.x)[rep] = c;
+        pace_cost(S, (int)gridDim.x)[rep] = c;   // read by the placement and by the skin rule (awsem_list_mean_kernel)
     }
+}
+// Mean number of listed pairs per replica after the last launch, for the host's skin rule: written to pinned host memory as
+// {mean, tag} -- the tag last, behind a system-scope fence, so that a host that sees the tag of its request sees that request's mean.
+__global__ void awsem_list_mean_kernel(const long long* prof, int nrep, double tag, volatile double* out) {
+    __shared__ double part[256];
+    const int* cost = (const int*)(prof + pace_perm_offset(nrep)) + nrep;
+    double s = 0;
+    for (int r = threadIdx.x; r < nrep; r += 256) s += (double)cost[r];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) { out[0] = part[0] / (double)nrep; __threadfence_system(); out[1] = tag; }
 }
 // One workgroup: rank the replicas by cost (heaviest first) and deal them to the CUs boustrophedon -- row 0 left to right, row 1 right
 // to left, ... -- so that the workgroups b, b + group, b + 2 group, ... of a CU hold one replica of every weight class.

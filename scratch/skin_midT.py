@@ -13,7 +13,7 @@ ctx.set_positions(oa.pdb.positions, replica=-1)
 ctx.set_velocities_to_temperature(np.full(R, 800.0), 2026)
 n = int(round((800.0 - T0) / 1.5))
 for i in range(n):
-    ctx.step(250, np.full(R, 800.0 - 1.5 * i), 0.002, 1.0, 2026)     # 5x the default stage length: closer to equilibrium at T0
+    ctx.step(int(os.environ.get("PER_STAGE", "250")), np.full(R, 800.0 - 1.5 * i), 0.002, 1.0, 2026)     # default 5x the default stage length: closer to equilibrium at T0
 for _ in range(5):
     ctx.step(50, np.full(R, T0), 0.002, 1.0, 2026)
 ctx.synchronize()

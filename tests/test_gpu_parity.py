@@ -320,6 +320,34 @@ def test_pacing_and_placement_leave_the_trajectories_alone(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_the_skin_rule_cannot_show_in_a_trajectory(monkeypatch):
+    """The skin only decides how often the lists are rebuilt and how long they are (supersets of the interacting pairs either way):
+    the rule that follows the lists' lengths (default), the rule in T alone (AWSEM_SKIN_ADAPT=0) and two pinned skins end twelve
+    launches of a cooling ensemble bit for bit alike."""
+    monkeypatch.delenv("AWSEM_FORCE_CELL", raising=False)
+    oa, traj, _ = golden_system("1ubq")
+    R = 40
+    out = []
+    for env in ({}, {"AWSEM_SKIN_ADAPT": "0"}, {"AWSEM_SKIN": "0.08"}, {"AWSEM_SKIN": "0.3"}):
+        for k in ("AWSEM_SKIN_ADAPT", "AWSEM_SKIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        gpu = _gpu(oa, R, FP32)
+        for r in range(R):
+            gpu.set_positions(traj[r % len(traj)], replica=r)
+        gpu.set_velocities_to_temperature(np.full(R, 700.0), 5)
+        for it in range(12):
+            gpu.step(25, np.full(R, 700.0 - 30.0 * it), 0.002, 1.0, 6)
+        out.append(gpu.get_state())
+        gpu.close()
+    for k in ("AWSEM_SKIN_ADAPT", "AWSEM_SKIN"):
+        monkeypatch.delenv(k, raising=False)
+    for x, v in out[1:]:
+        assert np.array_equal(x, out[0][0]) and np.array_equal(v, out[0][1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("precision", [FP32, FP64])
 def test_lists_carried_from_launch_to_launch_change_nothing(precision, monkeypatch):
     """A step launch goes on with the pair lists, list lengths and reference positions its predecessor left in device memory
