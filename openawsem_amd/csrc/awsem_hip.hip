@@ -1442,6 +1442,11 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         size_t per_cu = std::max<size_t>(1, lds_max / std::max<size_t>(1, step_ok_ ? lds_step_ : lds_eval_));
         per_cu = std::min(per_cu, std::max<size_t>(1, ((size_t)nrep_ + n_cu_ - 1) / n_cu_));   // fewer replicas than slots: a CU holds fewer (1r69, <= 256 replicas: 14.3 -> 12.1 us per step)
         block_ = per_cu >= 4 ? 256 : per_cu >= 2 && per_cu * 512 <= 1024 ? 512 : per_cu == 1 ? 1024 : 256;   // powers of two only: 320 threads (three replicas per CU) were measured 70 % slower than 256
+        // The priority bias is learnt from the end times of the workgroups that shared a CU from the first step to the last: that is a
+        // grid of one wave.  With more replicas than slots workgroups start whenever a slot frees up and their end times say nothing
+        // about each other (measured: 2048 / 4096 replicas of 1r69 lose 4-6 % with the feedback on, 0.8 % with the gain at zero): the
+        // plain rotation takes over.
+        if ((dsys_.prio & 0xff) == 3 && (size_t)nrep_ > (size_t)n_cu_ * std::min<size_t>(per_cu, 4)) { dsys_.prio = 1; place_every_ = 0; }
     }
     if (getenv("AWSEM_INFO"))
         fprintf(stderr, "[awsem] %d atoms x %d replicas: LDS %zu B per replica stepping (%zu B evaluating) of %zu B per CU -> %zu per CU, %d threads per replica\n",
