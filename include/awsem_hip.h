@@ -164,6 +164,13 @@ int awsem_add_hbond_pap_fn(awsem_handle h, int group, int nacc, const int32_t* a
 /* helical_term hydrogenBondTerms.py:790-832: E = -coef theta(O_i; N_{i+4}, H_{i+4}), coef = k(fa_i + fa_{i+4}). */
 int awsem_add_helical(awsem_handle h, int group, int n, const int32_t* atoms3, const double* coef, double r_ON,
                       double sigma_NO, double r_OH, double sigma_HO);
+/* z_dependent_helical_term hydrogenBondTerms.py:835-887 (CustomCompoundBondForce(4): O_i, N_{i+4}, H_{i+4}, CA_i):
+ * E = -theta ((1 - alpha) coef + alpha coef_membrane), alpha = 1/2 tanh(eta (z + z_m)) + 1/2 tanh(eta (z_m - z)),
+ * z = z(CA_i) - membrane_center; coef = k(fa_i + fa_{i+4}) with the water propensities, coef_membrane with the membrane ones.
+ * atoms4: n x (O, N, H, CA). */
+int awsem_add_helical_z(awsem_handle h, int group, int n, const int32_t* atoms4, const double* coef, const double* coef_membrane,
+                        double r_ON, double sigma_NO, double r_OH, double sigma_HO, double eta_switching, double z_m,
+                        double membrane_center);
 
 /* fragment_memory_term templateTerms.py:122-294 (CustomCompoundBondForce(2) + Discrete2DFunction):
  * E = -k_fm lerp(table[b][i], table[b][i+1]) with i = min(ntab-2, floor(r/dr)); table is nbonds x ntab, row major. */

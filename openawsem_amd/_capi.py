@@ -40,6 +40,8 @@ _SIGNATURES = {
     "add_hbond_pap_fn": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int, C.c_int, c_int_p, c_dbl_p,
                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
     "add_helical": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "add_helical_z": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, c_dbl_p, C.c_double, C.c_double, C.c_double, C.c_double,
+                                C.c_double, C.c_double, C.c_double]),
     "add_fragment_memory": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, C.c_int, c_dbl_p, C.c_double, C.c_double]),
     "add_membrane": (C.c_int, ["H", C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double, C.c_double, C.c_double]),
     "add_external": (C.c_int, ["H", C.c_int, C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_double, C.c_double]),
@@ -247,6 +249,12 @@ class Context:
     def add_helical(self, group, atoms3, coef, r_ON, sigma_NO, r_OH, sigma_HO):
         a, c = _i32(atoms3).reshape(-1), _f64(coef)
         self._call("add_helical", group, len(c), _ip(a), _dp(c), float(r_ON), float(sigma_NO), float(r_OH), float(sigma_HO))
+
+    def add_helical_z(self, group, atoms4, coef, coef_membrane, r_ON, sigma_NO, r_OH, sigma_HO, eta_switching, z_m, membrane_center):
+        a, c, cm = _i32(atoms4).reshape(-1), _f64(coef), _f64(coef_membrane)
+        assert len(a) == 4 * len(c) and len(cm) == len(c)
+        self._call("add_helical_z", group, len(c), _ip(a), _dp(c), _dp(cm), float(r_ON), float(sigma_NO), float(r_OH), float(sigma_HO),
+                   float(eta_switching), float(z_m), float(membrane_center))
 
     def add_fragment_memory(self, group, pairs, table, k_fm, dr):
         p, t = _i32(pairs).reshape(-1), _f64(table)

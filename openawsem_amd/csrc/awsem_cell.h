@@ -617,7 +617,7 @@ template <bool ENERGY, class real> __global__ void cell_bonded_kernel(DevSys<rea
     case CJ_HARM: { HarmD<real> d = S.harm[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f); term_harmonic<ENERGY>(d, L); } break;
     case CJ_CHI: { ChiD<real> d = S.chi[job.term]; if (!AWSEM_ON(d)) return; d.atoms += f; d.n = min(256, d.n - f); term_chi<ENERGY>(d, L); } break;
     case CJ_RAMA: { RamaD<real> d = S.rama[job.term]; if (!AWSEM_ON(d)) return; d.atoms += f; d.bw += (size_t)f * d.nwell; d.n = min(256, d.n - f); term_rama<ENERGY>(d, L); } break;
-    case CJ_HELICAL: { HelicalD<real> d = S.helical[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f); term_helical<ENERGY>(d, L); } break;
+    case CJ_HELICAL: { HelicalD<real> d = S.helical[job.term]; if (!AWSEM_ON(d)) return; d.items += f; if (d.zitems) d.zitems += f; d.n = min(256, d.n - f); term_helical<ENERGY>(d, L); } break;
     case CJ_FM: { FmD<real> d = S.fm[job.term]; if (!AWSEM_ON(d)) return; d.pairs2 += 2 * (size_t)f; d.table2 += (size_t)f * (d.ntab - 1); d.n = min(256, d.n - f); term_fm<ENERGY, false>(d, L); } break;
     case CJ_MEMB: { MembD<real> d = S.memb[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f); term_memb<ENERGY>(d, L); } break;
     case CJ_DH: { DhD<real> d = S.dh[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f); term_dh<ENERGY>(d, L); } break;
@@ -656,7 +656,7 @@ template <bool ENERGY, class real> __global__ void cell_window_kernel(DevSys<rea
     for (int t = 0; t < S.n_harm; t++, ws += stride) { HarmD<real> d = S.harm[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.items += ws[0]; d.n = ws[1] - ws[0]; term_harmonic<ENERGY>(d, L); }
     for (int t = 0; t < S.n_chi; t++, ws += stride) { ChiD<real> d = S.chi[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.atoms += ws[0]; d.n = ws[1] - ws[0]; term_chi<ENERGY>(d, L); }
     for (int t = 0; t < S.n_rama; t++, ws += stride) { RamaD<real> d = S.rama[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.atoms += ws[0]; d.bw += (size_t)ws[0] * d.nwell; d.n = ws[1] - ws[0]; term_rama<ENERGY>(d, L); }
-    for (int t = 0; t < S.n_helical; t++, ws += stride) { HelicalD<real> d = S.helical[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.items += ws[0]; d.n = ws[1] - ws[0]; term_helical<ENERGY>(d, L); }
+    for (int t = 0; t < S.n_helical; t++, ws += stride) { HelicalD<real> d = S.helical[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.items += ws[0]; if (d.zitems) d.zitems += ws[0]; d.n = ws[1] - ws[0]; term_helical<ENERGY>(d, L); }
     for (int t = 0; t < S.n_fm; t++, ws += stride) { FmD<real> d = S.fm[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.pairs2 += 2 * (size_t)ws[0]; d.table2 += (size_t)ws[0] * (d.ntab - 1); d.n = ws[1] - ws[0]; term_fm<ENERGY, false>(d, L); }
     for (int t = 0; t < S.n_memb; t++, ws += stride) { MembD<real> d = S.memb[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.items += ws[0]; d.n = ws[1] - ws[0]; term_memb<ENERGY>(d, L); }
     __syncthreads();

@@ -35,6 +35,8 @@ struct ListSlot { int list_off, list_cap, list_id; };
 
 template <class real> struct HarmItem { int i, j; real r0, k; };
 template <class real> struct HelicalItem { int o, n, h; real coef; };
+// z_dependent_helical_term: coef blends towards coef + dcoef with the membrane switch alpha(z of CA_i)
+template <class real> struct HelicalZItem { int ca; real dcoef; };
 template <class real> struct DhItem { int i, j; real qq, pad; };
 template <class real> struct GaussItem { int i, j; real r0, a, c; };   // a = 1/(2 sigma^2), c = k gamma (bond value g = -c exp(-a (r-r0)^2), or c r^2)
 template <class real> struct MembItem { int atom; real scale; };
@@ -137,7 +139,8 @@ template <class real> struct PapD {
     ListSlot ls; real list_rc2;           // HbEntry records, shared like BetaD's
     int list_owner;
 };
-template <class real> struct HelicalD { int group, n; const HelicalItem<real>* items; real r_ON, r_OH, inv_sNO2, inv_sHO2; };
+template <class real> struct HelicalD { int group, n; const HelicalItem<real>* items; real r_ON, r_OH, inv_sNO2, inv_sHO2;
+                                        const HelicalZItem<real>* zitems; real k_m2, z_m, center; };   // zitems: null unless z-dependent
 // table2[b][i] = (t[b][i], t[b][i+1]) for i < ntab-1: the two interpolation nodes of a bin in one aligned load
 // pairs[b] = atom_i | atom_j << 16 on the replica-resident path (atoms < 65536); pairs2 = (atom_i, atom_j) for the cell path
 // Replica-resident path: the bonds are grouped into BUNDLES of up to AWSEM_FM_BUNDLE bonds that share one atom (the
@@ -200,4 +203,6 @@ template <class real> struct DevSys {
     int* status;                          // device error word: bit 0 = a pair list overflowed
     long long* prof;                      // 16 phase-cycle accumulators (written by -DAWSEM_PROF builds only)
 };
-static_assert(sizeof(DevSys<double>) <= 4000, "DevSys must fit the 4 KB kernarg segment");
+// Not a hardware limit (the kernarg segment is sized per kernel: the fp64 cell-list kernels take DevSys + CellSys = 4.4 KB); a guard against growing
+// the block unnoticed -- past some size the compiler may copy a by-value block to scratch (rejected (vii)), which build() checks.
+static_assert(sizeof(DevSys<double>) <= 4064, "DevSys grew: check the step kernel's scratch size in the build remarks");

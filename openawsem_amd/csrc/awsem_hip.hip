@@ -66,7 +66,8 @@ struct HContact {
 struct HFn { int kind = 0; std::vector<int> info; std::vector<double> coef; };
 struct HBeta { int group, two_theta, nres; std::vector<int> acc_atoms, acc_res, don_atoms, don_res; std::vector<double> lambda; double k, r_ON, s_NO, r_OH, s_HO, cutoff; HFn fn; };
 struct HPap { int group, nres; std::vector<int> acc_atoms, acc_res, don_atoms, don_res; std::vector<double> gamma; double k, eta, r0, d_i4, cutoff; HFn fn; };
-struct HHelical { int group; std::vector<int> atoms; std::vector<double> coef; double r_ON, s_NO, r_OH, s_HO; };
+struct HHelical { int group; std::vector<int> atoms; std::vector<double> coef; double r_ON, s_NO, r_OH, s_HO;   // atoms: (O, N, H, CA or -1) per bond
+                  std::vector<double> coef_m; double eta = 0, z_m = 0, center = 0; };   // z-dependent variant: coef_m non-empty
 struct HFm { int group, ntab; std::vector<int> pairs; std::vector<double> table; double k, dr; };
 struct HMemb { int group; std::vector<int> atoms; std::vector<double> scale; double k, k_m, z_m, center; int kind = 0; };
 struct HDh { int group; std::vector<int> pairs; std::vector<double> qq; double k, lam; };
@@ -1208,9 +1209,16 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         std::vector<HelicalD<real>> D;
         for (auto& h : H.helical) {
             std::vector<HelicalItem<real>> it(h.coef.size());
-            const std::vector<int> perm = item_order((int)it.size(), 3, h.atoms.data());
-            for (size_t b = 0; b < it.size(); b++) { int o = perm[b]; it[b] = HelicalItem<real>{h.atoms[3 * o], h.atoms[3 * o + 1], h.atoms[3 * o + 2], (real)h.coef[o]}; }
-            D.push_back(HelicalD<real>{h.group, (int)it.size(), upload(it), (real)h.r_ON, (real)h.r_OH, (real)(1.0 / (h.s_NO * h.s_NO)), (real)(1.0 / (h.s_HO * h.s_HO))});
+            const std::vector<int> perm = item_order((int)it.size(), 4, h.atoms.data());
+            for (size_t b = 0; b < it.size(); b++) { int o = perm[b]; it[b] = HelicalItem<real>{h.atoms[4 * o], h.atoms[4 * o + 1], h.atoms[4 * o + 2], (real)h.coef[o]}; }
+            HelicalD<real> d{h.group, (int)it.size(), upload(it), (real)h.r_ON, (real)h.r_OH, (real)(1.0 / (h.s_NO * h.s_NO)), (real)(1.0 / (h.s_HO * h.s_HO)),
+                             nullptr, (real)(2 * h.eta), (real)h.z_m, (real)h.center};
+            if (!h.coef_m.empty()) {
+                std::vector<HelicalZItem<real>> zi(it.size());
+                for (size_t b = 0; b < it.size(); b++) { int o = perm[b]; zi[b] = HelicalZItem<real>{h.atoms[4 * o + 3], (real)(h.coef_m[o] - h.coef[o])}; }
+                d.zitems = upload(zi);
+            }
+            D.push_back(d);
         }
         if (D.size() > AWSEM_MAX_HELICAL) throw std::string("too many helical terms: at most " + std::to_string(AWSEM_MAX_HELICAL) + " per system");
         S.n_helical = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.helical[t] = D[t];
@@ -2257,7 +2265,18 @@ int awsem_add_hbond_pap_fn(awsem_handle h, int group, int nacc, const int32_t* a
 int awsem_add_helical(awsem_handle h, int group, int n, const int32_t* atoms, const double* coef, double r_ON, double s_NO, double r_OH, double s_HO) {
     NEED_BUILD(h, group);
     if (n < 0 || (n && (!atoms || !coef)) || !atoms_ok(h, atoms, 3 * (size_t)n)) return fail(AWSEM_EINVAL, "add_helical: bad arguments");
-    h->H.helical.push_back(HHelical{group, vec(atoms, 3 * (size_t)n), vec(coef, n), r_ON, s_NO, r_OH, s_HO});
+    HHelical t{group, std::vector<int>(4 * (size_t)n, -1), vec(coef, n), r_ON, s_NO, r_OH, s_HO};
+    for (int b = 0; b < n; b++) for (int k = 0; k < 3; k++) t.atoms[4 * (size_t)b + k] = atoms[3 * (size_t)b + k];
+    h->H.helical.push_back(std::move(t));
+    return AWSEM_OK;
+}
+int awsem_add_helical_z(awsem_handle h, int group, int n, const int32_t* atoms, const double* coef, const double* coef_m, double r_ON, double s_NO,
+                        double r_OH, double s_HO, double eta, double z_m, double center) {
+    NEED_BUILD(h, group);
+    if (n < 0 || (n && (!atoms || !coef || !coef_m)) || !atoms_ok(h, atoms, 4 * (size_t)n)) return fail(AWSEM_EINVAL, "add_helical_z: bad arguments");
+    HHelical t{group, vec(atoms, 4 * (size_t)n), vec(coef, n), r_ON, s_NO, r_OH, s_HO};
+    t.coef_m = vec(coef_m, n); t.eta = eta; t.z_m = z_m; t.center = center;
+    h->H.helical.push_back(std::move(t));
     return AWSEM_OK;
 }
 int awsem_add_fragment_memory(awsem_handle h, int group, int nb, const int32_t* pairs, int ntab, const double* table, double k, double dr) {

@@ -412,9 +412,18 @@ template <bool ENERGY, class V> __device__ __forceinline__ void term_helical(con
         real r1s = A.x * A.x + A.y * A.y + A.z * A.z, r2s = B.x * B.x + B.y * B.y + B.z * B.z;
         real i1 = M<real>::rsqrt(r1s), i2 = M<real>::rsqrt(r2s), g1, g2;
         real th = hb_theta(r1s * i1, r2s * i2, d.r_ON, d.r_OH, d.inv_sNO2, d.inv_sHO2, g1, g2);
-        if (ENERGY) e += (double)(-it.coef * th);
-        L.pair_force(it.o, it.n, A.x, A.y, A.z, it.coef * g1 * i1);
-        L.pair_force(it.o, it.h, B.x, B.y, B.z, it.coef * g2 * i2);
+        real coef = it.coef;
+        if (d.zitems) {   // uniform: z_dependent_helical_term, coef = (1 - alpha) coef_water + alpha coef_membrane, alpha(z of CA_i)
+            const HelicalZItem<real> zi = d.zitems[b];
+            const real z = L.pos(zi.ca).z - d.center;
+            // 1/2 tanh(u) + 1/2 tanh(v) = sig(2u) + sig(2v) - 1
+            const real su = sigmoid(d.k_m2 * (z + d.z_m)), sv = sigmoid(d.k_m2 * (d.z_m - z));
+            coef += zi.dcoef * (su + sv - (real)1);
+            L.add_fz(zi.ca, th * zi.dcoef * d.k_m2 * (su * ((real)1 - su) - sv * ((real)1 - sv)));   // -dE/dz, E = -coef theta
+        }
+        if (ENERGY) e += (double)(-coef * th);
+        L.pair_force(it.o, it.n, A.x, A.y, A.z, coef * g1 * i1);
+        L.pair_force(it.o, it.h, B.x, B.y, B.z, coef * g2 * i2);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }

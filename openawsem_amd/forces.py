@@ -283,14 +283,26 @@ class HelicalForce(Force):
         self.r_ON, self.sigma_NO, self.r_OH, self.sigma_HO = r_ON, sigma_NO, r_OH, sigma_HO
         self.atoms, self.coef = [], []
 
-    def addBond(self, atoms, coef):
+        # z_dependent_helical_term: every bond carries a fourth atom (CA_i) and a membrane coefficient
+        self.coef_membrane, self.eta_switching, self.z_m, self.membrane_center = None, 10.0, 1.5, 0.0
+
+    def addBond(self, atoms, coef, coef_membrane=None):
         self.atoms.append(tuple(int(a) for a in atoms))
         self.coef.append(float(coef))
+        if coef_membrane is not None:
+            if self.coef_membrane is None:
+                self.coef_membrane = []
+            self.coef_membrane.append(float(coef_membrane))
 
     def getNumBonds(self):
         return len(self.coef)
 
     def _upload(self, ctx):
+        if self.coef_membrane is not None:
+            assert len(self.coef_membrane) == len(self.coef)
+            ctx.add_helical_z(self._group, np.array(self.atoms, dtype=np.int32).reshape(-1, 4), self.coef, self.coef_membrane,
+                              self.r_ON, self.sigma_NO, self.r_OH, self.sigma_HO, self.eta_switching, self.z_m, self.membrane_center)
+            return
         ctx.add_helical(self._group, np.array(self.atoms, dtype=np.int32).reshape(-1, 3), self.coef, self.r_ON, self.sigma_NO,
                         self.r_OH, self.sigma_HO)
 

@@ -365,3 +365,20 @@ def helical_term(oa, k_helical=4.184, inMembrane=False, forceGroup=29):
             helical.addBond([oa.o[i], oa.n[i + 4], oa.h[i + 4]], k_helical * (fa_i + fa_ip4))
     helical.setForceGroup(forceGroup)
     return helical
+
+
+def z_dependent_helical_term(oa, k_helical=4.184, membrane_center=0 * _u.angstrom, z_m=1.5, forceGroup=29):
+    """Helical term whose propensities blend from the water to the membrane table with the z of CA_i (reference :835-887):
+    E = -k theta(O_i; N_i+4, H_i+4) ((fa_i + fa_i+4)(1 - alpha) + (fa_i^mem + fa_i+4^mem) alpha), eta_switching = 10."""
+    k_helical *= oa.k_awsem
+    helical = HelicalForce()
+    helical.eta_switching, helical.z_m = 10.0, float(z_m)
+    helical.membrane_center = membrane_center.value_in_unit(_u.nanometer)
+    helical.coef_membrane = []
+    for i in range(oa.nres):
+        if not isChainEnd(i, oa.chain_ends, n=4) and oa.res_type[i + 4] != "IPR":
+            fa = get_helical_f(oa.seq[i], inMembrane=False) + get_helical_f(oa.seq[i + 4], inMembrane=False)
+            fm = get_helical_f(oa.seq[i], inMembrane=True) + get_helical_f(oa.seq[i + 4], inMembrane=True)
+            helical.addBond([oa.o[i], oa.n[i + 4], oa.h[i + 4], oa.ca[i]], k_helical * fa, k_helical * fm)
+    helical.setForceGroup(forceGroup)
+    return helical

@@ -53,7 +53,8 @@ typedef struct {
     double *gamma;
     double k, eta, r0, d_i4, cutoff;
 } pap_t;
-typedef struct { int group, n; int *atoms; double *coef; double r_ON, s_NO, r_OH, s_HO; } helical_t;
+typedef struct { int group, n; int *atoms; double *coef; double r_ON, s_NO, r_OH, s_HO;
+                 int *ca; double *coef_m; double eta, z_m, center; } helical_t;   /* ca != NULL: z_dependent_helical_term */
 typedef struct { int group, n, ntab; int *pairs; double *table; double k, dr; } fm_t;
 typedef struct { int group, n; int *atoms; double *scale; double k, k_m, z_m, center; int kind; } memb_t;   /* kind 0: slab; 1-3: -k s x|y|z; 4: k|z-c-s| */
 typedef struct { int group, n; int *pairs; double *qq; double k, lam; } dh_t;
@@ -127,7 +128,7 @@ static void free_term(term_t* t) {
     case T_CONTACT: { contact_t* x = p; free(x->atom); free(x->restype); free(x->resid); free(x->chain); free(x->gamma_idx); free(x->bgamma_idx); } break;
     case T_BETA: { beta_t* x = p; if (x->fn) { free(x->fn->info); free(x->fn); } free(x->acc_atoms); free(x->acc_res); free(x->don_atoms); free(x->don_res); free(x->lambda); } break;
     case T_PAP: { pap_t* x = p; if (x->fn) { free(x->fn->info); free(x->fn); } free(x->acc_atoms); free(x->acc_res); free(x->don_atoms); free(x->don_res); free(x->gamma); } break;
-    case T_HELICAL: { helical_t* x = p; free(x->atoms); free(x->coef); } break;
+    case T_HELICAL: { helical_t* x = p; free(x->atoms); free(x->coef); free(x->ca); free(x->coef_m); } break;
     case T_FM: { fm_t* x = p; free(x->pairs); free(x->table); } break;
     case T_MEMB: { memb_t* x = p; free(x->atoms); free(x->scale); } break;
     case T_DH: { dh_t* x = p; free(x->pairs); free(x->qq); } break;
@@ -354,6 +355,17 @@ int awsem_oracle_add_helical(ctx_t* c, int group, int n, const int* atoms, const
     if (n < 0 || (n && (!atoms || !coef)) || !check_atoms(c, atoms, 3 * n, 0)) return fail(-1, "add_helical: bad arguments");
     helical_t* t = calloc(1, sizeof *t); t->group = group; t->n = n; t->atoms = dup_mem(atoms, 3 * n * sizeof(int));
     t->coef = dup_mem(coef, n * sizeof(double)); t->r_ON = r_ON; t->s_NO = s_NO; t->r_OH = r_OH; t->s_HO = s_HO;
+    return add_term(c, T_HELICAL, t);
+}
+int awsem_oracle_add_helical_z(ctx_t* c, int group, int n, const int* atoms4, const double* coef, const double* coef_m, double r_ON, double s_NO,
+                               double r_OH, double s_HO, double eta, double z_m, double center) {
+    CHECK_BUILD(c, group);
+    if (n < 0 || (n && (!atoms4 || !coef || !coef_m)) || !check_atoms(c, atoms4, 4 * n, 0)) return fail(-1, "add_helical_z: bad arguments");
+    helical_t* t = calloc(1, sizeof *t); t->group = group; t->n = n;
+    t->atoms = malloc((3 * n + 1) * sizeof(int)); t->ca = malloc((n + 1) * sizeof(int));
+    for (int b = 0; b < n; b++) { for (int k = 0; k < 3; k++) t->atoms[3 * b + k] = atoms4[4 * b + k]; t->ca[b] = atoms4[4 * b + 3]; }
+    t->coef = dup_mem(coef, n * sizeof(double)); t->coef_m = dup_mem(coef_m, n * sizeof(double));
+    t->r_ON = r_ON; t->s_NO = s_NO; t->r_OH = r_OH; t->s_HO = s_HO; t->eta = eta; t->z_m = z_m; t->center = center;
     return add_term(c, T_HELICAL, t);
 }
 int awsem_oracle_add_fragment_memory(ctx_t* c, int group, int nb, const int* pairs, int ntab, const double* table, double k, double dr) {
@@ -752,16 +764,25 @@ static double eval_pap(const pap_t* t, const double* x, double* f) {
     }
     return e;
 }
-/* hydrogenBondTerms.py:818-829 */
+/* hydrogenBondTerms.py:818-829; z_dependent_helical_term 869-873: the coefficient (fa_i + fa_ip4)(1 - alpha) +
+ * (fa_i_membrane + fa_ip4_membrane) alpha with alpha = 1/2 tanh(eta (z + z_m)) + 1/2 tanh(eta (z_m - z)), z of CA_i */
 static double eval_helical(const helical_t* t, const double* x, double* f) {
     double e = 0, d1[3], d2[3];
     for (int b = 0; b < t->n; b++) {
         const int* a = t->atoms + 3 * b;
         double r1 = dist(x, a[0], a[1], d1), r2 = dist(x, a[0], a[2], d2), g1, g2;
         double th = hb_theta(r1, r2, t->r_ON, t->s_NO, t->r_OH, t->s_HO, &g1, &g2);
-        e += -t->coef[b] * th;
-        pair_force(f, a[0], a[1], d1, r1, -t->coef[b] * g1);
-        pair_force(f, a[0], a[2], d2, r2, -t->coef[b] * g2);
+        double coef = t->coef[b];
+        if (t->ca) {
+            const double z = x[3 * t->ca[b] + 2] - t->center;
+            const double tu = tanh(t->eta * (z + t->z_m)), tv = tanh(t->eta * (t->z_m - z));
+            const double alpha = 0.5 * tu + 0.5 * tv, dalpha = 0.5 * t->eta * ((1 - tu * tu) - (1 - tv * tv));
+            coef = t->coef[b] * (1 - alpha) + t->coef_m[b] * alpha;
+            if (f) f[3 * t->ca[b] + 2] += th * (t->coef_m[b] - t->coef[b]) * dalpha;   /* -dE/dz, E = -coef theta */
+        }
+        e += -coef * th;
+        pair_force(f, a[0], a[1], d1, r1, -coef * g1);
+        pair_force(f, a[0], a[2], d2, r2, -coef * g2);
     }
     return e;
 }

@@ -15,7 +15,7 @@ import pytest
 import openawsem_amd as oa_pkg
 from openawsem_amd import _capi, unit as u
 from openawsem_amd.forces import System
-from openawsem_amd.functionTerms import contactTerms, debyeHuckelTerms, membraneTerms
+from openawsem_amd.functionTerms import contactTerms, debyeHuckelTerms, hydrogenBondTerms, membraneTerms
 from oracle import awsem_oracle
 from tests.common import GOLDEN, golden_system
 from tests.test_oracle_forces import _fd_check
@@ -171,6 +171,48 @@ def test_debye_huckel_oracle_matches_the_closed_form(oracle_api):
         assert np.abs(got - fd).max() / max(1.0, np.abs(fd).max()) < 2e-6
 
 
+def _z_helical_closed_form(oa, x, k, c, z_m):
+    """hydrogenBondTerms.py:866-885 of the reference, bond by bond, straight from its expression string."""
+    hb = hydrogenBondTerms
+    e = 0.0
+    for i in range(oa.nres):
+        if not hb.isChainEnd(i, oa.chain_ends, n=4) and oa.res_type[i + 4] != "IPR":
+            fa = hb.get_helical_f(oa.seq[i]) + hb.get_helical_f(oa.seq[i + 4])
+            fm = hb.get_helical_f(oa.seq[i], True) + hb.get_helical_f(oa.seq[i + 4], True)
+            r_n = np.linalg.norm(x[oa.o[i]] - x[oa.n[i + 4]])
+            r_h = np.linalg.norm(x[oa.o[i]] - x[oa.h[i + 4]])
+            theta = np.exp(-(r_n - 0.298) ** 2 / (2 * 0.068 ** 2) - (r_h - 0.206) ** 2 / (2 * 0.076 ** 2))
+            alpha = _slab(x[oa.ca[i], 2], 10.0, z_m, c)
+            e += -k * theta * (fa * (1 - alpha) + fm * alpha)
+    return e
+
+
+def test_z_dependent_helical_oracle_matches_the_closed_form(oracle_api):
+    """z_dependent_helical_term (hydrogenBondTerms.py:835-887).  Unlike the other terms of this file it IS pinned by a reference-held
+    number (the Helical column of examples/2xov_complete/run0/info.dat: tests/test_legacy_tables.py); this test adds the closed form
+    at other parameters, finite differences for the forces, and the reduction to the golden-pinned helical_term far outside the slab."""
+    oa, traj, _ = golden_system("1ubq")
+    c, z_m, k = 0.2, 1.1, 3.0
+    f = hydrogenBondTerms.z_dependent_helical_term(oa, k_helical=k, membrane_center=10 * c * u.angstrom, z_m=z_m)
+    assert f.getForceGroup() == 29 and f.getNumBonds() == len(f.coef_membrane) > 40
+    ctx = awsem_oracle.make_context(_system_of(oa, f), n_replicas=1)
+    for shift in (0.0, 1.0, -1.2):
+        x = _centred(traj[6], oa, shift)
+        ctx.set_positions(x, replica=0)
+        e = ctx.energy_by_group()[0, 29]
+        want = _z_helical_closed_form(oa, x, k, c, z_m)
+        assert abs(want) > 1.0 and abs(e - want) < 1e-10 * abs(want)
+        atoms = np.random.default_rng(3).choice(oa.natoms, size=30, replace=False)
+        got, fd = _fd_check(ctx, x, 1 << 29, atoms)
+        assert np.abs(fd).max() > 1.0 and np.abs(got - fd).max() / max(1.0, np.abs(fd).max()) < 2e-6
+    # 50 nm away from the slab alpha = 0: the water propensities alone, i.e. helical_term
+    plain = hydrogenBondTerms.helical_term(oa, k_helical=k, forceGroup=5)
+    ctx = awsem_oracle.make_context(_system_of(oa, f, plain), n_replicas=1)
+    ctx.set_positions(_centred(traj[6], oa, 50.0), replica=0)
+    e = ctx.energy_by_group()[0]
+    assert abs(e[5]) > 1.0 and abs(e[29] - e[5]) < 1e-12 * abs(e[5])
+
+
 # ------------------------------------------------------------------ GPU: HIP kernels against the oracle
 def _compare(system, oa, frames, groups, precision, etol, ftol, fabs):
     gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=len(frames), precision=precision)
@@ -241,6 +283,19 @@ def test_membrane_terms_gpu_match_oracle(cell, precision, etol, ftol, tmp_path, 
     system = _system_of(oa, membraneTerms.membrane_term(oa, k_m=20, z_m=1.5, forceGroup=24),
                         membraneTerms.membrane_preassigned_term(oa, k=2 * u.kilocalorie_per_mole, forceGroup=25))
     frames = [_centred(traj[4], oa, s) for s in (0.0, 1.45, -1.55)]
+    _compare(system, oa, frames, [24, 25], precision, etol, ftol, 5e-3 if precision == 0 and cell == "0" else 1e-7 if precision else 1e-5).close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,etol,ftol", [(0, 1e-4, 1e-3), (1, 1e-9, 1e-7)])
+@pytest.mark.parametrize("cell", ["0", "1"])
+def test_z_dependent_helical_gpu_matches_oracle(cell, precision, etol, ftol, monkeypatch):
+    """Next to a plain helical_term (two helical-shaped terms in one system); slab edges through the protein."""
+    monkeypatch.setenv("AWSEM_FORCE_CELL", cell)
+    oa, traj, _ = golden_system("1ubq")
+    system = _system_of(oa, hydrogenBondTerms.z_dependent_helical_term(oa, k_helical=4.184, z_m=1.1, forceGroup=24),
+                        hydrogenBondTerms.helical_term(oa, forceGroup=25))
+    frames = [_centred(traj[6], oa, s) for s in (0.0, 1.0, -1.2)]
     _compare(system, oa, frames, [24, 25], precision, etol, ftol, 5e-3 if precision == 0 and cell == "0" else 1e-7 if precision else 1e-5).close()
 
 
