@@ -124,6 +124,44 @@ def _valu_view(args, folded, kernel_ms):
     return out
 
 
+def _launch_ranks(n):
+    """Start `n` ranks of this script (one process per GPU, as torch.distributed.run would: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
+    pass their output through (rank 0 prints the JSON line) and return the worst return code.  Called before anything has
+    initialised the GPU in this process; the children are fresh interpreters (no fork of a process with GPU state, no exec)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, 16 // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(0.05)
+            for p in list(live):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                if rc != 0 and worst == 0:
+                    worst = rc if rc > 0 else 128 - rc
+                    for q in live:               # a rank died: the others would wait in a collective for ever
+                        q.terminate()
+    except KeyboardInterrupt:
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        worst = 130
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,23 +180,40 @@ def main():
                                                         "launches at 300 K -- the compact state a production run spends most of its time in")
     ap.add_argument("--no-schedule-legs", action="store_true", help="skip the two extra legs of the default workload (whole 400-stage schedule, compact state at 300 K)")
     ap.add_argument("--minimize", action="store_true", help="relax the start structure on the device first (awsem_minimize), as awsem_run does")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: let the N ranks share the GPUs that are there (rank r on device r mod count) with gloo "
+                                                             "collectives -- exercises the launcher and the multi-rank code path on a one-GPU box")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as typed: this process becomes the launcher.  It has not touched torch or HIP (and never
+        # will), starts one fresh child per rank, relays rank 0's JSON line and exits with the worst return code.
+        sys.exit(_launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
 
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank
+    backend = "nccl"
+    if args.share_gpu:
+        # rehearsal of the multi-rank path on a box with fewer GPUs than ranks: ranks share devices, and since RCCL refuses two ranks
+        # on one device the collectives go through gloo (host memory).  Never a scaling number: the line says "rehearsal".
+        device_index = local_rank % torch.cuda.device_count()
+        backend = "gloo"
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo")
+    coll_device = "cuda" if backend == "nccl" else "cpu"     # where the timing reductions live
+    local_rank = device_index
 
     from openawsem_amd import _capi, workloads
     synthetic = args.workload.startswith("synthetic")
@@ -229,7 +284,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms.append(ctx.last_kernel_ms())     # mean over the timed launches: HIP events on the engine's stream around each
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -240,7 +295,7 @@ def main():
 
     def all_ranks_max(t):
         if world > 1:
-            tt = torch.tensor([t], device="cuda", dtype=torch.float64)
+            tt = torch.tensor([t], device=coll_device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item())
         return t
@@ -291,7 +346,7 @@ def main():
             "data": (f"synthetic ({kwargs.get('n_chains', 122)} rigidly rotated copies of the reference's 2lzm test structure on a jittered lattice, seed {kwargs.get('seed', 2026)})" if synthetic else
                      f"synthetic ({args.workload.split('-')[0]} start structure from the reference's examples/, Maxwell-Boltzmann velocities, Philox seed 2026)"),
             "config": {"workload": description + (" -- timed at 300 K after an untimed anneal (compact chains)" if args.folded else ""), "replicas_per_gpu": R, "md_steps_per_launch": args.md_steps,
-                       "residues": oa.nres, "atoms": oa.natoms, "parallelism": f"replica-sharded x{world}"},
+                       "residues": oa.nres, "atoms": oa.natoms, "parallelism": f"replica-sharded x{world}" + (" (REHEARSAL: ranks share GPUs, gloo collectives)" if args.share_gpu and world > 1 else "")},
             "force_eval_us_per_replica_step": k_ms * 1e3 / (R * args.md_steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": _measured_traffic(args, oa), "kernel": "cell-list step (kernel sequence)" if synthetic else "awsem_step_kernel<float>", "kernel_ms": k_ms,

@@ -267,6 +267,8 @@ public:
             if (!(ladder[r] > 0)) throw std::string("remd_setup: temperatures must be positive");
         }
         remd_tmax_ = tmax;
+        // a second set-up on the same handle (a new ladder, a restart) replaces the first one's buffers
+        dfree(remd_ladder_); dfree(remd_slot_); dfree(remd_where_); dfree(remd_counts_); dfree(remd_U_); dfree(remd_scale_); dfree(remd_T_);
         remd_ladder_ = upload(std::vector<double>(ladder, ladder + n_total));
         remd_slot_ = const_cast<int*>(upload(slot));
         remd_where_ = upload(wh);
@@ -275,7 +277,10 @@ public:
         remd_U_ = dalloc<double>(n_total);
         HIP_TRY(hipMemset(remd_U_, 0, n_total * sizeof(double)));
         remd_scale_ = dalloc<double>(nrep_);
-        HIP_TRY(hipMemcpy(dT_, ladder + local_start, sizeof(double) * nrep_, hipMemcpyHostToDevice));   // replica r starts at ladder[r]
+        // The temperatures the replicas run at.  A buffer of its own, written by this call and by the sweep kernel only: awsem_step(T) and
+        // awsem_set_velocities_to_temperature(T) on the same handle go through dT_ and cannot disturb the ladder's assignment.
+        remd_T_ = dalloc<double>(nrep_);
+        HIP_TRY(hipMemcpy(remd_T_, ladder + local_start, sizeof(double) * nrep_, hipMemcpyHostToDevice));   // replica r starts at ladder[r]
     }
     void need_remd() const { if (!remd_n_) throw StateError{"replica exchange: call awsem_remd_setup first"}; }
     void step_remd(int nsteps, double dt, double friction, uint64_t seed, int64_t step0) override {
@@ -303,7 +308,7 @@ public:
         const int N = remd_n_;
         hipLaunchKernelGGL(awsem_remd_sweep_kernel, dim3(1), dim3(256), 2 * (size_t)N * sizeof(int), stream_, d_all ? d_all : (const double*)remd_U_, remd_where_,
                            remd_ladder_, remd_slot_, remd_counts_, remd_counts_ + std::max(1, N - 1), N, (long long)iteration, (unsigned long long)remd_seed_,
-                           remd_start_, nrep_, dT_, remd_scale_);
+                           remd_start_, nrep_, remd_T_, remd_scale_);
         hipLaunchKernelGGL(awsem_scale_velocities_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, vel_, (const double*)remd_scale_, 3 * natoms_);
         HIP_TRY(hipGetLastError());
     }
@@ -315,7 +320,7 @@ public:
         if (slot) HIP_TRY(hipMemcpy(slot, remd_slot_, sizeof(int) * remd_n_, hipMemcpyDeviceToHost));
         if (attempted && remd_n_ > 1) HIP_TRY(hipMemcpy(attempted, remd_counts_, sizeof(long long) * (remd_n_ - 1), hipMemcpyDeviceToHost));
         if (accepted && remd_n_ > 1) HIP_TRY(hipMemcpy(accepted, remd_counts_ + np, sizeof(long long) * (remd_n_ - 1), hipMemcpyDeviceToHost));
-        if (T_local) HIP_TRY(hipMemcpy(T_local, dT_, sizeof(double) * nrep_, hipMemcpyDeviceToHost));
+        if (T_local) HIP_TRY(hipMemcpy(T_local, remd_T_, sizeof(double) * nrep_, hipMemcpyDeviceToHost));
     }
     void step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) override { step_impl(nsteps, T, dt, friction, seed, step0); }
     // T == nullptr: the temperatures already on the device (replica exchange) drive the launch
@@ -480,6 +485,10 @@ private:
         // null: the temperatures are on the device already (replica exchange).  Otherwise the kernel reads them from this launch's
         // slot of pinned host memory itself (one double per workgroup): no copy between two launches on the stream
         step_T_ = dT_;
+        if (!T) {   // replica exchange: the ladder's own buffer (the cell-list path bakes dT_ into its captured graphs: one small copy on the stream)
+            if (cell_mode_) HIP_TRY(hipMemcpyAsync(dT_, remd_T_, sizeof(double) * nrep_, hipMemcpyDeviceToDevice, stream_));
+            else step_T_ = remd_T_;
+        }
         if (T) {
             memcpy(ringT_[k], T, sizeof(double) * nrep_);
             if (cell_mode_ || !zero_copy_T_) HIP_TRY(hipMemcpyAsync(dT_, ringT_[k], sizeof(double) * nrep_, hipMemcpyHostToDevice, stream_));
@@ -554,7 +563,7 @@ private:
     int* remd_slot_ = nullptr;
     const int* remd_where_ = nullptr;
     unsigned long long* remd_counts_ = nullptr;   // attempted[N-1], accepted[N-1]
-    double *remd_U_ = nullptr, *remd_scale_ = nullptr;
+    double *remd_U_ = nullptr, *remd_scale_ = nullptr, *remd_T_ = nullptr;
     int block_ = 256;
     size_t lds_eval_ = 0, lds_step_ = 0;
     hipStream_t stream_ = nullptr;

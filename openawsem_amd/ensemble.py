@@ -46,39 +46,78 @@ def counter_uniform(seed: int, iteration: int, pair: int) -> float:
 
 class _Gather:
     """One all-gather of per-replica doubles across ranks: shard sizes are static, so they are worked out once (no collective),
-    the buffers are allocated once, and an exchange is a single all_gather_into_tensor (RCCL on GPUs, gloo on CPU)."""
+    the buffers are allocated once, and an exchange is a single all_gather_into_tensor (RCCL on GPUs, gloo on CPU).  Every rank's
+    block is padded to the longest shard plus ONE more word that carries the number of values the rank actually sent: after the
+    gather every rank sees every length, so a caller whose split is not shard()'s fails on ALL ranks with the same error instead
+    of leaving the others blocked in the collective."""
 
     def __init__(self, n_total, world, rank, device=None):
         import torch
         self.world, self.rank = world, rank
         self.shards = [shard(n_total, world, r) for r in range(world)]
         self.m = max(len(s) for s in self.shards)                    # shards are padded to the longest one
-        self.local = torch.zeros(self.m, dtype=torch.float64, device=device)
-        self.all = torch.zeros(world * self.m, dtype=torch.float64, device=device)
-        # replica r sits at rank * m + (r - start(rank)) of the gathered buffer
-        self.index = np.concatenate([r * self.m + np.arange(len(s)) for r, s in enumerate(self.shards)]).astype(np.int32)
+        self.stride = self.m + 1                                     # + the length word
+        self.local = torch.zeros(self.stride, dtype=torch.float64, device=device)
+        self.all = torch.zeros(world * self.stride, dtype=torch.float64, device=device)
+        self.local[self.m] = len(self.shards[rank])                  # the device path (engine writes its energies here) always sends its shard
+        # replica r sits at rank * stride + (r - start(rank)) of the gathered buffer
+        self.index = np.concatenate([r * self.stride + np.arange(len(s)) for r, s in enumerate(self.shards)]).astype(np.int32)
+        self._host = None
 
     def gather(self):
+        import torch
         import torch.distributed as dist
-        dist.all_gather_into_tensor(self.all, self.local)
+        if self.all.is_cuda and dist.get_backend() == "gloo":
+            # rehearsals of the multi-rank path on one GPU (bench.py --share-gpu): gloo moves host memory only
+            if self._host is None:
+                self._host = torch.zeros(self.world * self.stride, dtype=torch.float64)
+            dist.all_gather_into_tensor(self._host, self.local.cpu())
+            self.all.copy_(self._host)
+        else:
+            dist.all_gather_into_tensor(self.all, self.local)
         return self.all
+
+    def lengths(self, gathered):
+        return [int(gathered[r * self.stride + self.m]) for r in range(self.world)]
+
+
+def _all_gather_ragged(local, world, device=None):
+    """Per-rank vectors of ANY length, concatenated in rank order: the lengths first, then one padded gather."""
+    import torch
+    import torch.distributed as dist
+    lens = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(lens, torch.tensor([len(local)], dtype=torch.int64, device=device))
+    lens = [int(v) for v in lens.cpu()]
+    m = max(max(lens), 1)
+    mine = torch.zeros(m, dtype=torch.float64, device=device)
+    mine[:len(local)] = torch.as_tensor(local, device=device)
+    out = torch.zeros(world * m, dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, mine)
+    out = out.cpu().numpy()
+    return np.concatenate([out[r * m:r * m + n] for r, n in enumerate(lens)])
 
 
 def all_gather_energies(local: np.ndarray, world: int, device=None, gather=None) -> np.ndarray:
     """Per-rank energy vectors concatenated in rank order (host in, host out: the path of drivers that report every energy).
-    `gather`: a _Gather to reuse (its buffers are allocated once); built on the fly otherwise."""
+    Without `gather` the vectors may have any length per rank (two small collectives: lengths, then values).  With a `_Gather`
+    (buffers allocated once, one collective) the split must be shard()'s; a rank that brings another length makes EVERY rank
+    raise ValueError after the collective -- nobody is left waiting in it."""
+    local = np.asarray(local, dtype=np.float64).reshape(-1)
     if world == 1:
-        return np.asarray(local, dtype=np.float64)
+        return local
     import torch
-    import torch.distributed as dist
     if gather is None:
-        total = torch.tensor([len(local)], dtype=torch.int64, device=device)
-        dist.all_reduce(total)
-        gather = _Gather(int(total.item()), world, dist.get_rank(), device)
-    mine = gather.shards[gather.rank]
-    assert len(local) == len(mine)
-    gather.local[:len(mine)] = torch.as_tensor(np.asarray(local, dtype=np.float64))
-    return gather.gather().cpu().numpy()[gather.index]
+        return _all_gather_ragged(local, world, device)
+    n = min(len(local), gather.m)
+    gather.local[:n] = torch.as_tensor(local[:n])
+    gather.local[gather.m] = len(local)
+    out = gather.gather().cpu().numpy()
+    gather.local[gather.m] = len(gather.shards[gather.rank])
+    got, want = gather.lengths(out), [len(s) for s in gather.shards]
+    if got != want:
+        raise ValueError(f"all_gather_energies: per-rank lengths {got} are not the block partition {want} this gather was built for "
+                         "(pass gather=None for vectors of arbitrary length)")
+    return out[gather.index]
 
 
 class ReplicaExchange:

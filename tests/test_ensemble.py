@@ -125,9 +125,11 @@ def test_two_ranks_over_gloo_take_identical_decisions(tmp_path):
     r1 = np.load(tmp_path / "rank1.npz")
     assert (int(r0["start"]), int(r0["stop"]), int(r1["start"]), int(r1["stop"])) == (0, 7, 7, 13)
     assert np.array_equal(r0["slots"], r1["slots"])             # replicated bookkeeping stays in lock step
-    # the gather buffer: shards padded to the longer one (7), replica r at rank * 7 + (r - start(rank)); both ranks hold the same
-    assert int(r0["pad"]) == 7 and list(r0["index"]) == list(range(7)) + list(range(7, 13))
-    assert np.array_equal(r0["gathered"], r1["gathered"]) and r0["gathered"].shape == (14,)
+    # the gather buffer: shards padded to the longer one (7) plus one word holding the length sent, replica r at
+    # rank * 8 + (r - start(rank)); both ranks hold the same
+    assert int(r0["pad"]) == 7 and list(r0["index"]) == list(range(7)) + list(range(8, 14))
+    assert np.array_equal(r0["gathered"], r1["gathered"]) and r0["gathered"].shape == (16,)
+    assert r0["gathered"][7] == 7 and r0["gathered"][15] == 6
     assert np.array_equal(r0["accepted"], r1["accepted"]) and r0["accepted"].sum() > 0
 
     # single-rank run of the same ladder and seed: same decisions, and the per-rank scale vectors tile it
@@ -138,3 +140,65 @@ def test_two_ranks_over_gloo_take_identical_decisions(tmp_path):
         s = remd.exchange(U_all)
         assert np.array_equal(remd.slot, r0["slots"][it])
         assert np.allclose(s[:7], r0["scales"][it]) and np.allclose(s[7:], r1["scales"][it])
+
+
+_RAGGED_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from openawsem_amd import ensemble
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+U = np.arange(13, dtype=np.float64) * 1.5
+# (1) no _Gather: any split goes (here 3 + 10, not shard()'s 7 + 6)
+cut = 3
+mine = U[:cut] if rank == 0 else U[cut:]
+got = ensemble.all_gather_energies(mine, world)
+assert np.array_equal(got, U), got
+# (2) with a _Gather the split must be shard()'s; a wrong length on ONE rank raises on BOTH (after the collective: nobody hangs)
+g = ensemble._Gather(13, world, rank)
+ok = ensemble.all_gather_energies(U[g.shards[rank].start:g.shards[rank].stop], world, gather=g)
+assert np.array_equal(ok, U)
+wrong = U[:7] if rank == 0 else U[7:12]          # rank 1 brings 5 values where its shard has 6
+try:
+    ensemble.all_gather_energies(wrong, world, gather=g)
+    raised = ""
+except ValueError as e:
+    raised = str(e)
+assert "[7, 5]" in raised and "[7, 6]" in raised, raised
+# ... and the gather is still usable afterwards
+assert np.array_equal(ensemble.all_gather_energies(U[g.shards[rank].start:g.shards[rank].stop], world, gather=g), U)
+open(os.path.join({out!r}, f"ragged{{rank}}.ok"), "w").write(raised)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_a_split_that_is_not_the_block_partition_fails_on_every_rank_instead_of_hanging(tmp_path):
+    import subprocess
+    script = tmp_path / "ragged.py"
+    script.write_text(_RAGGED_WORKER.format(root=ROOT, out=str(tmp_path)))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+    for p in procs:
+        assert p.wait(timeout=120) == 0
+    assert (tmp_path / "ragged0.ok").read_text() == (tmp_path / "ragged1.ok").read_text() != ""
+
+
+def test_bench_launches_its_own_ranks_when_asked_for_several_gpus():
+    """`python bench.py --gpus N` as typed (no torch.distributed.run around it) starts N ranks itself.  Without a GPU every rank
+    stops at once with the product path's own message -- which shows that N children were started with a rendezvous environment,
+    that the launcher returns their failure, and that nothing waits for ever."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the -m gpu rehearsal (tests/test_gpu_drivers.py)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 1
+    assert res.stderr.count("bench.py needs a GPU") == 3

@@ -76,7 +76,34 @@ def test_queries_between_sweeps_leave_the_ladder_temperatures_alone():
     assert np.array_equal(gpu.remd_state()[3], before) and np.array_equal(before, T) and np.all(ke > 0)
     gpu.step_remd(10, 0.002, 1.0, 9)
     assert np.isfinite(gpu.get_state()[0]).all()
-    gpu.close()
+    # neither do a Maxwell-Boltzmann draw nor an ordinary step at other temperatures (they once uploaded into the ladder's buffer: the
+    # next step_remd would have run at them while slot[] said otherwise)
+    other = np.full(n, 777.0)
+    gpu.set_velocities_to_temperature(other, 4)
+    assert np.array_equal(gpu.remd_state()[3], T)
+    gpu.step(5, other, 0.002, 1.0, 9)
+    gpu.synchronize()
+    assert np.array_equal(gpu.remd_state()[3], T)
+    # ... and the dynamics that follows is the ladder's: identical to a handle that never saw the foreign temperatures
+    twin = _start(oa, traj, n, 0)
+    twin.set_velocities_to_temperature(rex.local_temperatures(), 3)
+    ensemble.ReplicaExchange(T, seed=5).attach(twin)
+    x, v = gpu.get_state()
+    twin.set_state(x, v)
+    twin.step_count = gpu.step_count
+    for c in (gpu, twin):
+        c.step_remd(10, 0.002, 1.0, 9)
+    assert np.array_equal(gpu.get_state()[0], twin.get_state()[0])
+    # a second set-up replaces the first (new ladder, fresh counters) instead of piling up buffers
+    T2 = np.linspace(310.0, 400.0, n)
+    gpu.remd_setup(T2, local_start=0, gather_index=None, seed=6)
+    slot, att, acc, T_local = gpu.remd_state()
+    assert np.array_equal(T_local, T2) and np.array_equal(slot, np.arange(n)) and not att.any() and not acc.any()
+    gpu.step_remd(5, 0.002, 1.0, 9)
+    gpu.remd_energies(0xFFFFFFFF)
+    gpu.remd_sweep(0)
+    assert np.array_equal(np.sort(gpu.remd_state()[3]), T2)
+    gpu.close(); twin.close()
 
 
 def test_sharded_ladder_with_a_gather_index_takes_the_same_decisions():
@@ -126,3 +153,44 @@ def test_sharded_ladder_with_a_gather_index_takes_the_same_decisions():
     assert hip.hipFree(buf) == 0
     for c, _, _ in parts:
         c.close()
+
+
+def test_energies_handed_over_in_torch_memory_give_the_same_sweeps():
+    """The hand-off of ensemble.exchange_on_device with several ranks (ensemble.py: ctx.remd_energies(mask, g.local.data_ptr()) ...
+    ctx.remd_sweep(it, g.all.data_ptr())): the engine writes its energies into memory that TORCH allocated and the sweep kernel reads
+    the gathered buffer from there.  torch ships its own copy of the HIP runtime next to the one libawsem_hip.so links against, so
+    this crosses runtimes inside one process; the engine's stream is joined (ctx.synchronize()) before torch touches the buffer and
+    torch's stream before the sweep reads it.  Must equal the NULL-buffer path (the engine's own buffer) bit for bit: ladder
+    assignment, counters, temperatures, coordinates."""
+    import torch
+    oa, traj, _ = golden_system("1ubq")
+    n, iters, steps = 8, 10, 20
+    T = np.linspace(300.0, 316.0, n)
+    runs = []
+    for torch_buffers in (False, True):
+        ctx = _start(oa, traj, n, 0)
+        ctx.set_velocities_to_temperature(T, 3)
+        # a one-rank _Gather has the layout of the multi-rank one (padded block + length word, replica r at index[r])
+        g = ensemble._Gather(n, 1, 0, torch.device("cuda", 0)) if torch_buffers else None
+        ctx.remd_setup(T, local_start=0, gather_index=None if g is None else g.index, seed=4)
+        slots = []
+        for it in range(iters):
+            ctx.step_remd(steps, 0.002, 1.0, 9)
+            if g is None:
+                ctx.remd_energies(0xFFFFFFFF)
+                ctx.remd_sweep(it)
+            else:
+                ctx.remd_energies(0xFFFFFFFF, g.local.data_ptr())
+                ctx.synchronize()
+                g.all.copy_(g.local)                      # what the all-gather does for a world of one, on torch's stream
+                torch.cuda.current_stream().synchronize()
+                assert np.array_equal(g.all.cpu().numpy()[g.index], ctx.energy())
+                ctx.remd_sweep(it, g.all.data_ptr())
+            slots.append(ctx.remd_state()[0].copy())
+        runs.append((np.array(slots), ctx.remd_state(), ctx.get_state()))
+        ctx.close()
+    (sa, ra, xa), (sb, rb, xb) = runs
+    assert np.array_equal(sa, sb) and np.any(sa[-1] != np.arange(n))
+    for a, b in zip(ra, rb):
+        assert np.array_equal(a, b)
+    assert np.array_equal(xa[0], xb[0]) and np.array_equal(xa[1], xb[1])
