@@ -435,6 +435,33 @@ class Context:
 _hip_api = None
 
 
+def _share_torchs_hip_runtime():
+    """One HIP runtime per process.  libawsem_hip.so is linked against libamdhip64.so.7; a ROCm build of torch ships its own copy of
+    that library (torch/lib, found through torch's RUNPATH).  Whichever is loaded first serves every later user with the same
+    SONAME -- except torch, which always maps its own: if the engine came first, the process holds two runtimes and torch's cannot
+    see the GPU any more ("No HIP GPUs are available"; measured on the MI355X box, scratch/runtime_order.py), so pointers and
+    streams could not be shared with torch.distributed.  Preloading torch's copy (when torch is installed; no `import torch`)
+    before dlopen'ing the engine makes the order irrelevant: engine, torch and RCCL share one runtime, one set of streams and
+    one address space.  AWSEM_SYSTEM_HIP=1 keeps the system runtime (hosts that never touch torch)."""
+    if os.environ.get("AWSEM_SYSTEM_HIP") == "1":
+        return None
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    lib = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(lib):
+        return None
+    try:
+        C.CDLL(lib, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+    return lib
+
+
 def load_hip_library(path: str | None = None) -> CApi:
     """Load libawsem_hip.so (built in-tree by __graft_entry__.build()).  Fails loudly when it is missing:
     there is no CPU fallback in the product path."""
@@ -444,6 +471,7 @@ def load_hip_library(path: str | None = None) -> CApi:
     p = path or os.environ.get("AWSEM_HIP_LIBRARY") or HIP_LIBRARY_PATH   # AWSEM_HIP_LIBRARY: an experiment build (tools/try_*.sh)
     if not os.path.exists(p):
         raise ImportError(f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')")
+    _share_torchs_hip_runtime()
     api = CApi(C.CDLL(p), "awsem_", extra=_HIP_ONLY)
     if path is None:
         _hip_api = api

@@ -3,9 +3,9 @@
 It runs the same kernels on caller-owned device buffers with its pair lists in the library's static __device__ array, so
 its energies must equal awsem_energy_by_group's BIT FOR BIT (both precisions: every sum is fixed point).  Two calls in a
 row, the second with a smaller input whose output buffer is poisoned first; then a call with more replicas than the handle
-has, and the size limit.  The device buffers and the stream come from the HIP runtime the library itself is linked against
-(libamdhip64.so.7, through ctypes): torch bundles a HIP runtime of its own, and a stream of one runtime means nothing to
-the other.  Collected last (test_zz_*): the round-end run is `pytest -x`."""
+has, and the size limit.  The device buffers and the stream come from the HIP runtime the library itself runs on
+(libamdhip64.so.7, through ctypes -- the one instance in the process, see _capi._share_torchs_hip_runtime); torch is not needed
+here.  Collected last (test_zz_*): the round-end run is `pytest -x`."""
 import ctypes as C
 
 import numpy as np
