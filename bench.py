@@ -124,6 +124,20 @@ def _valu_view(args, folded, kernel_ms):
     return out
 
 
+def force_eval_leg(ctx, R, n=5):
+    """BASELINE.json's second figure: one force evaluation (awsem_forces: pair lists built from scratch, every term, virtual-site
+    forces redistributed, fp64 forces written out) of all R replicas at their current coordinates; HIP events around the kernel on the
+    engine's stream (awsem_last_kernel_ms), the copy of the 3 x natoms x R forces to the host is outside them.  Mean of n calls after
+    one untimed call."""
+    ctx.forces()
+    ms = []
+    for _ in range(n):
+        ctx.forces()
+        ms.append(ctx.last_kernel_ms())
+    k = float(np.mean(ms))
+    return {"kernel_ms": k, "us_per_replica": k * 1e3 / R, "calls": n}
+
+
 def _launch_ranks(n):
     """Start `n` ranks of this script (one process per GPU, as torch.distributed.run would: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
     pass their output through (rank 0 prints the JSON line) and return the worst return code.  Called before anything has
@@ -293,6 +307,11 @@ def main():
     if not np.all(np.isfinite(e)):
         sys.exit("non-finite potential energy after the benchmark run")
 
+    # force-evaluation cost on the frames the timed launches ended at (the headline's extended chains, ~790 K; compact chains with --folded)
+    force_eval = {}
+    if remd is None and not synthetic:
+        force_eval["compact_300K" if args.folded else "extended_800K"] = force_eval_leg(ctx, R)
+
     def all_ranks_max(t):
         if world > 1:
             tt = torch.tensor([t], device=coll_device, dtype=torch.float64)
@@ -331,6 +350,7 @@ def main():
                                 "what": f"{args.steps} launches x {args.md_steps} steps at 300 K after an untimed 400 x 250-step anneal 800 -> 300 K (compact chains)"}
         if not np.all(np.isfinite(ctx.energy())):
             sys.exit("non-finite potential energy after the schedule legs")
+        force_eval["compact_300K"] = force_eval_leg(ctx, R)
 
     if rank == 0:
         total_steps = world * R * args.md_steps * args.steps
@@ -347,7 +367,8 @@ def main():
                      f"synthetic ({args.workload.split('-')[0]} start structure from the reference's examples/, Maxwell-Boltzmann velocities, Philox seed 2026)"),
             "config": {"workload": description + (" -- timed at 300 K after an untimed anneal (compact chains)" if args.folded else ""), "replicas_per_gpu": R, "md_steps_per_launch": args.md_steps,
                        "residues": oa.nres, "atoms": oa.natoms, "parallelism": f"replica-sharded x{world}" + (" (REHEARSAL: ranks share GPUs, gloo collectives)" if args.share_gpu and world > 1 else "")},
-            "force_eval_us_per_replica_step": k_ms * 1e3 / (R * args.md_steps),
+            # the whole MD step (forces + virtual sites + list upkeep + Langevin update) per replica, from the step kernel's own time
+            "md_step_us_per_replica_step": k_ms * 1e3 / (R * args.md_steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": _measured_traffic(args, oa), "kernel": "cell-list step (kernel sequence)" if synthetic else "awsem_step_kernel<float>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_replica_step": b_alg,
@@ -356,6 +377,11 @@ def main():
                                  ("state is LDS-resident across the launch, so the kernel is VALU/LDS-bound, not HBM-bound "
                                   "(see DESIGN.md); the HBM fraction is reported because the metric asks for it")},
         }
+        if force_eval:
+            # BASELINE.json's "force-eval us/step": a standalone awsem_forces call (lists from scratch + all terms + fp64 output), per replica
+            first = "extended_800K" if "extended_800K" in force_eval else "compact_300K"
+            out["force_eval_us_per_replica_step"] = force_eval[first]["us_per_replica"]
+            out["force_eval"] = force_eval
         valu = None if synthetic else _valu_view(args, args.folded, k_ms)
         if valu is not None:
             # The state is LDS-resident, so the roof this kernel actually sits under is VALU issue, not HBM: that fraction is the

@@ -311,6 +311,11 @@ int awsem_synchronize(awsem_handle h);
  *                        (i, i+1) with i of the parity of `iteration`, accepted when delta = (beta_i - beta_i+1)(U_a - U_b) >= 0
  *                        or u < exp(delta), u = Philox4x32-10(counter (i, iteration, 'REMD'), key seed) -- the stream
  *                        openawsem_amd/ensemble.py:counter_uniform reproduces on the host; then rescales the local velocities
+ *   awsem_remd_set_mixing  0 (default): the neighbour sweep above.  1: openmmtools' DEFAULT scheme 'swap-all', which the reference gets by
+ *                        passing no replica_mixing_scheme (scripts/mm_remd.py:133-140): n_total^3 attempts per iteration on uniformly
+ *                        drawn replica pairs (i, j), each accepted when (beta_si - beta_sj)(U_i - U_j) >= 0 or ln u < that; draws from
+ *                        Philox4x32-10(counter (attempt, iteration, 'RMSA'), key seed) (ensemble.py:_swap_all_draws on the host).  A
+ *                        chain of dependent decisions: ~0.1 us per attempt on one thread (12 replicas: 0.2 ms; 64: 27 ms)
  *   awsem_remd_state     copies out the ladder index of every replica, attempt / acceptance counts per neighbouring pair and
  *                        the local temperatures (any pointer may be NULL); the only call here that waits for the device
  * awsem_remd_energies and awsem_remd_sweep are asynchronous on the handle's stream; a caller that gathers with another
@@ -320,6 +325,7 @@ int awsem_remd_setup(awsem_handle h, int n_total, const double* ladder_T, const 
 int awsem_step_remd(awsem_handle h, int nsteps, double dt_ps, double friction_per_ps, uint64_t seed);
 int awsem_remd_energies(awsem_handle h, uint32_t group_mask, double* d_energy);
 int awsem_remd_sweep(awsem_handle h, const double* d_all_energies, int64_t iteration);
+int awsem_remd_set_mixing(awsem_handle h, int scheme);
 int awsem_remd_state(awsem_handle h, int32_t* ladder_index, int64_t* attempted, int64_t* accepted, double* T_local);
 
 /* ---- allocation-free evaluation ---------------------------------------------------------------------------

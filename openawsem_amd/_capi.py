@@ -82,6 +82,7 @@ _HIP_ONLY = {
     "remd_energies": (C.c_int, ["H", C.c_uint32, C.c_void_p]),
     "remd_sweep": (C.c_int, ["H", C.c_void_p, C.c_int64]),
     "remd_state": (C.c_int, ["H", c_int_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_dbl_p]),
+    "remd_set_mixing": (C.c_int, ["H", C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple("awsem_" + n for n in list(_SIGNATURES) + list(_HIP_ONLY))
@@ -412,6 +413,11 @@ class Context:
 
     def remd_sweep(self, iteration, d_all_energies=None):
         self._call("remd_sweep", C.c_void_p(int(d_all_energies)) if d_all_energies else None, C.c_int64(int(iteration)))
+
+    def remd_set_mixing(self, scheme):
+        """'neighbours' / 0 or 'swap-all' / 1 (openmmtools' default, what scripts/mm_remd.py of the reference runs)."""
+        code = {"neighbours": 0, "neighbors": 0, "swap-neighbors": 0, "swap-all": 1}.get(scheme, scheme)
+        self._call("remd_set_mixing", int(code))
 
     def remd_state(self):
         """(ladder index of every replica, attempted, accepted per neighbouring pair, temperatures of the local replicas)."""

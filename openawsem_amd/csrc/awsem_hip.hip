@@ -109,6 +109,7 @@ struct EngineBase {
     virtual void step_remd(int nsteps, double dt, double friction, uint64_t seed, int64_t step0) = 0;
     virtual void remd_energies(unsigned mask, double* d_energy) = 0;
     virtual void remd_sweep(const double* d_all, int64_t iteration) = 0;
+    virtual void remd_set_mixing(int scheme) = 0;
     virtual void remd_state(int32_t* slot, int64_t* attempted, int64_t* accepted, double* T_local) = 0;
     double last_ms = 0.0;
 };
@@ -306,11 +307,22 @@ public:
         need_remd();
         HIP_TRY(hipSetDevice(device_));
         const int N = remd_n_;
+        if (remd_mixing_ == 1) {
+            const size_t lds = (2 * (size_t)N + AWSEM_MIX_BATCH) * sizeof(double) + (4 * (size_t)N + 2 * AWSEM_MIX_BATCH) * sizeof(int);
+            hipLaunchKernelGGL(awsem_remd_mix_all_kernel, dim3(1), dim3(256), lds, stream_, d_all ? d_all : (const double*)remd_U_, remd_where_,
+                               remd_ladder_, remd_slot_, remd_counts_, remd_counts_ + std::max(1, N - 1), N, (long long)iteration, (unsigned long long)remd_seed_,
+                               remd_start_, nrep_, remd_T_, remd_scale_);
+        } else
         hipLaunchKernelGGL(awsem_remd_sweep_kernel, dim3(1), dim3(256), 2 * (size_t)N * sizeof(int), stream_, d_all ? d_all : (const double*)remd_U_, remd_where_,
                            remd_ladder_, remd_slot_, remd_counts_, remd_counts_ + std::max(1, N - 1), N, (long long)iteration, (unsigned long long)remd_seed_,
                            remd_start_, nrep_, remd_T_, remd_scale_);
         hipLaunchKernelGGL(awsem_scale_velocities_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, vel_, (const double*)remd_scale_, 3 * natoms_);
         HIP_TRY(hipGetLastError());
+    }
+    void remd_set_mixing(int scheme) override {
+        if (scheme != 0 && scheme != 1) throw std::string("remd_set_mixing: scheme must be 0 (neighbour swaps) or 1 (swap-all)");
+        if (scheme == 1 && remd_n_ > 1024) throw std::string("remd_set_mixing: swap-all resolves N^3 attempts per iteration in one chain; at most 1024 replicas");
+        remd_mixing_ = scheme;
     }
     void remd_state(int32_t* slot, int64_t* attempted, int64_t* accepted, double* T_local) override {
         need_remd();
@@ -558,6 +570,7 @@ private:
     // replica exchange state (awsem_remd_setup); all of it lives on the device
     int remd_n_ = 0, remd_start_ = 0;
     uint64_t remd_seed_ = 0;
+    int remd_mixing_ = 0;   // 0: neighbour swaps of alternating parity; 1: openmmtools' swap-all (awsem_remd_set_mixing)
     double remd_tmax_ = 0;
     const double* remd_ladder_ = nullptr;
     int* remd_slot_ = nullptr;
@@ -2476,6 +2489,10 @@ int awsem_remd_sweep(awsem_handle h, const double* d_all, int64_t iteration) {
     NEED_RUN(h);
     if (iteration < 0) return fail(AWSEM_EINVAL, "remd_sweep: negative iteration");
     GUARD_BEGIN h->eng->remd_sweep(d_all, iteration); return AWSEM_OK; GUARD_END
+}
+int awsem_remd_set_mixing(awsem_handle h, int scheme) {
+    NEED_RUN(h);
+    GUARD_BEGIN h->eng->remd_set_mixing(scheme); return AWSEM_OK; GUARD_END
 }
 int awsem_remd_state(awsem_handle h, int32_t* ladder_index, int64_t* attempted, int64_t* accepted, double* T_local) {
     NEED_RUN(h);

@@ -1612,6 +1612,75 @@ __global__ void awsem_remd_sweep_kernel(const double* __restrict__ U /* gathered
     }
 }
 
+// openmmtools' DEFAULT mixing scheme, 'swap-all' (ReplicaExchangeSampler(replica_mixing_scheme='swap-all'), which scripts/mm_remd.py:133-140
+// inherits by passing none): N^3 attempts per iteration, each on a uniformly drawn pair of REPLICAS (i, j) -- not of neighbouring
+// rungs --, accepted when log_p = (beta_si - beta_sj)(U_i - U_j) >= 0 or u < exp(log_p); an accepted pair swaps its ladder indices.
+// The attempts form a chain (each sees the swaps before it), so they are resolved by ONE thread; the other 255 draw the chain's
+// random numbers a batch ahead: attempt a of this iteration uses Philox4x32-10(counter (a, iteration, 'RMSA'), key seed): word 0 ->
+// i = (w0 * N) >> 32, word 1 -> j likewise, words 2,3 -> u with 53 bits (ensemble.py:_swap_all_draws is the same stream on the
+// host).  The test is ln u < log_p (no exp in the chain).  Counters: attempts / acceptances between NEIGHBOURING rungs only (the
+// pair (s, s+1) in either order), which keeps awsem_remd_state's meaning; i == j is drawn and counted as nothing, as in openmmtools.
+#define AWSEM_STREAM_REMD_ALL 0x524d5341u
+#define AWSEM_MIX_BATCH 256
+__global__ void awsem_remd_mix_all_kernel(const double* __restrict__ U, const int* __restrict__ where, const double* __restrict__ ladder, int* __restrict__ slot,
+                                          unsigned long long* __restrict__ attempted, unsigned long long* __restrict__ accepted, int N,
+                                          long long iteration, unsigned long long seed, int local_start, int nlocal,
+                                          double* __restrict__ T_local, double* __restrict__ scale_local) {
+    extern __shared__ double shd[];   // beta[N], Us[N], lnu[BATCH]; then ints: s[N], old[N], pi[BATCH], pj[BATCH], att[N], acc[N]
+    double* beta = shd;
+    double* Us = shd + N;
+    double* lnu = shd + 2 * N;
+    int* s = (int*)(lnu + AWSEM_MIX_BATCH);
+    int* old = s + N;
+    int* pi = old + N;
+    int* pj = pi + AWSEM_MIX_BATCH;
+    int* att = pj + AWSEM_MIX_BATCH;
+    int* acc = att + N;
+    for (int r = threadIdx.x; r < N; r += blockDim.x) {
+        const int v = slot[r];
+        s[r] = v; old[r] = v; att[r] = 0; acc[r] = 0;
+        beta[r] = 1.0 / (AWSEM_KB * ladder[r]);      // by ladder index
+        Us[r] = U[where[r]];                         // by replica
+    }
+    const long long total = (long long)N * N * N;
+    for (long long a0 = 0; a0 < total; a0 += AWSEM_MIX_BATCH) {
+        __syncthreads();
+        const long long a = a0 + threadIdx.x;
+        if (threadIdx.x < AWSEM_MIX_BATCH && a < total) {
+            unsigned c[4] = {(unsigned)a, (unsigned)(unsigned long long)iteration, (unsigned)((unsigned long long)iteration >> 32) ^ (unsigned)((unsigned long long)a >> 32), AWSEM_STREAM_REMD_ALL};
+            philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+            pi[threadIdx.x] = (int)(((unsigned long long)c[0] * (unsigned)N) >> 32);
+            pj[threadIdx.x] = (int)(((unsigned long long)c[1] * (unsigned)N) >> 32);
+            const double u = (double)((((unsigned long long)c[2] << 32) | c[3]) >> 11) * (1.0 / 9007199254740992.0);
+            lnu[threadIdx.x] = u > 0.0 ? ::log(u) : -1e300;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int nb = (int)((total - a0) < AWSEM_MIX_BATCH ? (total - a0) : AWSEM_MIX_BATCH);
+            for (int k = 0; k < nb; k++) {
+                const int i = pi[k], j = pj[k];
+                if (i == j) continue;
+                const int si = s[i], sj = s[j];
+                const double log_p = (beta[si] - beta[sj]) * (Us[i] - Us[j]);
+                const int lo = si < sj ? si : sj, near = (si - sj == 1) | (sj - si == 1);
+                if (near) att[lo]++;
+                if (log_p >= 0.0 || lnu[k] < log_p) { s[i] = sj; s[j] = si; if (near) acc[lo]++; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < N; r += blockDim.x) {
+        slot[r] = s[r];
+        if (r < N - 1) { attempted[r] += (unsigned long long)att[r]; accepted[r] += (unsigned long long)acc[r]; }
+    }
+    for (int k = threadIdx.x; k < nlocal; k += blockDim.x) {
+        const int r = local_start + k;
+        const double Tn = ladder[s[r]], To = ladder[old[r]];
+        T_local[k] = Tn;
+        scale_local[k] = ::sqrt(Tn / To);
+    }
+}
+
 // kinetic energy of every replica: sum over the massive particles of 1/2 m v^2 (StateDataReporter's temperature column)
 template <class real>
 __global__ void awsem_kinetic_kernel(const DevSys<real> S, const real* __restrict__ vel, double* __restrict__ ke) {

@@ -44,6 +44,35 @@ def counter_uniform(seed: int, iteration: int, pair: int) -> float:
     return (((c0 << 32) | c1) >> 11) * (1.0 / (1 << 53))
 
 
+def _philox4x32_10_np(c0, c1, c2, c3, k0, k1):
+    """The same generator over numpy uint64 arrays (values kept below 2^32)."""
+    M = np.uint64(_M32)
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M, p1 & M, ((p0 >> np.uint64(32)) ^ c3 ^ k1) & M, p0 & M
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M, (k1 + np.uint64(0xBB67AE85)) & M
+    return c0, c1, c2, c3
+
+
+def _swap_all_draws(seed: int, iteration: int, n: int):
+    """The n^3 attempts of one swap-all iteration: replica indices (i, j) and ln u, the stream of awsem_remd_mix_all_kernel
+    (counter (attempt, iteration, 'RMSA'), key seed; word 0 -> i, word 1 -> j by multiply-shift, words 2,3 -> 53-bit u)."""
+    seed, iteration = int(seed) & 0xFFFFFFFFFFFFFFFF, int(iteration) & 0xFFFFFFFFFFFFFFFF
+    a = np.arange(n ** 3, dtype=np.uint64)
+    c0 = a & np.uint64(_M32)
+    c1 = np.full_like(a, iteration & _M32)
+    c2 = np.uint64(iteration >> 32) ^ (a >> np.uint64(32))
+    c3 = np.full_like(a, 0x524D5341)
+    w0, w1, w2, w3 = _philox4x32_10_np(c0, c1, c2, c3, seed & _M32, seed >> 32)
+    i = ((w0 * np.uint64(n)) >> np.uint64(32)).astype(np.int64)
+    j = ((w1 * np.uint64(n)) >> np.uint64(32)).astype(np.int64)
+    u = (((w2 << np.uint64(32)) | w3) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    with np.errstate(divide="ignore"):
+        lnu = np.where(u > 0.0, np.log(np.maximum(u, 1e-320)), -1e300)
+    return i, j, lnu
+
+
 class _Gather:
     """One all-gather of per-replica doubles across ranks: shard sizes are static, so they are worked out once (no collective),
     the buffers are allocated once, and an exchange is a single all_gather_into_tensor (RCCL on GPUs, gloo on CPU).  Every rank's
@@ -123,7 +152,15 @@ def all_gather_energies(local: np.ndarray, world: int, device=None, gather=None)
 class ReplicaExchange:
     """Temperature REMD bookkeeping.  `slot[r]` is the ladder index replica r currently runs at."""
 
-    def __init__(self, temperatures, rank=0, world=1, seed=2026, device=None):
+    def __init__(self, temperatures, rank=0, world=1, seed=2026, device=None, mixing="neighbours"):
+        """mixing: "neighbours" -- one sweep of neighbouring-rung swaps of alternating parity per exchange (cheap, the bench default) --
+        or "swap-all", openmmtools' default scheme and therefore what the reference's mm_remd.py runs (scripts/mm_remd.py:133-140
+        passes no replica_mixing_scheme): n^3 attempts per exchange on uniformly drawn replica pairs."""
+        if mixing in ("neighbors", "swap-neighbors"):
+            mixing = "neighbours"
+        if mixing not in ("neighbours", "swap-all"):
+            raise ValueError(f"unknown replica mixing scheme {mixing!r}")
+        self.mixing = mixing
         self.T = np.asarray(temperatures, dtype=np.float64)
         self.n = len(self.T)
         self.rank, self.world, self.seed, self.device = rank, world, int(seed), device
@@ -147,6 +184,10 @@ class ReplicaExchange:
         beta = 1.0 / (KB * self.T)
         holder = np.argsort(self.slot)         # ladder index -> replica
         old_T = self.T[self.slot].copy()
+        if self.mixing == "swap-all":
+            self._mix_all(U, beta)
+            self.iteration += 1
+            return np.sqrt(self.T[self.slot] / old_T)[self.local.start:self.local.stop]
         for i in range(self.iteration % 2, self.n - 1, 2):
             a, b = holder[i], holder[i + 1]    # a runs at T_i, b at T_{i+1}
             delta = (beta[i] - beta[i + 1]) * (U[a] - U[b])
@@ -157,6 +198,29 @@ class ReplicaExchange:
         self.iteration += 1
         new_T = self.T[self.slot]
         return np.sqrt(new_T / old_T)[self.local.start:self.local.stop]
+
+    def _mix_all(self, U, beta):
+        """openmmtools' _mix_all_replicas restated for a temperature ladder: n^3 times, draw replicas i, j uniformly; with
+        s = slot[.] the current rungs, log_p = -(u_ij + u_ji) + u_ii + u_jj with u_ab = beta_{s_b} U_a, i.e.
+        (beta_si - beta_sj)(U_i - U_j); accept when log_p >= 0 or u < exp(log_p) and swap the two rungs.  Counters as on the
+        device: attempts between neighbouring rungs only."""
+        pi, pj, lnu = _swap_all_draws(self.seed, self.iteration, self.n)
+        s = [int(v) for v in self.slot]
+        b, Ul = [float(v) for v in beta], [float(v) for v in U]
+        for k in range(len(pi)):
+            i, j = int(pi[k]), int(pj[k])
+            if i == j:
+                continue
+            si, sj = s[i], s[j]
+            log_p = (b[si] - b[sj]) * (Ul[i] - Ul[j])
+            near = abs(si - sj) == 1
+            if near:
+                self.attempted[min(si, sj)] += 1
+            if log_p >= 0.0 or lnu[k] < log_p:
+                s[i], s[j] = sj, si
+                if near:
+                    self.accepted[min(si, sj)] += 1
+        self.slot = np.array(s)
 
     def acceptance(self):
         return self.accepted / np.maximum(self.attempted, 1)
@@ -170,6 +234,7 @@ class ReplicaExchange:
         self._ctx = ctx
         self._gather = _Gather(self.n, self.world, self.rank, self.device) if self.world > 1 else None
         ctx.remd_setup(self.T, local_start=self.local.start, gather_index=None if self._gather is None else self._gather.index, seed=self.seed)
+        ctx.remd_set_mixing(self.mixing)
 
     def exchange_on_device(self, group_mask=0xFFFFFFFF):
         """One sweep without a host hop: energies -> device buffer -> (all-gather) -> sweep kernel -> temperatures and velocity

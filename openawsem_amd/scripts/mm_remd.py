@@ -6,7 +6,8 @@ attempts :92-93,133-141, minimisation of the start structure :108-113).
 The reference hands the sampling to openmmtools' ReplicaExchangeSampler in one process and stores a NetCDF file
 (output.nc, MultiStateReporter); neither library is part of this build.  Here all replicas of a rank live in one engine
 handle (one launch advances them all), an exchange step is one gather of the potential energies, identical Metropolis
-decisions on every rank and a swap of temperature labels with a velocity rescale (openawsem_amd.ensemble).  Launch with
+decisions on every rank and a swap of temperature labels with a velocity rescale (openawsem_amd.ensemble); the mixing scheme is
+openmmtools' default, swap-all, as in the reference (which passes no replica_mixing_scheme, :133-140).  Launch with
 `python -m torch.distributed.run --nproc-per-node N ...` to spread the ladder over N GPUs.  Outputs in --to:
   output.npz          temperatures, per-iteration potential energies [iteration][replica] (kJ/mol), ladder index of every
                       replica after each exchange, acceptance per neighbouring pair          (rank 0)
@@ -79,7 +80,7 @@ def run_replica_exchange(args):
     forces = load_forces_module(forceSetupFile).set_up_forces(oa, submode=args.subMode, contactParameterLocation=parametersLocation)
     oa.addForcesWithDefaultForceGroup(forces)
 
-    remd = ensemble.ReplicaExchange(temps, rank=rank, world=world, seed=args.seed, device=device)
+    remd = ensemble.ReplicaExchange(temps, rank=rank, world=world, seed=args.seed, device=device, mixing=args.mixing)
     R = len(remd.local)
     integrator = engine.LangevinIntegrator(args.tempStart * kelvin, 1 / picosecond, args.timeStep * femtoseconds)
     integrator.setRandomNumberSeed(args.seed + 7919 * rank)
@@ -153,6 +154,10 @@ def main(argv=None):
     parser.add_argument("--includeLigands", action="store_true", default=False)
     # extensions of the MI355X engine
     parser.add_argument("--iterations", type=int, default=None, help="number of exchange attempts (overrides --runtime)")
+    parser.add_argument("--mixing", choices=["swap-all", "neighbours"], default="swap-all",
+                        help="replica mixing scheme per exchange: swap-all = openmmtools' default, which the reference's mm_remd.py runs "
+                             "(replicas^3 attempts on uniformly drawn replica pairs); neighbours = one sweep of neighbouring-rung swaps of "
+                             "alternating parity (cheaper for long ladders)")
     parser.add_argument("--seed", type=int, default=2026)
     parser.add_argument("--device", type=int, default=None)
     args = parser.parse_args(argv)

@@ -202,3 +202,39 @@ def test_bench_launches_its_own_ranks_when_asked_for_several_gpus():
                          env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 1
     assert res.stderr.count("bench.py needs a GPU") == 3
+
+
+def test_swap_all_mixing_samples_the_boltzmann_distribution_over_assignments():
+    """Closed-form detailed balance of openmmtools' default scheme (what the reference's mm_remd.py runs): with the energies held
+    fixed, repeated swap-all mixing is a Markov chain over the n! assignments of replicas to rungs whose stationary distribution is
+    P(s) ~ exp(-sum_r beta_{s(r)} U_r).  Three replicas, six assignments, 3000 exchanges of 27 attempts each."""
+    import itertools
+    T = np.array([300.0, 340.0, 390.0])
+    U = np.array([-12.0, -9.5, -7.0])          # kJ/mol: differences of a few kT
+    beta = 1.0 / (ensemble.KB * T)
+    perms = list(itertools.permutations(range(3)))
+    w = np.array([np.exp(-sum(beta[s[r]] * U[r] for r in range(3))) for s in perms])
+    p_exact = w / w.sum()
+    assert p_exact.min() > 0.03                # every assignment is visited often enough to test
+    remd = ensemble.ReplicaExchange(T, seed=77, mixing="swap-all")
+    counts = np.zeros(6)
+    n_iter = 3000
+    for _ in range(n_iter):
+        remd.exchange(U)
+        counts[perms.index(tuple(int(v) for v in remd.slot))] += 1
+    p = counts / n_iter
+    sigma = np.sqrt(p_exact * (1 - p_exact) / n_iter)
+    assert np.all(np.abs(p - p_exact) < 4.5 * sigma), (p, p_exact)
+    # neighbouring-rung counters only: every counted attempt had |s_i - s_j| = 1
+    assert remd.attempted.shape == (2,) and (remd.accepted <= remd.attempted).all() and remd.attempted.min() > n_iter
+
+
+def test_swap_all_draws_are_uniform_pairs_from_the_documented_stream():
+    i, j, lnu = ensemble._swap_all_draws(seed=9, iteration=4, n=12)
+    assert len(i) == 12 ** 3 and i.min() == 0 and i.max() == 11 and j.min() == 0 and j.max() == 11
+    # attempt 7 by the scalar generator: counter (attempt, iteration lo, iteration hi ^ attempt hi, 'RMSA'), key seed
+    c = ensemble._philox4x32_10((7, 4, 0, 0x524D5341), 9, 0)
+    assert (c[0] * 12) >> 32 == i[7] and (c[1] * 12) >> 32 == j[7]
+    u = (((c[2] << 32) | c[3]) >> 11) / float(1 << 53)
+    assert abs(np.log(u) - lnu[7]) < 1e-15
+    assert abs(np.exp(lnu).mean() - 0.5) < 0.03 and abs(np.bincount(i, minlength=12).std() / 144) < 0.2

@@ -21,15 +21,16 @@ def _start(oa, traj, n, precision):
     return gpu
 
 
+@pytest.mark.parametrize("mixing", ["neighbours", "swap-all"])
 @pytest.mark.parametrize("cell", ["0", "1"])
 @pytest.mark.parametrize("precision", [0, 1])
-def test_device_sweeps_equal_host_sweeps(precision, cell, monkeypatch):
+def test_device_sweeps_equal_host_sweeps(precision, cell, mixing, monkeypatch):
     monkeypatch.setenv("AWSEM_FORCE_CELL", cell)
     oa, traj, _ = golden_system("1ubq")
     n, iters, steps = 12, 12, 25
     T = np.linspace(300.0, 322.0, n)           # 2 K apart: plenty of accepted swaps for a 76-residue chain
     # host path: energies to the host, decisions in numpy, factors back to the device
-    host = ensemble.ReplicaExchange(T, seed=5)
+    host = ensemble.ReplicaExchange(T, seed=5, mixing=mixing)
     a = _start(oa, traj, n, precision)
     a.set_velocities_to_temperature(host.local_temperatures(), 3)
     slots_host = []
@@ -38,7 +39,7 @@ def test_device_sweeps_equal_host_sweeps(precision, cell, monkeypatch):
         a.scale_velocities(host.exchange(a.energy()))
         slots_host.append(host.slot.copy())
     # device path: nothing leaves the device until the end
-    dev = ensemble.ReplicaExchange(T, seed=5)
+    dev = ensemble.ReplicaExchange(T, seed=5, mixing=mixing)
     b = _start(oa, traj, n, precision)
     b.set_velocities_to_temperature(dev.local_temperatures(), 3)
     dev.attach(b)
@@ -194,3 +195,42 @@ def test_energies_handed_over_in_torch_memory_give_the_same_sweeps():
     for a, b in zip(ra, rb):
         assert np.array_equal(a, b)
     assert np.array_equal(xa[0], xb[0]) and np.array_equal(xa[1], xb[1])
+
+
+@pytest.mark.parametrize("mixing", ["neighbours", "swap-all"])
+def test_replica_exchange_sweeps_on_the_2xov_membrane_system(mixing):
+    """BASELINE.json configs[3] itself: the 276-residue membrane protein (membrane_term + z-dependent contact, one replica per CU),
+    a 16-rung ladder 300-330 K, exchanges after every 40 steps.  Device-side sweeps against the host-side ones on the same energies:
+    identical ladder assignment after every sweep, identical counters, identical coordinates at the end."""
+    from openawsem_amd import workloads
+    oa = workloads.build_2xov()
+    n, iters, steps = 16, 6, 40
+    T = np.linspace(300.0, 330.0, n)
+    runs = []
+    for on_device in (False, True):
+        rex = ensemble.ReplicaExchange(T, seed=12, mixing=mixing)
+        ctx = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=n, precision=0)
+        oa.system.upload(ctx)
+        ctx.set_positions(oa.pdb.positions)
+        ctx.minimize(10.0, 0)
+        ctx.set_velocities_to_temperature(T, 3)
+        slots = []
+        if on_device:
+            rex.attach(ctx)
+        for it in range(iters):
+            if on_device:
+                ctx.step_remd(steps, 0.002, 1.0, 9)
+                rex.exchange_on_device()
+                slots.append(ctx.remd_state()[0].copy())
+            else:
+                ctx.step(steps, rex.local_temperatures(), 0.002, 1.0, 9)
+                ctx.scale_velocities(rex.exchange(ctx.energy()))
+                slots.append(rex.slot.copy())
+        if on_device:
+            rex.pull()
+        runs.append((np.array(slots), rex.attempted.copy(), rex.accepted.copy(), ctx.get_state()))
+        ctx.close()
+    (sa, ta, aa, xa), (sb, tb, ab, xb) = runs
+    assert np.array_equal(sa, sb) and np.array_equal(ta, tb) and np.array_equal(aa, ab)
+    assert aa.sum() > 0 and np.any(sa[-1] != np.arange(n))
+    assert np.array_equal(xa[0], xb[0]) and np.array_equal(xa[1], xb[1]) and np.isfinite(xa[0]).all()
