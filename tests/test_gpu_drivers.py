@@ -171,7 +171,8 @@ def test_awsem_remd_runs_a_ladder_and_restarts(tmp_path, monkeypatch):
         assert z["energies"].shape == (12, 8) and np.isfinite(z["energies"]).all()
         assert np.allclose(z["temperatures"], np.linspace(300, 500, 8))
         assert all(sorted(row) == list(range(8)) for row in z["ladder_index"])      # a permutation of the ladder after every sweep
-        assert z["attempted"].sum() == 12 * 4 - 6 and 0 < z["accepted"].sum() <= z["attempted"].sum()   # 4 even pairs, 3 odd pairs
+        # default mixing = openmmtools' swap-all: 8^3 attempts per exchange, of which those between neighbouring rungs are counted
+        assert 12 * 8 ** 3 // 8 < z["attempted"].sum() < 12 * 8 ** 3 and 0 < z["accepted"].sum() <= z["attempted"].sum()
     with np.load(out / "replicas_rank0.npz") as z:
         assert z["frames"].shape == (3, 8, 368, 3) and z["positions"].shape == (8, 368, 3)
         assert int(z["iteration"]) == 12 and int(z["step_count"]) == 1200
@@ -181,6 +182,11 @@ def test_awsem_remd_runs_a_ladder_and_restarts(tmp_path, monkeypatch):
     remd2 = mm_remd.main(["1r69", "--to", str(tmp_path / "remd1"), "--replicas", "8", "--tempStart", "300", "--tempEnd", "500", "-x", "100",
                           "--iterations", "4", "--timeStep", "2", "--fromCheckPoint", str(out), "-f", forces])
     assert remd2.iteration == 16 and remd2.attempted.sum() > remd.attempted.sum() - 1
+    # the cheaper scheme as an option: one sweep of neighbouring-rung swaps of alternating parity per exchange
+    monkeypatch.chdir(d)
+    remd3 = mm_remd.main(["1r69", "--to", str(tmp_path / "remd2"), "--replicas", "8", "--tempStart", "300", "--tempEnd", "500", "-x", "100",
+                          "--iterations", "12", "--timeStep", "2", "--mixing", "neighbours", "-f", forces])
+    assert remd3.attempted.sum() == 12 * 4 - 6 and 0 < remd3.accepted.sum() <= remd3.attempted.sum()   # 4 even pairs, 3 odd pairs
 
 
 def test_awsem_run_on_the_cell_list_path(tmp_path, monkeypatch):
