@@ -190,6 +190,7 @@ public:
         for (auto& G : cell_graph_) if (G.exec) (void)hipGraphExecDestroy(G.exec);
         for (void* p : allocs_) (void)hipFree(p);
         if (h_lmean_) (void)hipHostFree(h_lmean_);
+        if (lmean_ev_) (void)hipEventDestroy(lmean_ev_);
         for (int k = 0; k < NRING; k++) { if (ring0_[k]) (void)hipEventDestroy(ring0_[k]); if (ring1_[k]) (void)hipEventDestroy(ring1_[k]); if (ringT_[k]) (void)hipHostFree(ringT_[k]); }
         if (ev0_) (void)hipEventDestroy(ev0_);
         if (ev1_) (void)hipEventDestroy(ev1_);
@@ -349,13 +350,19 @@ public:
         begin_async(T);
         if ((dsys_.prio & 0xff) == 3 && place_every_ > 0 && launch_ > 0 && launch_ % place_every_ == 0 && nrep_ <= 8192)   // deal the replicas to the CUs anew
             hipLaunchKernelGGL(awsem_place_kernel, dim3(1), dim3(1024), (size_t)nrep_ * sizeof(int), stream_, dsys_.prof, nrep_, dsys_.pace_group);
+        const bool reuse = list_reuse_ && lists_valid_ && skin_ <= lists_skin_;
         hipLaunchKernelGGL(awsem_step_kernel<real>, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, step_T_, nsteps, dt, friction,
-                           (unsigned long long)seed, (long long)step0, launch_++, (int)(list_reuse_ && lists_valid_ && skin_ <= lists_skin_));
+                           (unsigned long long)seed, (long long)step0, launch_++, (int)reuse);
+        // the skin the lists counted after this launch were built under: lists carried in from the previous launch carry ITS skin
+        const double built_skin = reuse ? std::max(skin_, lists_skin_) : skin_;
         lists_valid_ = nsteps > 0;
         lists_skin_ = skin_;
         if (skin_adapt_ && !skin_fixed_ && h_lmean_ && nsteps > 0 && launch_ % 8 == 1) {   // (launch_ was incremented above)
-            lmean_skin_ = skin_;
+            lmean_skin_req_ = built_skin;
+            lmean_due_ = launch_ + AWSEM_LMEAN_LAG;   // the launch whose skin takes the answer
+            if (!lmean_ev_) HIP_TRY(hipEventCreateWithFlags(&lmean_ev_, hipEventDisableTiming));
             hipLaunchKernelGGL(awsem_list_mean_kernel, dim3(1), dim3(256), 0, stream_, (const long long*)dsys_.prof, nrep_, (double)++lmean_tag_, (volatile double*)h_lmean_);
+            HIP_TRY(hipEventRecord(lmean_ev_, stream_));
         }
         HIP_TRY(hipGetLastError());
         end_async();   // asynchronous: resolved by synchronize() / last_kernel_ms
@@ -615,14 +622,18 @@ private:
         for (int r = 0; T && r < nrep_; r++) tmax = std::max(tmax, T[r]);
         static const double sa = getenv("AWSEM_SKIN_A") ? atof(getenv("AWSEM_SKIN_A")) : -0.0125, sb = getenv("AWSEM_SKIN_B") ? atof(getenv("AWSEM_SKIN_B")) : 0.000375;   // tuning knobs
         double skin = std::min(0.25, std::max(0.07, sa + sb * tmax));
-        // Once the lists' lengths are known (every 8th launch asks for their mean, awsem_list_mean_kernel; the answer is picked up here
-        // without waiting for it) the skin follows what the optimum depends on: rebuilds cost ~ N^2 sqrt(T) / skin per step, walks
+        // Once the lists' lengths are known (every 8th launch asks for their mean, awsem_list_mean_kernel; the answer is taken up
+        // exactly AWSEM_LMEAN_LAG launches later -- waiting for it if need be, which by then costs nothing: the launches in between are
+        // still queued -- so the skin schedule, and with it a run's timing, does not depend on how far the host runs ahead of the GPU)
+        // the skin follows what the optimum depends on: rebuilds cost ~ N^2 sqrt(T) / skin per step, walks
         // ~ L (r + skin)^3, so skin_opt ~ N T^(1/4) / sqrt(L).  Calibrated on 1r69 (63 sites) in eight states -- the default schedule and
         // one five times slower, 650 ... 300 K: the constant came out within 10 % in all of them -- where a rule in T alone is right
         // for one schedule only (equilibrated chains at 500 K want 0.13 nm, the default schedule's 0.19).
-        if (skin_adapt_ && h_lmean_ && lmean_tag_ > 0 && h_lmean_[1] == (double)lmean_tag_) {
+        if (skin_adapt_ && h_lmean_ && lmean_due_ >= 0 && launch_ >= lmean_due_) {
+            HIP_TRY(hipEventSynchronize(lmean_ev_));
+            lmean_due_ = -1;
             const double m = 1.3, r_eff = 0.8;   // the lists' mean cutoff and the mean factor on the skin (virtual-site margins)
-            const double f = (r_eff + 0.1 * m) / (r_eff + lmean_skin_ * m);
+            const double f = (r_eff + 0.1 * m) / (r_eff + lmean_skin_req_ * m);
             lhat_ = h_lmean_[0] * f * f * f;      // listed pairs per replica, referred to a skin of 0.1 nm
         }
         if (skin_adapt_ && lhat_ > 0) {
@@ -645,7 +656,10 @@ private:
     bool skin_adapt_ = !(getenv("AWSEM_SKIN_ADAPT") && atoi(getenv("AWSEM_SKIN_ADAPT")) == 0);
     double* h_lmean_ = nullptr;   // pinned: {mean listed pairs per replica, tag of the request}
     long long lmean_tag_ = 0;
-    double lmean_skin_ = 0, lhat_ = 0, skin_sites_ = 63;
+    double lmean_skin_req_ = 0, lhat_ = 0, skin_sites_ = 63;
+    static constexpr int AWSEM_LMEAN_LAG = 4;
+    int lmean_due_ = -1;          // launch number that consumes the pending answer (-1: none pending)
+    hipEvent_t lmean_ev_ = nullptr;
     double skin_ = 0.2;    // nm; AWSEM_SKIN overrides (0.15-0.3 measured: 0.2 and above rebuild rarely enough on the hot, extended stage of an annealing run)
     size_t lds_list_ = 0, lds_max_ = 0, n_cu_ = 256;
     int launch_ = 0;        // step launches so far (parity of the pacing records)

@@ -11,4 +11,4 @@ timeout -s KILL 300 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format c
 timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU_TRANS SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_INSTS_SENDMSG SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU --output-format csv -d $O/pmc_x2_$tag -- $B "$@" > $O/pmc_x2_$tag.log 2>&1 || { tail -5 $O/pmc_x2_$tag.log; exit 2; }
 python3 $R/tools/pmc_tail.py pmc $O/pmc_x1_$tag awsem_step_kernel 3 1 | tee $O/${tag}_pmc_extra.txt
 python3 $R/tools/pmc_tail.py pmc $O/pmc_x2_$tag awsem_step_kernel 3 51200 | tee -a $O/${tag}_pmc_extra.txt
-python3 $R/tools/pmc_tail.py trace $O/prof_r02_v1 awsem_step_kernel 20 2>/dev/null
+[ -d $O/prof_$tag ] && python3 $R/tools/pmc_tail.py trace $O/prof_$tag awsem_step_kernel 20
