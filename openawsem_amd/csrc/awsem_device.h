@@ -149,8 +149,13 @@ template <class real> struct HelicalD { int group, n; const HelicalItem<real>* i
 #define AWSEM_FM_BUNDLE 7
 struct FmBundle { unsigned head, first; };
 template <class real> struct FmD {
-    int group, n, ntab; const unsigned* pairs; const int* pairs2; const real2_t<real>* table2; real k, dr, inv_dr;
+    int group, n, ntab, crop_len; const unsigned* pairs; const int* pairs2; const real2_t<real>* table2; real k, dr, inv_dr;
     const FmBundle* bundles; const unsigned* partners; int nbundles, nb_pad;
+    // fp32 force walks of the bundled form read CROPPED rows (templateTerms.py:273-281 is the full row): per bond only the `crop_len` nodes
+    // crop[b][0 .. crop_len) = t[b][lo_b .. lo_b + crop_len) around the bins whose slope can show in a Q19.12 force accumulator (outside
+    // them k |slope| < 2^-15, which rounds to exactly zero there); lo_b rides in the high half of the bond's partner word.  One float per
+    // node (the two nodes of a bin are one 8-byte load at 4-byte alignment).  Null in fp64 mode and without bundles.
+    const float* crop;
 };
 template <class real> struct MembD { int group, n; const MembItem<real>* items; real k, k_m2, z_m, center; int kind, pad; };   // kind 0: slab; AWSEM_EXT_*: awsem_add_external
 template <class real> struct DhD { int group, n; const DhItem<real>* items; real k, inv_lam; };
@@ -205,4 +210,4 @@ template <class real> struct DevSys {
 };
 // Not a hardware limit (the kernarg segment is sized per kernel: the fp64 cell-list kernels take DevSys + CellSys = 4.4 KB); a guard against growing
 // the block unnoticed -- past some size the compiler may copy a by-value block to scratch (rejected (vii)), which build() checks.
-static_assert(sizeof(DevSys<double>) <= 4064, "DevSys grew: check the step kernel's scratch size in the build remarks");
+static_assert(sizeof(DevSys<double>) <= 4096, "DevSys grew: check the step kernel's scratch size in the build remarks");

@@ -1298,8 +1298,44 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
             std::vector<unsigned> packed(nb, 0u);
             if (natoms_ <= 65535) for (int b = 0; b < nb; b++) packed[b] = (unsigned)pp[2 * b] | ((unsigned)pp[2 * b + 1] << 16);
             if ((size_t)nb * (h.ntab - 1) >= (1ull << 31)) throw std::string("fragment memory: table too large (nbonds x ntab must stay below 2^31)");
-            D.push_back(FmD<real>{h.group, nb, h.ntab, upload(packed), upload(pp), upload(t2), (real)h.k, (real)h.dr, (real)(1.0 / h.dr),
-                                  bundles.empty() ? nullptr : upload(bundles), partners.empty() ? nullptr : upload(partners), (int)bundles.size(), nb_pad});
+            // Cropped rows for the fp32 force walks of the bundled form (FmD::crop).  A bin is ACTIVE when k |slope|, computed in fp32 as the
+            // kernel does, reaches 2^-15: below that every force component s * d * 4096 with |d / r| <= 1 rounds to exactly 0 in a Q19.12
+            // accumulator (a factor 4 inside the rounding threshold 2^-13).  A bond keeps the nodes of its first..last active bin; all rows
+            // have the length of the longest window, a row that would pass the table's end starts earlier.
+            std::vector<float> crop;
+            int crop_len = 0;
+            if (sizeof(real) == 4 && !bundles.empty()) {
+                const float kf = (float)h.k, inv_dr = (float)(1.0 / h.dr), thr = 1.0f / 32768.0f;
+                const bool on = !(getenv("AWSEM_FM_CROP") && atoi(getenv("AWSEM_FM_CROP")) == 0);
+                std::vector<int> first(nb, 0), last(nb, -1);
+                crop_len = 2;
+                for (int b = 0; b < nb && on; b++) {
+                    const double* row = &h.table[(size_t)perm[b] * h.ntab];
+                    int f = -1, l = -1;
+                    for (int i = 0; i + 1 < h.ntab; i++) {
+                        const float slope = ((float)row[i + 1] - (float)row[i]) * inv_dr;
+                        if (std::fabs(kf * slope) >= thr) { if (f < 0) f = i; l = i; }
+                    }
+                    if (f >= 0) { first[b] = f; last[b] = l; crop_len = std::max(crop_len, l - f + 2); }
+                }
+                if (!on || crop_len > (h.ntab * 3) / 4) { crop_len = h.ntab; std::fill(first.begin(), first.end(), 0); }   // not worth cropping
+                crop.resize((size_t)nb * crop_len);
+                std::vector<unsigned> lo_of(nb);
+                for (int b = 0; b < nb; b++) {
+                    const int lo = std::min(first[b], h.ntab - crop_len);
+                    lo_of[b] = (unsigned)lo;
+                    for (int i = 0; i < crop_len; i++) crop[(size_t)b * crop_len + i] = (float)h.table[(size_t)perm[b] * h.ntab + lo + i];
+                }
+                // the window start rides in the high half of the bond's partner word (slots past a bundle's count repeat its first bond)
+                for (size_t k = 0; k < bundles.size(); k++) {
+                    const unsigned cnt = bundles[k].head >> 16, fb = bundles[k].first;
+                    for (unsigned u = 0; u < AWSEM_FM_BUNDLE; u++) partners[(size_t)u * nb_pad + k] |= lo_of[fb + (u < cnt ? u : 0u)] << 16;
+                }
+            }
+            if (getenv("AWSEM_INFO") && crop_len) fprintf(stderr, "[awsem] fragment memory: %d bonds, rows of %d nodes cropped to %d for the fp32 force walk (%.1f MB -> %.1f MB)\n", nb, h.ntab, crop_len, nb * (h.ntab - 1) * 8e-6, nb * crop_len * 4e-6);
+            D.push_back(FmD<real>{h.group, nb, h.ntab, crop_len, upload(packed), upload(pp), upload(t2), (real)h.k, (real)h.dr, (real)(1.0 / h.dr),
+                                  bundles.empty() ? nullptr : upload(bundles), partners.empty() ? nullptr : upload(partners), (int)bundles.size(), nb_pad,
+                                  crop.empty() ? nullptr : upload(crop)});
         }
         if (D.size() > AWSEM_MAX_FM) throw std::string("too many fm terms: at most " + std::to_string(AWSEM_MAX_FM) + " per system");
         S.n_fm = (int)D.size(); for (size_t t = 0; t < D.size(); t++) S.fm[t] = D[t];
@@ -1492,12 +1528,13 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         // plain rotation takes over.
         if ((dsys_.prio & 0xff) == 3 && (size_t)nrep_ > (size_t)n_cu_ * std::min<size_t>(per_cu, 4)) { dsys_.prio = 1; place_every_ = 0; }
     }
+    if (sizeof(real) == 8) block_ = std::min(block_, 512);   // the fp64 kernels are compiled for at most 512 threads (AWSEM_BOUNDS)
     if (getenv("AWSEM_INFO"))
         fprintf(stderr, "[awsem] %d atoms x %d replicas: LDS %zu B per replica stepping (%zu B evaluating) of %zu B per CU -> %zu per CU, %d threads per replica\n",
                 natoms_, nrep_, lds_step_, lds_eval_, lds_max, lds_max / std::max<size_t>(1, lds_step_), block_);
     if (const char* env = getenv("AWSEM_BLOCK")) {
         int b = atoi(env);
-        if (b >= 64 && b <= 1024 && (b & (b - 1)) == 0) block_ = b;   // a power of two: the kernels deal work to waves with masks
+        if (b >= 64 && b <= (sizeof(real) == 8 ? 512 : 1024) && (b & (b - 1)) == 0) block_ = b;   // a power of two: the kernels deal work to waves with masks
     }
     // One distance scan for the hydrogen-bond terms that share a list (build_hbond_group): the members must screen the same atoms
     // against the same radius, and a wave's share of the donors must fit a 64-bit mask (ndon <= 64 waves = block size).

@@ -486,11 +486,18 @@ template <bool ENERGY, bool PACKED = true, class V> __device__ __forceinline__ v
 // Bundled walk (replica-resident path): one lane per bundle of <= AWSEM_FM_BUNDLE bonds around one owner atom.  The owner's
 // position is read once, its force is summed in integer registers (bit-identical to the atomics it replaces) and added once:
 // a third fewer LDS reads and atomics than bond-by-bond, all table gathers of the bundle in flight together.
+// two neighbouring floats in one 8-byte load at 4-byte alignment (global_load_dwordx2 needs dword alignment only)
+struct __attribute__((packed, aligned(4))) Float2U { float x, y; };
 template <bool ENERGY, class V> __device__ __forceinline__ void term_fm_bundled(const FmD<typename V::real_t>& d, const V& L, int rot = 0) {
     typedef typename V::real_t real;
     constexpr int K = AWSEM_FM_BUNDLE;
+    // fp32 force walks read the cropped rows (FmD::crop): a bin outside a bond's window has k |slope| < 2^-15 and adds exact zeros to the
+    // Q19.12 accumulators, so it is skipped -- bit-identical forces from a table a quarter of the size (2xov: 27.6 MB -> 3.8 MB, inside L2).
+    // Energy evaluations and the fp64 mode read the full rows.
+    constexpr bool CROP = !ENERGY && sizeof(real) == 4;
     Energy e;
     const unsigned nrow = (unsigned)d.ntab - 1u;
+    const unsigned clen = (unsigned)d.crop_len;
     for (int k = rot_tid(rot); k < d.nbundles; k += L.nthr) {
         const FmBundle h = d.bundles[k];
         const unsigned o = h.head & 0xffffu, cnt = h.head >> 16;
@@ -498,25 +505,33 @@ template <bool ENERGY, class V> __device__ __forceinline__ void term_fm_bundled(
         real r[K], ir[K];
         real2_t<real> v[K];
 #pragma unroll
-        for (int u = 0; u < K; u++) pj[u] = d.partners[(unsigned)u * (unsigned)d.nb_pad + (unsigned)k];   // slots past the count repeat the first partner
+        for (int u = 0; u < K; u++) pj[u] = d.partners[(unsigned)u * (unsigned)d.nb_pad + (unsigned)k];   // atom | lo << 16; slots past the count repeat the first partner
         const R3<real> po = L.pos(o);
 #pragma unroll
         for (int u = 0; u < K; u++) {
-            const R3<real> dd = po - L.pos(pj[u]);
+            const R3<real> dd = po - L.pos(pj[u] & 0xffffu);
             const real r2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z;
             ir[u] = M<real>::rsqrt(r2); r[u] = r2 * ir[u];
             const unsigned bin = (unsigned)(int)(r[u] * d.inv_dr);   // r >= 0: truncation is floor
             i1[u] = bin < nrow - 1u ? bin : nrow - 1u;
-            v[u] = d.table2[(h.first + ((unsigned)u < cnt ? (unsigned)u : 0u)) * nrow + i1[u]];   // (t[i], t[i+1]) in one load
+            const unsigned bond = h.first + ((unsigned)u < cnt ? (unsigned)u : 0u);
+            if (CROP) {
+                const unsigned c = i1[u] - (pj[u] >> 16);            // wraps below the window
+                i1[u] = c;                                           // kept as the in-window test
+                const Float2U w = *(const Float2U*)((const float*)d.crop + bond * clen + (c < clen - 1u ? c : 0u));
+                v[u].x = (real)w.x; v[u].y = (real)w.y;
+            } else
+                v[u] = d.table2[bond * nrow + i1[u]];                // (t[i], t[i+1]) in one load
         }
         typename V::acc_t A = V::acc_zero();
 #pragma unroll
         for (int u = 0; u < K; u++) {
             if ((unsigned)u >= cnt) continue;
+            if (CROP && i1[u] >= clen - 1u) continue;
             const real slope = (v[u].y - v[u].x) * d.inv_dr;
             if (ENERGY) e += (double)(-d.k * (v[u].x + slope * (r[u] - d.dr * (real)i1[u])));
-            const R3<real> dd = po - L.pos(pj[u]);   // read again rather than kept in registers across the gather
-            L.pair_force_owner(A, pj[u], dd.x, dd.y, dd.z, d.k * slope * ir[u]);
+            const R3<real> dd = po - L.pos(pj[u] & 0xffffu);   // read again rather than kept in registers across the gather
+            L.pair_force_owner(A, pj[u] & 0xffffu, dd.x, dd.y, dd.z, d.k * slope * ir[u]);
         }
         L.add_acc(o, A);
     }
@@ -1461,8 +1476,14 @@ template <class V> __device__ inline void load_positions(const typename V::real_
 }
 
 // ------------------------------------------------------------------ evaluation kernel (energies and/or forces)
+// The fp64 check mode compiles with a register budget of its own: at most 512 threads per workgroup (two waves per SIMD -> 256 VGPRs); under
+// the fp32 kernels' 1024-thread cap (128 VGPRs) its step kernel spilled 176 VGPRs.  Engine::finalize keeps fp64 workgroups within the bound.
+#ifndef AWSEM_FP64_THREADS
+#define AWSEM_FP64_THREADS 512
+#endif
+#define AWSEM_BOUNDS(real) __launch_bounds__(sizeof(real) == 8 ? AWSEM_FP64_THREADS : 1024)
 template <bool ENERGY, class real>
-__global__ void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__ pos, unsigned mask, int redistribute,
+__global__ AWSEM_BOUNDS(real) void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__ pos, unsigned mask, int redistribute,
                                   double* __restrict__ e_out /* [R][32] or null */, double* __restrict__ f_out /* [R][natoms][3] or null */,
                                   const double* __restrict__ xyz_aos /* null, or [R][natoms][3] in the caller's atom order instead of `pos` */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1500,7 +1521,7 @@ __global__ void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__
 
 // Pair-list dump for awsem_neighbors: builds the lists of the terms in `mask` and writes the per-list counts.
 template <class real>
-__global__ void awsem_list_kernel(const DevSys<real> S, const real* __restrict__ pos, unsigned mask, unsigned* __restrict__ counts /* [R][AWSEM_MAX_LISTS] */) {
+__global__ AWSEM_BOUNDS(real) void awsem_list_kernel(const DevSys<real> S, const real* __restrict__ pos, unsigned mask, unsigned* __restrict__ counts /* [R][AWSEM_MAX_LISTS] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = blockIdx.x;
     Lds<real> L = carve_lds((real)0, smem, lds_shape(S), false);
@@ -1832,7 +1853,7 @@ __device__ __forceinline__ void set_wave_priority(int p) {
 #define AWSEM_STEP_ATTR
 #endif
 template <class real>
-__global__ AWSEM_STEP_ATTR void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, real* __restrict__ vel,
+__global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, real* __restrict__ vel,
                                   const double* __restrict__ T, int nsteps, double dt, double friction, unsigned long long seed,
                                   long long step0, int launch, int reuse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2063,7 +2084,7 @@ __global__ void awsem_place_kernel(long long* prof, int nrep, int group) {
 // The three sums an iteration needs (F.v, F.F, v.v) are fixed-point LDS accumulators (L.eg[0..2]), so a minimisation is
 // bit-reproducible; F.v and F.F are scaled by 2^-10 / 2^-20 to stay inside Q31.32 for the clashing start structures.
 template <class real>
-__global__ void awsem_minimize_kernel(const DevSys<real> S, real* __restrict__ pos, double tolerance, int max_iterations,
+__global__ AWSEM_BOUNDS(real) void awsem_minimize_kernel(const DevSys<real> S, real* __restrict__ pos, double tolerance, int max_iterations,
                                       int* __restrict__ iterations /* [R] */, double* __restrict__ rms_out /* [R] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = blockIdx.x;

@@ -418,3 +418,41 @@ def test_beta_screen_drops_only_exact_zeros(knob, monkeypatch):
     assert np.array_equal(out[0][0], out[1][0])                       # forces
     assert np.array_equal(out[0][2][0], out[1][2][0]) and np.array_equal(out[0][2][1], out[1][2][1])   # positions, velocities after 300 steps
     assert np.abs(out[0][1] - out[1][1]).max() < 1e-6 and np.abs(out[0][1][:, 27 if "BETA" in knob else 28]).min() > 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["1ubq", "2xov"])
+def test_cropped_fragment_memory_rows_drop_only_exact_zeros(workload, monkeypatch):
+    """fp32: the force walk of the fragment-memory term reads rows cropped to the bins whose slope can show in a Q19.12 accumulator
+    (csrc/awsem_hip.hip, fragment-memory block: k |slope| >= 2^-15, a quarter of what rounds to zero; the full row is the reference's,
+    templateTerms.py:273-281).  With AWSEM_FM_CROP=0 the same walk reads full rows: forces and a 300-step trajectory must agree BIT FOR
+    BIT, and so must the energies, which are always evaluated from the full rows.  2xov is the configuration the crop is for (6 908
+    bonds, a 27.6 MB table against 4 MB of L2).  (Q19.12 is the replica-resident path's: the test pins that path.)"""
+    monkeypatch.delenv("AWSEM_FORCE_CELL", raising=False)
+    if workload == "1ubq":
+        oa, traj, _ = golden_system("1ubq")
+        starts = [traj[0], traj[9]]
+    else:
+        from openawsem_amd import workloads
+        oa = workloads.build_2xov()
+        x0 = np.asarray(oa.pdb.positions, dtype=np.float64)
+        starts = [x0, x0 + np.random.default_rng(3).normal(0, 0.005, x0.shape)]
+    T = np.array([300.0, 700.0])
+    out = []
+    for crop in (None, "0"):
+        monkeypatch.delenv("AWSEM_FM_CROP", raising=False)
+        if crop:
+            monkeypatch.setenv("AWSEM_FM_CROP", crop)
+        gpu = _gpu(oa, 2, FP32)
+        for r in range(2):
+            gpu.set_positions(starts[r], replica=r)
+        f0 = gpu.forces(redistribute=False)
+        e0 = gpu.energy_by_group()
+        gpu.set_velocities_to_temperature(T, 5)
+        gpu.step(300, T, 0.002, 1.0, 6)
+        out.append((f0, e0, gpu.get_state()))
+        gpu.close()
+    monkeypatch.delenv("AWSEM_FM_CROP", raising=False)
+    assert np.array_equal(out[0][0], out[1][0])                       # forces
+    assert np.array_equal(out[0][1], out[1][1]) and np.abs(out[0][1][:, 23]).min() > 1.0   # energies (group 23 = Fragment)
+    assert np.array_equal(out[0][2][0], out[1][2][0]) and np.array_equal(out[0][2][1], out[1][2][1])   # positions, velocities after 300 steps
