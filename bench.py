@@ -302,6 +302,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # replica exchange: what one exchange costs with the launch's lists in place -- back-to-back sweeps on unchanged positions (energy
+    # kernel walking the lists the last launch left, group sum, [all-gather,] sweep kernel, velocity rescale), outside the timed region
+    exchange_us = None
+    if remd is not None:
+        barrier()
+        remd.exchange_on_device()      # a replica that ended the launch beyond skin/2 rebuilds its lists in this one (the next launch's rebuild)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            remd.exchange_on_device()
+        barrier()
+        exchange_us = (time.perf_counter() - t0) / args.steps * 1e6
+        if world > 1:
+            t = torch.tensor([exchange_us], device=coll_device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            exchange_us = float(t.item())
+
     # sanity: the trajectories are alive (finite energies), not part of the timed region
     e = ctx.energy()
     if not np.all(np.isfinite(e)):
@@ -399,8 +416,12 @@ def main():
         if remd is not None:
             remd.pull()
             out["config"]["remd_acceptance"] = [round(float(a), 3) for a in remd.acceptance()[:8]]
-            # what one exchange costs on top of the MD launch it follows: wall time per iteration minus the step kernel's own time
-            out["remd_exchange_us"] = (elapsed / args.steps - k_ms * 1e-3) * 1e6
+            # What one exchange costs once the lists are in place (measured above, back to back), and the in-situ figure: wall time per
+            # iteration minus the step kernel's own time.  The latter also holds the list rebuilds of the replicas that ended the launch
+            # more than skin/2 from where their lists were built: they rebuild in the energy kernel and hand the lists to the next
+            # launch, which would otherwise have begun with that rebuild.
+            out["remd_exchange_us"] = exchange_us
+            out["remd_iteration_minus_step_kernel_us"] = (elapsed / args.steps - k_ms * 1e-3) * 1e6
             out["config"]["remd_exchange"] = ("per iteration: energy kernel + group sum into a device buffer, "
                                               + ("one all_gather_into_tensor over RCCL, " if world > 1 else "") + "sweep kernel (Metropolis, ladder index swap), velocity rescale; no host copy")
         if not args.no_cpu_baseline and world == 1 and args.workload == "1r69":

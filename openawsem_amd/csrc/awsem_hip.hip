@@ -233,8 +233,9 @@ public:
     void energy_by_group(unsigned mask, double* e) override {
         HIP_TRY(hipSetDevice(device_));
         if (cell_mode_) { cell_evaluate(true, mask, 0, e, nullptr); return; }
+        const bool reuse = query_reuse();
         HIP_TRY(hipEventRecord(ev0_, stream_));
-        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr);
+        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1_, stream_));
         HIP_TRY(hipMemcpyAsync(e, dE_, sizeof(double) * nrep_ * AWSEM_NGROUPS, hipMemcpyDeviceToHost, stream_));
@@ -245,8 +246,9 @@ public:
     void forces(unsigned mask, int redistribute, double* f) override {
         HIP_TRY(hipSetDevice(device_));
         if (cell_mode_) { cell_evaluate(false, mask, redistribute, nullptr, f); return; }
+        const bool reuse = query_reuse();
         HIP_TRY(hipEventRecord(ev0_, stream_));
-        hipLaunchKernelGGL((awsem_eval_kernel<false, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, eval_sys(), pos_, mask, redistribute, (double*)nullptr, dF_, (const double*)nullptr);
+        hipLaunchKernelGGL((awsem_eval_kernel<false, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, redistribute, (double*)nullptr, dF_, (const double*)nullptr, (int)reuse);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1_, stream_));
         HIP_TRY(hipMemcpyAsync(f, dF_, sizeof(double) * 3 * natoms_ * nrep_, hipMemcpyDeviceToHost, stream_));
@@ -300,7 +302,8 @@ public:
             HIP_TRY(hipMemcpy(out, e.data(), sizeof(double) * nrep_, hipMemcpyHostToDevice));
             return;
         }
-        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr);
+        const bool reuse = query_reuse();
+        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse);
         hipLaunchKernelGGL(awsem_group_sum_kernel, dim3((nrep_ + 255) / 256), dim3(256), 0, stream_, (const double*)dE_, mask, out, nrep_);
         HIP_TRY(hipGetLastError());
     }
@@ -450,7 +453,7 @@ public:
         S.lists = (unsigned*)(base + 256);
         HIP_TRY(hipMemsetAsync(base, 0, 256, stream));   // the status word must start at zero; the lists are written before they are read
         hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep), dim3(block_), lds_eval_, stream, S, (const real*)nullptr, 0xffffffffu, 0,
-                           d_energy, (double*)nullptr, d_xyz);
+                           d_energy, (double*)nullptr, d_xyz, 0);
         HIP_TRY(hipGetLastError());
     }
 
@@ -667,9 +670,12 @@ private:
     // positions since (every place that sets cell_stale_), or the skin has grown: lists built with a larger skin stay valid under a
     // smaller one (the rebuild test only gets stricter), not the other way round.  Energy / force / neighbour queries build their lists
     // in a buffer of their own (lists_eval_), so a reporter between two launches costs the dynamics nothing.  AWSEM_LIST_REUSE=0: off.
-    bool lists_valid_ = false, list_reuse_ = true;
+    bool lists_valid_ = false, list_reuse_ = true, query_reuse_ = true;
     double lists_skin_ = 0;
     unsigned* lists_eval_ = nullptr;
+    // Energy / force queries walk the pair lists the last step launch left in device memory when those are still the lists of the stored
+    // positions (nothing set from outside since, no minimisation, same skin): awsem_eval_kernel checks the displacement per replica.
+    bool query_reuse() const { return list_reuse_ && query_reuse_ && lists_valid_ && !cell_mode_; }
     DevSys<real> eval_sys() const { DevSys<real> S = dsys_; if (lists_eval_) S.lists = lists_eval_; return S; }
     int place_every_ = 16;  // launches between two placements of the replicas on the CUs (0: never), AWSEM_PLACE_EVERY
     bool step_ok_ = false;
@@ -1488,6 +1494,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         S.list_ref = dalloc<real>((size_t)nrep_ * 3 * std::max(1, S.nmassive));
         S.list_counts = dalloc<unsigned>((size_t)nrep_ * AWSEM_MAX_LISTS);
         list_reuse_ = !(getenv("AWSEM_LIST_REUSE") && atoi(getenv("AWSEM_LIST_REUSE")) == 0);
+        query_reuse_ = !(getenv("AWSEM_QUERY_REUSE") && atoi(getenv("AWSEM_QUERY_REUSE")) == 0);
         if (!h_lmean_) { HIP_TRY(hipHostMalloc((void**)&h_lmean_, 2 * sizeof(double), hipHostMallocDefault)); h_lmean_[0] = h_lmean_[1] = 0; }
         skin_sites_ = S.max_contact_sites > 0 ? (double)S.max_contact_sites : (double)natoms_ / 6.0;
         S.skin_half2 = (real)(0.25 * skin_ * skin_ * 0.999);

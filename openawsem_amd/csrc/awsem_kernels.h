@@ -1475,6 +1475,12 @@ template <class V> __device__ inline void load_positions(const typename V::real_
     for (int i = threadIdx.x; i < natoms; i += L.nthr) { L.set_pos(i, R3<real>{g[i], g[natoms + i], g[2 * natoms + i]}); L.zero_force(i); }
 }
 
+// largest squared displacement of the workgroup's particles since the last list build, into an LDS word
+__device__ __forceinline__ void book_displacement(unsigned* flag, float m) {
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(flag, __float_as_uint(m));   // non-negative floats order like their bits
+}
+
 // ------------------------------------------------------------------ evaluation kernel (energies and/or forces)
 // The fp64 check mode compiles with a register budget of its own: at most 512 threads per workgroup (two waves per SIMD -> 256 VGPRs); under
 // the fp32 kernels' 1024-thread cap (128 VGPRs) its step kernel spilled 176 VGPRs.  Engine::finalize keeps fp64 workgroups within the bound.
@@ -1485,7 +1491,8 @@ template <class V> __device__ inline void load_positions(const typename V::real_
 template <bool ENERGY, class real>
 __global__ AWSEM_BOUNDS(real) void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__ pos, unsigned mask, int redistribute,
                                   double* __restrict__ e_out /* [R][32] or null */, double* __restrict__ f_out /* [R][natoms][3] or null */,
-                                  const double* __restrict__ xyz_aos /* null, or [R][natoms][3] in the caller's atom order instead of `pos` */) {
+                                  const double* __restrict__ xyz_aos /* null, or [R][natoms][3] in the caller's atom order instead of `pos` */,
+                                  int reuse /* S.lists are the lists the last step launch left for these very positions: walk them instead of building */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = blockIdx.x;
     Lds<real> L = carve_lds((real)0, smem, lds_shape(S), false);
@@ -1500,11 +1507,38 @@ __global__ AWSEM_BOUNDS(real) void awsem_eval_kernel(const DevSys<real> S, const
     } else load_positions(pos + (size_t)rep * 3 * natoms, L, natoms);
     for (int i = threadIdx.x; i < S.max_contact_sites; i += L.nthr) L.rho[i] = 0;
     if (threadIdx.x < AWSEM_NGROUPS) L.eg[threadIdx.x] = 0;
-    if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
+    if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = reuse ? S.list_counts[(size_t)rep * AWSEM_MAX_LISTS + threadIdx.x] : 0u;
+    if (threadIdx.x == 0) L.flag[0] = 0;
     stage_tables(S, L);
     __syncthreads();
-    build_lists(S, L, mask);
-    __syncthreads();
+    // A query right after a step launch (a reporter's energies, the energies of a replica-exchange sweep) finds that launch's lists in
+    // device memory, built for positions at most skin/2 away unless the launch's last step went further: the evaluators apply the exact
+    // cutoffs themselves, so the lists serve as they are.  A replica that HAS gone further rebuilds them here, in place, and leaves
+    // them (lengths, reference positions) as the next step launch expects them -- the rebuild that launch would have started with.
+    bool build = true;
+    if (reuse) {   // uniform
+        real* gr = S.list_ref + (size_t)rep * 3 * S.nmassive;
+        float m = 0;
+        for (int k = threadIdx.x; k < S.nmassive; k += L.nthr)
+            m = fmaxf(m, (float)dist2(L.pos(S.massive[k].atom) - R3<real>{gr[3 * k], gr[3 * k + 1], gr[3 * k + 2]}));
+        book_displacement(&L.flag[0], m);
+        __syncthreads();
+        build = __uint_as_float(L.flag[0]) > (float)S.skin_half2;
+        if (build) {
+            __syncthreads();   // everyone has read the flag and the old reference positions
+            if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
+            for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) {
+                const R3<real> x = L.pos(S.massive[k].atom);
+                gr[3 * k] = x.x; gr[3 * k + 1] = x.y; gr[3 * k + 2] = x.z;
+            }
+            __syncthreads();
+        }
+    }
+    if (build) {
+        build_lists(S, L, reuse ? 0xffffffffu : mask);
+        __syncthreads();
+        if (reuse && threadIdx.x < AWSEM_MAX_LISTS) S.list_counts[(size_t)rep * AWSEM_MAX_LISTS + threadIdx.x] = L.lcount[threadIdx.x];
+    }
     AWSEM_STAMP_INIT;
     evaluate_terms<ENERGY>(S, L, mask, false AWSEM_STAMP_PASS);
     if (f_out) {
@@ -1742,10 +1776,6 @@ __global__ void awsem_vsite_kernel(const DevSys<real> S, real* __restrict__ pos)
 //       atomics), clears its accumulator, takes the Langevin step and books its displacement since the last list build
 //   ->  VIRTUAL SITES: positions from the new parents, accumulators cleared, displacement booked.
 // The displacement maximum is double buffered (L.flag[s & 1] is read while L.flag[~s & 1] is being written).
-__device__ __forceinline__ void book_displacement(unsigned* flag, float m) {
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(flag, __float_as_uint(m));   // non-negative floats order like their bits
-}
 // ---- centre-of-mass motion removal (OpenMM CMMotionRemover, frequency 1)
 // The total momentum sum_i m_i v_i of a replica is accumulated in fixed point (integer adds commute: the sum does not depend on
 // which lane owns which particle, so a trajectory stays bit-identical under any workgroup size or atom order).  fp32: Q15.16 in

@@ -456,3 +456,40 @@ def test_cropped_fragment_memory_rows_drop_only_exact_zeros(workload, monkeypatc
     assert np.array_equal(out[0][0], out[1][0])                       # forces
     assert np.array_equal(out[0][1], out[1][1]) and np.abs(out[0][1][:, 23]).min() > 1.0   # energies (group 23 = Fragment)
     assert np.array_equal(out[0][2][0], out[1][2][0]) and np.array_equal(out[0][2][1], out[1][2][1])   # positions, velocities after 300 steps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [FP32, FP64])
+@pytest.mark.parametrize("skin", ["0.03", "0.25"])
+def test_queries_after_a_launch_walk_the_launch_s_own_lists(precision, skin, monkeypatch):
+    """Energies and forces asked for right after a step launch (a reporter; the energies of a replica-exchange sweep, scripts/mm_remd.py:
+    133-149) walk the pair lists that launch left in device memory instead of building their own (awsem_eval_kernel, `reuse`).  With a
+    skin of 0.03 nm nearly every replica ends a launch further than skin/2 from where its lists were built: the query then rebuilds them
+    in place and hands them to the next launch; with 0.25 nm none does.  Either way energies (also of a subset of the groups), forces
+    and the trajectory that follows must equal AWSEM_QUERY_REUSE=0 bit for bit."""
+    monkeypatch.delenv("AWSEM_FORCE_CELL", raising=False)
+    monkeypatch.setenv("AWSEM_SKIN", skin)
+    oa, traj, _ = golden_system("1ubq")
+    R = 5
+    out = []
+    for reuse in ("1", "0"):
+        monkeypatch.setenv("AWSEM_QUERY_REUSE", reuse)
+        gpu = _gpu(oa, R, precision)
+        for r in range(R):
+            gpu.set_positions(traj[(2 * r) % len(traj)], replica=r)
+        T = np.linspace(300.0, 800.0, R)
+        gpu.set_velocities_to_temperature(T, 5)
+        log = []
+        for it in range(3):
+            gpu.step(20, T, 0.002, 1.0, 6)
+            log.append(gpu.energy((1 << 22) | (1 << 27)))         # contact and beta only: a stale replica still rebuilds every list
+            log.append(gpu.forces())
+            gpu.step(20, T, 0.002, 1.0, 6)
+            log.append(gpu.energy_by_group())
+        out.append((gpu.get_state(), log))
+        gpu.close()
+    monkeypatch.delenv("AWSEM_QUERY_REUSE", raising=False)
+    assert np.array_equal(out[0][0][0], out[1][0][0]) and np.array_equal(out[0][0][1], out[1][0][1])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b)
+    assert np.isfinite(out[0][0][0]).all() and np.abs(out[0][1][0]).min() > 1.0
