@@ -235,6 +235,18 @@ int awsem_get_state(awsem_handle h, double* xyz, double* vxyz);
 /* Kinetic energy of every replica, sum over the massive particles of 1/2 m v^2 (kJ/mol): the temperature column of
  * StateDataReporter (scripts/mm_run.py:157-158), reduced on the device. */
 int awsem_kinetic_energy(awsem_handle h, double* ke_per_replica);
+/* Asynchronous snapshot for the reporters of a run (StateDataReporter, DCDReporter, CheckpointReporter: scripts/mm_run.py:157-164, which
+ * OpenMM serves synchronously inside simulation.step).  awsem_snapshot_begin queues, BEHIND everything the handle's stream already holds:
+ * the potential energy of the masked groups (of every replica when energy_replica is -1, else of that replica alone -- what
+ * StateDataReporter prints; the other replicas' entries are then NaN) and the kinetic energy of every replica, a copy of the positions
+ * of `replica` (-1: none) and, if with_state != 0, of the whole ensemble state -- all into pinned host memory the handle owns (slot 0 or 1) -- and returns
+ * without waiting.  awsem_snapshot_end waits for that slot only and hands the values out, converted exactly as awsem_energy,
+ * awsem_kinetic_energy, awsem_get_positions and awsem_get_state convert them (any output may be NULL; xyz_all / vxyz_all need
+ * with_state).  A caller that queues the next awsem_step between the two calls writes its files while the GPU computes.  A slot holds
+ * one snapshot at a time: begin on a slot that has not been collected is AWSEM_ESTATE. */
+int awsem_snapshot_begin(awsem_handle h, int slot, uint32_t group_mask, int energy_replica, int replica, int with_state);
+int awsem_snapshot_end(awsem_handle h, int slot, double* e_per_replica, double* ke_per_replica, double* xyz_replica,
+                       double* xyz_all, double* vxyz_all);
 int awsem_compute_virtual_sites(awsem_handle h);
 /* context.setVelocitiesToTemperature scripts/mm_run.py:151; T is per replica (n_replicas). */
 int awsem_set_velocities_to_temperature(awsem_handle h, const double* T_kelvin, uint64_t seed);

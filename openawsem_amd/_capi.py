@@ -83,6 +83,9 @@ _HIP_ONLY = {
     "remd_sweep": (C.c_int, ["H", C.c_void_p, C.c_int64]),
     "remd_state": (C.c_int, ["H", c_int_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_dbl_p]),
     "remd_set_mixing": (C.c_int, ["H", C.c_int]),
+    # asynchronous snapshots for reporters: pinned host memory and stream events, nothing for the CPU oracle to mirror
+    "snapshot_begin": (C.c_int, ["H", C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int]),
+    "snapshot_end": (C.c_int, ["H", C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p]),
 }
 
 EXPORTED_SYMBOLS = tuple("awsem_" + n for n in list(_SIGNATURES) + list(_HIP_ONLY))
@@ -162,7 +165,7 @@ class Context:
             pass
 
     _READ_ONLY = frozenset(("get_positions", "get_velocities", "get_state", "kinetic_energy", "energy", "energy_by_group",
-                            "forces", "neighbors", "synchronize"))
+                            "forces", "neighbors", "synchronize", "snapshot_begin", "snapshot_end"))
 
     def _call(self, name, *args):
         if name not in self._READ_ONLY:
@@ -332,6 +335,22 @@ class Context:
 
     def compute_virtual_sites(self):
         self._call("compute_virtual_sites")
+
+    # ---- asynchronous snapshots (include/awsem_hip.h: awsem_snapshot_begin / _end): what the reporters of a run read, fetched behind
+    # the launches already queued and collected after the NEXT launch has been queued, so the GPU does not idle while files are written
+    def snapshot_begin(self, slot, group_mask=0xFFFFFFFF, energy_replica=-1, replica=0, with_state=False):
+        self._call("snapshot_begin", int(slot), C.c_uint32(group_mask & 0xFFFFFFFF), int(energy_replica), int(replica), int(bool(with_state)))
+
+    def snapshot_end(self, slot, energy=True, replica_positions=True, state=False):
+        """-> dict(energy [R], kinetic [R], positions [natoms, 3] or None, state (x, v) or None)"""
+        e = np.empty(self.n_replicas) if energy else None
+        ke = np.empty(self.n_replicas)
+        x1 = np.empty((self.natoms, 3)) if replica_positions else None
+        xs = np.empty((self.n_replicas, self.natoms, 3)) if state else None
+        vs = np.empty((self.n_replicas, self.natoms, 3)) if state else None
+        self._call("snapshot_end", int(slot), None if e is None else _dp(e), _dp(ke), None if x1 is None else _dp(x1),
+                   None if xs is None else _dp(xs), None if vs is None else _dp(vs))
+        return {"energy": e, "kinetic": ke, "positions": x1, "state": (xs, vs) if state else None}
 
     def set_velocities_to_temperature(self, T, seed):
         T = np.broadcast_to(_f64(T), (self.n_replicas,)).copy()

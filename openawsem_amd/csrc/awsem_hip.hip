@@ -16,6 +16,7 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <limits>
 #include <map>
 
 #include "../../include/awsem_hip.h"
@@ -102,6 +103,8 @@ struct EngineBase {
     virtual void kinetic_energy(double* ke) = 0;
     virtual void set_state_all(const double* xyz, const double* v) = 0;
     virtual void get_state_all(double* xyz, double* v) = 0;
+    virtual void snapshot_begin(int slot, unsigned mask, int energy_replica, int replica, int with_state) = 0;
+    virtual void snapshot_end(int slot, double* e, double* ke, double* xyz_replica, double* xyz_all, double* v_all) = 0;
     virtual void minimize(double tolerance, int max_iterations, int32_t* iterations, double* rms) = 0;
     virtual int neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity) = 0;
     virtual void energy_noalloc(int nrep, const double* d_xyz, double* d_energy, hipStream_t stream) = 0;
@@ -193,6 +196,10 @@ public:
         if (lmean_ev_) (void)hipEventDestroy(lmean_ev_);
         for (int k = 0; k < NRING; k++) { if (ring0_[k]) (void)hipEventDestroy(ring0_[k]); if (ring1_[k]) (void)hipEventDestroy(ring1_[k]); if (ringT_[k]) (void)hipHostFree(ringT_[k]); }
         if (ev0_) (void)hipEventDestroy(ev0_);
+        for (auto& sn : snap_) {
+            if (sn.ev) (void)hipEventDestroy(sn.ev);
+            for (void* q : {(void*)sn.e, (void*)sn.ke, (void*)sn.x1, (void*)sn.xs, (void*)sn.vs}) if (q) (void)hipHostFree(q);
+        }
         if (ev1_) (void)hipEventDestroy(ev1_);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
@@ -235,7 +242,7 @@ public:
         if (cell_mode_) { cell_evaluate(true, mask, 0, e, nullptr); return; }
         const bool reuse = query_reuse();
         HIP_TRY(hipEventRecord(ev0_, stream_));
-        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse);
+        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, 0);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1_, stream_));
         HIP_TRY(hipMemcpyAsync(e, dE_, sizeof(double) * nrep_ * AWSEM_NGROUPS, hipMemcpyDeviceToHost, stream_));
@@ -248,7 +255,7 @@ public:
         if (cell_mode_) { cell_evaluate(false, mask, redistribute, nullptr, f); return; }
         const bool reuse = query_reuse();
         HIP_TRY(hipEventRecord(ev0_, stream_));
-        hipLaunchKernelGGL((awsem_eval_kernel<false, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, redistribute, (double*)nullptr, dF_, (const double*)nullptr, (int)reuse);
+        hipLaunchKernelGGL((awsem_eval_kernel<false, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, redistribute, (double*)nullptr, dF_, (const double*)nullptr, (int)reuse, 0);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1_, stream_));
         HIP_TRY(hipMemcpyAsync(f, dF_, sizeof(double) * 3 * natoms_ * nrep_, hipMemcpyDeviceToHost, stream_));
@@ -303,7 +310,7 @@ public:
             return;
         }
         const bool reuse = query_reuse();
-        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse);
+        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, 0);
         hipLaunchKernelGGL(awsem_group_sum_kernel, dim3((nrep_ + 255) / 256), dim3(256), 0, stream_, (const double*)dE_, mask, out, nrep_);
         HIP_TRY(hipGetLastError());
     }
@@ -423,6 +430,80 @@ public:
                 dst[r * n3 + 3 * (size_t)i + k] = (double)t[r * n3 + (size_t)k * natoms_ + in_(i)];
         }
     }
+    // ---- asynchronous snapshots for reporters (include/awsem_hip.h: awsem_snapshot_begin / _end)
+    // begin: behind whatever the stream holds, the masked potential energies and the kinetic energies of all replicas, the positions of
+    // one replica and (with_state) the whole ensemble state are evaluated / copied into pinned host memory of slot 0 or 1; nothing waits.
+    // end: waits for that slot's event only -- launches queued after `begin` keep the GPU busy meanwhile -- and converts exactly as the
+    // synchronous queries do (awsem_energy, awsem_kinetic_energy, awsem_get_positions, awsem_get_state): the same numbers.
+    struct Snap { hipEvent_t ev = nullptr; double* e = nullptr; double* ke = nullptr; real* x1 = nullptr; real* xs = nullptr; real* vs = nullptr;
+                  unsigned mask = 0; int replica = -1, energy_replica = -1; bool with_state = false, busy = false; };
+    Snap snap_[2];
+    void snapshot_begin(int slot, unsigned mask, int energy_replica, int replica, int with_state) override {
+        if (slot < 0 || slot > 1) throw std::string("snapshot_begin: slot must be 0 or 1");
+        if (replica >= nrep_ || energy_replica >= nrep_) throw std::string("snapshot_begin: replica out of range");
+        Snap& sn = snap_[slot];
+        if (sn.busy) throw StateError{"snapshot_begin: the slot holds a snapshot that has not been collected (awsem_snapshot_end)"};
+        HIP_TRY(hipSetDevice(device_));
+        const size_t n3 = (size_t)3 * natoms_;
+        if (!sn.ev) {
+            HIP_TRY(hipEventCreateWithFlags(&sn.ev, hipEventDisableTiming));
+            HIP_TRY(hipHostMalloc((void**)&sn.e, sizeof(double) * nrep_ * AWSEM_NGROUPS, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void**)&sn.ke, sizeof(double) * nrep_, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void**)&sn.x1, sizeof(real) * n3, hipHostMallocDefault));
+        }
+        if (with_state && !sn.xs) {
+            HIP_TRY(hipHostMalloc((void**)&sn.xs, sizeof(real) * n3 * nrep_, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void**)&sn.vs, sizeof(real) * n3 * nrep_, hipHostMallocDefault));
+        }
+        sn.mask = mask; sn.replica = replica; sn.with_state = with_state != 0;
+        if (cell_mode_) {   // the cell-list evaluation is a host-driven sequence with its own retries: taken at once
+            cell_evaluate(true, mask, 0, sn.e, nullptr);
+        } else if (mask) {
+            const bool reuse = query_reuse();
+            // one replica's energies (what StateDataReporter prints) are one workgroup; the other rows of the slot are left as NaN
+            const int first = energy_replica >= 0 ? energy_replica : 0, count = energy_replica >= 0 ? 1 : nrep_;
+            hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(count), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, first);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(sn.e + (size_t)first * AWSEM_NGROUPS, dE_ + (size_t)first * AWSEM_NGROUPS, sizeof(double) * count * AWSEM_NGROUPS, hipMemcpyDeviceToHost, stream_));
+        }
+        sn.energy_replica = cell_mode_ ? -1 : energy_replica;
+        hipLaunchKernelGGL(awsem_kinetic_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, vel_, dtmp_);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(sn.ke, dtmp_, sizeof(double) * nrep_, hipMemcpyDeviceToHost, stream_));
+        if (replica >= 0) HIP_TRY(hipMemcpyAsync(sn.x1, pos_ + (size_t)replica * n3, sizeof(real) * n3, hipMemcpyDeviceToHost, stream_));
+        if (with_state) {
+            HIP_TRY(hipMemcpyAsync(sn.xs, pos_, sizeof(real) * n3 * nrep_, hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipMemcpyAsync(sn.vs, vel_, sizeof(real) * n3 * nrep_, hipMemcpyDeviceToHost, stream_));
+        }
+        HIP_TRY(hipEventRecord(sn.ev, stream_));
+        sn.busy = true;
+    }
+    void snapshot_end(int slot, double* e, double* ke, double* xyz_replica, double* xyz_all, double* v_all) override {
+        if (slot < 0 || slot > 1) throw std::string("snapshot_end: slot must be 0 or 1");
+        Snap& sn = snap_[slot];
+        if (!sn.busy) throw StateError{"snapshot_end: no snapshot was begun in this slot"};
+        if ((xyz_all || v_all) && !sn.with_state) throw StateError{"snapshot_end: the snapshot was begun without the ensemble state"};
+        if (xyz_replica && sn.replica < 0) throw StateError{"snapshot_end: the snapshot was begun without a replica's positions"};
+        HIP_TRY(hipSetDevice(device_));
+        HIP_TRY(hipEventSynchronize(sn.ev));
+        sn.busy = false;
+        const size_t n3 = (size_t)3 * natoms_;
+        if (e) for (int r = 0; r < nrep_; r++) {
+            if (sn.energy_replica >= 0 && r != sn.energy_replica) { e[r] = std::numeric_limits<double>::quiet_NaN(); continue; }
+            double s = 0;
+            if (sn.mask) for (int g = 0; g < AWSEM_NGROUPS; g++) if ((sn.mask >> g) & 1u) s += sn.e[(size_t)r * AWSEM_NGROUPS + g];
+            e[r] = s;
+        }
+        if (ke) memcpy(ke, sn.ke, sizeof(double) * nrep_);
+        if (xyz_replica) for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++) xyz_replica[3 * i + k] = (double)sn.x1[(size_t)k * natoms_ + in_(i)];
+        for (int pass = 0; pass < 2; pass++) {
+            double* dst = pass ? v_all : xyz_all;
+            const real* t = pass ? sn.vs : sn.xs;
+            if (!dst) continue;
+            for (int r = 0; r < nrep_; r++) for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++)
+                dst[r * n3 + 3 * (size_t)i + k] = (double)t[r * n3 + (size_t)k * natoms_ + in_(i)];
+        }
+    }
     void synchronize() override {
         HIP_TRY(hipSetDevice(device_));
         HIP_TRY(hipStreamSynchronize(stream_));
@@ -453,7 +534,7 @@ public:
         S.lists = (unsigned*)(base + 256);
         HIP_TRY(hipMemsetAsync(base, 0, 256, stream));   // the status word must start at zero; the lists are written before they are read
         hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep), dim3(block_), lds_eval_, stream, S, (const real*)nullptr, 0xffffffffu, 0,
-                           d_energy, (double*)nullptr, d_xyz, 0);
+                           d_energy, (double*)nullptr, d_xyz, 0, 0);
         HIP_TRY(hipGetLastError());
     }
 
@@ -2470,6 +2551,14 @@ int awsem_set_state(awsem_handle h, const double* xyz, const double* vxyz) {
 int awsem_get_state(awsem_handle h, double* xyz, double* vxyz) {
     NEED_RUN(h);
     GUARD_BEGIN h->eng->get_state_all(xyz, vxyz); return AWSEM_OK; GUARD_END
+}
+int awsem_snapshot_begin(awsem_handle h, int slot, uint32_t group_mask, int energy_replica, int replica, int with_state) {
+    NEED_RUN(h);
+    GUARD_BEGIN h->eng->snapshot_begin(slot, group_mask, energy_replica, replica, with_state); return AWSEM_OK; GUARD_END
+}
+int awsem_snapshot_end(awsem_handle h, int slot, double* e, double* ke, double* xyz_replica, double* xyz_all, double* vxyz_all) {
+    NEED_RUN(h);
+    GUARD_BEGIN h->eng->snapshot_end(slot, e, ke, xyz_replica, xyz_all, vxyz_all); return AWSEM_OK; GUARD_END
 }
 int awsem_energy_by_group(awsem_handle h, double* e) {
     NEED_RUN(h);

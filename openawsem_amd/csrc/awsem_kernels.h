@@ -1492,9 +1492,10 @@ template <bool ENERGY, class real>
 __global__ AWSEM_BOUNDS(real) void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__ pos, unsigned mask, int redistribute,
                                   double* __restrict__ e_out /* [R][32] or null */, double* __restrict__ f_out /* [R][natoms][3] or null */,
                                   const double* __restrict__ xyz_aos /* null, or [R][natoms][3] in the caller's atom order instead of `pos` */,
-                                  int reuse /* S.lists are the lists the last step launch left for these very positions: walk them instead of building */) {
+                                  int reuse /* S.lists are the lists the last step launch left for these very positions: walk them instead of building */,
+                                  int rep0 /* first replica of the launch (a grid of one workgroup evaluates one replica of the ensemble) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int natoms = S.natoms, rep = blockIdx.x;
+    const int natoms = S.natoms, rep = (int)blockIdx.x + rep0;
     Lds<real> L = carve_lds((real)0, smem, lds_shape(S), false);
     L.lists = S.lists + (size_t)rep * S.list_stride;
     if (xyz_aos) {   // uniform; awsem_energy_by_group_noalloc: the caller's device buffer, converted like the host does ((real) of the double)

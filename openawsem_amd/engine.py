@@ -10,6 +10,7 @@ engine handle (one workgroup per replica on the GPU); `Context.getState(replica=
 """
 from __future__ import annotations
 
+import os
 import sys
 import time
 
@@ -277,11 +278,19 @@ class Simulation:
         self.context = Context(system, integrator, platform, n_replicas=n_replicas)
         self.reporters = []
         self.currentStep = 0
+        # asynchronous reporting (step): two snapshot slots, one worker thread that writes in fetch order
+        import threading
+        self._async_reports = os.environ.get("AWSEM_ASYNC_REPORT", "1") != "0"
+        self._worker, self._jobs, self._worker_error, self._next_slot = None, None, None, 0
+        self._slot_free = [threading.Event() for _ in range(self._NSLOT)]
+        for ev in self._slot_free:
+            ev.set()
 
     def minimizeEnergy(self, tolerance=10.0, maxIterations=0):
         """All replicas at once on the device (FIRE, awsem_minimize) on either path; should the library report the device
         minimiser unavailable (AWSEM_ELIMIT), the host-driven L-BFGS of `minimize` takes over, one replica at a time."""
         from ._capi import AwsemError
+        self.flushReporters()
         tol = _value(tolerance, u.kilojoule_per_mole / u.nanometer)
         try:
             self.last_minimization = self.context._ctx.minimize(tol, int(maxIterations))
@@ -292,6 +301,13 @@ class Simulation:
                 minimize(self.context, tolerance, maxIterations, replica=r)
 
     def step(self, steps):
+        """simulation.step (scripts/mm_run.py:169-175): MD launches between report points.  The built-in reporters are served in two
+        halves: at a report point the values they need are FETCHED asynchronously (awsem_snapshot_begin: queued on the engine's stream
+        behind the launch, into pinned host memory), and the files are WRITTEN by a worker thread once the values have arrived -- by
+        which time this thread has long queued the next launches, so the GPU does not idle while checkpoints and frames are written
+        (the reference's OpenMM reporters run synchronously inside step).  Files are byte-identical to synchronous reporting: same
+        values, same order.  A reporter without the two halves (a user's own class with report() only) is served synchronously after
+        the pending ones have been written; AWSEM_ASYNC_REPORT=0 serves every reporter that way."""
         steps = int(steps)
         end = self.currentStep + steps
         while self.currentStep < end:
@@ -300,21 +316,102 @@ class Simulation:
                 k = rep._interval - self.currentStep % rep._interval
                 nxt = min(nxt, self.currentStep + k)
             n = nxt - self.currentStep
+            self._raise_worker_error()
             self.context._step(n)
             self.currentStep = nxt
-            for rep in self.reporters:
-                if self.currentStep % rep._interval == 0:
+            due = [rep for rep in self.reporters if self.currentStep % rep._interval == 0]
+            if not due:
+                continue
+            if self._async_reports and all(getattr(rep, "_deferred", False) for rep in due) and not isinstance(self.integrator, CustomIntegrator):
+                self._fetch(due)
+            else:
+                self.flushReporters()
+                for rep in due:
                     rep.report(self)
+
+    # ---- the two halves
+    _NSLOT = 2
+
+    def _fetch(self, due):
+        c = self.context._ctx
+        need_e = any(rep._needs().get("energy") for rep in due)
+        replicas = {rep._needs().get("positions") for rep in due} - {None}
+        with_state = any(rep._needs().get("state") for rep in due)
+        if len(replicas) > 1:   # reporters of different replicas at one step: not worth a slot each
+            self.flushReporters()
+            for rep in due:
+                rep.report(self)
+            return
+        slot = self._next_slot
+        self._next_slot = (slot + 1) % self._NSLOT
+        self._slot_free[slot].wait()          # its previous snapshot has been written (two stages ago)
+        self._raise_worker_error()
+        self._slot_free[slot].clear()
+        replica = replicas.pop() if replicas else -1
+        c.snapshot_begin(slot, 0xFFFFFFFF if need_e else 0, 0, replica, with_state)   # the built-in reporters print replica 0's energy
+        job = dict(slot=slot, due=due, need_e=need_e, replica=replica, with_state=with_state, step=self.currentStep,
+                   time_ps=self.context._time_ps, step_count=c.step_count)
+        if self._worker is None:
+            import queue
+            import threading
+            self._jobs = queue.Queue()
+            self._worker = threading.Thread(target=self._write_loop, name="awsem-reporters", daemon=True)
+            self._worker.start()
+        self._jobs.put(job)
+
+    def _write_loop(self):
+        while True:
+            job = self._jobs.get()
+            try:
+                if job is None:
+                    return
+                if self._worker_error is None:
+                    snap = self.context._ctx.snapshot_end(job["slot"], energy=job["need_e"], replica_positions=job["replica"] >= 0,
+                                                          state=job["with_state"])
+                    snap.update(step=job["step"], time_ps=job["time_ps"], step_count=job["step_count"])
+                    for rep in job["due"]:
+                        rep._write(self, snap)
+            except BaseException as err:   # handed to the thread that drives the simulation
+                self._worker_error = err
+            finally:
+                if job is not None:
+                    self._slot_free[job["slot"]].set()
+                self._jobs.task_done()
+
+    def _raise_worker_error(self):
+        if self._worker_error is not None:
+            err, self._worker_error = self._worker_error, None
+            raise err
+
+    def flushReporters(self):
+        """Wait until every report fetched so far is on disk (called by everything that reads or changes the state; call it yourself
+        before reading the output files of a run that is still alive)."""
+        if self._worker is not None:
+            self._jobs.join()
+        self._raise_worker_error()
+
+    def __del__(self):
+        try:
+            if self._worker is not None:
+                self._jobs.join()
+                self._jobs.put(None)
+        except Exception:
+            pass
 
     # own checkpoint format (OpenMM's is a platform-specific binary blob): a magic line, then four arrays in numpy's .npy framing, one
     # after the other.  (A .npz archive costs a CRC-32 pass over the 18 MB of a 1024-replica state per checkpoint -- a quarter of the
     # wall time of a default annealing run; archives written by earlier versions still load.)
     _CKP_MAGIC = b"AWSEMCKP1\n"
 
-    def saveCheckpoint(self, file):
+    def saveCheckpoint(self, file, _snap=None):
         c = self.context._ctx
-        x, v = c.get_state()
-        arrays = (x, v, np.array([self.currentStep, c.step_count], dtype=np.int64), np.array([self.context._time_ps]))
+        if _snap is None:
+            self.flushReporters()
+            x, v = c.get_state()
+            arrays = (x, v, np.array([self.currentStep, c.step_count], dtype=np.int64), np.array([self.context._time_ps]))
+        else:   # the write half of CheckpointReporter: everything was captured when the snapshot was fetched
+            x, v = _snap["state"]
+            arrays = (x, v, np.array([_snap["step"], _snap["step_count"]], dtype=np.int64), np.array([_snap["time_ps"]]))
 
         def write(fh):
             fh.write(self._CKP_MAGIC)
@@ -327,6 +424,7 @@ class Simulation:
             write(file)
 
     def loadCheckpoint(self, file):
+        self.flushReporters()
         fh = open(file, "rb") if isinstance(file, str) else file
         try:
             head = fh.read(len(self._CKP_MAGIC))
@@ -367,19 +465,29 @@ class StateDataReporter(_Reporter):
                           totalEnergy=totalEnergy, temperature=temperature)
         self._sep, self._header = separator, False
 
+    _deferred = True
+
+    def _needs(self):
+        return {"energy": self._cols["potentialEnergy"] or self._cols["totalEnergy"]}
+
     def report(self, simulation, state=None):
+        simulation.flushReporters()
         ctx = simulation.context
+        need_e = self._needs()["energy"]
+        self._write(simulation, {"step": simulation.currentStep, "time_ps": ctx._time_ps, "energy": ctx.energies() if need_e else None,
+                                 "kinetic": ctx.kineticEnergies()})
+
+    def _write(self, simulation, snap):
         names = {"step": "Step", "time": "Time (ps)", "potentialEnergy": "Potential Energy (kJ/mole)",
                  "kineticEnergy": "Kinetic Energy (kJ/mole)", "totalEnergy": "Total Energy (kJ/mole)", "temperature": "Temperature (K)"}
         if not self._header:
             print('#"' + (f'"{self._sep}"').join(names[k] for k, on in self._cols.items() if on) + '"', file=self._out)
             self._header = True
-        need_e = self._cols["potentialEnergy"] or self._cols["totalEnergy"]
-        pe = float(ctx.energies()[0]) if need_e else 0.0
-        ke = float(ctx.kineticEnergies()[0])
+        pe = float(snap["energy"][0]) if snap["energy"] is not None else 0.0
+        ke = float(snap["kinetic"][0])
         # OpenMM's StateDataReporter: 3 per massive particle, minus 3 when the System has a CMMotionRemover
         dof = 3 * int((simulation.system.masses > 0).sum()) - (3 if getattr(simulation.system, "remove_cm_motion", False) else 0)
-        vals = {"step": simulation.currentStep, "time": ctx._time_ps, "potentialEnergy": pe, "kineticEnergy": ke,
+        vals = {"step": snap["step"], "time": snap["time_ps"], "potentialEnergy": pe, "kineticEnergy": ke,
                 "totalEnergy": pe + ke, "temperature": 2 * ke / (dof * KB)}
         print(self._sep.join(str(vals[k]) for k, on in self._cols.items() if on), file=self._out)
         self._out.flush()
@@ -396,11 +504,20 @@ class DCDReporter(_Reporter):
         super().__init__(reportInterval)
         self._file, self._append, self._writer, self._replica = file, append, None, replica
 
+    _deferred = True
+
+    def _needs(self):
+        return {"positions": self._replica}
+
     def report(self, simulation, state=None):
+        simulation.flushReporters()
+        self._write(simulation, {"positions": simulation.context._ctx.get_positions(self._replica)})
+
+    def _write(self, simulation, snap):
         if self._writer is None:
             self._writer = DCDWriter(self._file, simulation.system.getNumParticles(), append=self._append,
                                      dt_ps=_value(simulation.integrator.getStepSize(), u.picosecond), interval=self._interval)
-        self._writer.write(simulation.context._ctx.get_positions(self._replica))
+        self._writer.write(snap["positions"])
 
 
 class PDBReporter(_Reporter):
@@ -410,9 +527,18 @@ class PDBReporter(_Reporter):
         super().__init__(reportInterval)
         self._out, self._model, self._replica = open(file, "w"), 0, replica
 
+    _deferred = True
+
+    def _needs(self):
+        return {"positions": self._replica}
+
     def report(self, simulation, state=None):
+        simulation.flushReporters()
+        self._write(simulation, {"positions": simulation.context._ctx.get_positions(self._replica)})
+
+    def _write(self, simulation, snap):
         self._model += 1
-        x = simulation.context._ctx.get_positions(self._replica) * 10.0
+        x = snap["positions"] * 10.0
         print(f"MODEL     {self._model:4d}", file=self._out)
         for a in simulation.topology.atoms():
             r = a.residue
@@ -429,8 +555,16 @@ class CheckpointReporter(_Reporter):
         super().__init__(reportInterval)
         self._file = file
 
+    _deferred = True
+
+    def _needs(self):
+        return {"state": True}
+
     def report(self, simulation, state=None):
         simulation.saveCheckpoint(self._file)
+
+    def _write(self, simulation, snap):
+        simulation.saveCheckpoint(self._file, _snap=snap)
 
 
 stdout = sys.stdout

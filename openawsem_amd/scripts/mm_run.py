@@ -105,6 +105,7 @@ def run(args):
         for i in range(snapShotCount):
             integrator.setTemperature((Tstart + deltaT * i) * kelvin)
             simulation.step(stepsPerT)
+    simulation.flushReporters()            # the reporters' files are complete (they are written behind the launches: engine.Simulation.step)
     simulation.context._ctx.synchronize()
     time_taken = time.time() - start_time
     hours, rest = divmod(time_taken, 3600)

@@ -18,5 +18,7 @@ with contextlib.redirect_stdout(io.StringIO()):
     sim = mm_run.main(["1r69", "--to", os.path.join(tmp, "run0"), "-s", "20000", "--replicas", str(R), "--seed", "7",
                        "-f", os.path.join(os.path.dirname(mm_run.__file__), "forces_setup.py")])
 dt = time.time() - t0
+loop = float(open(os.path.join(tmp, "run0", "time.dat")).read())
+print(f"  of which the annealing loop (time.dat): {loop:.3f} s; set-up, minimisation, first frames, final files: {dt - loop:.3f} s")
 print(f"awsem_run 1r69 x {R} replicas, 20000 steps, 400 stages: {dt:.2f} s wall -> {R * 20000 / dt / 1e6:.2f} M replica-steps/s end to end")
 shutil.rmtree(tmp)

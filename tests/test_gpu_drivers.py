@@ -152,6 +152,34 @@ def test_awsem_run_anneals_an_ensemble_and_writes_the_reference_files(tmp_path, 
     assert sim2.currentStep == 2000 + 400
 
 
+def test_reports_written_behind_the_launches_are_byte_identical(tmp_path, monkeypatch):
+    """engine.Simulation.step serves the built-in reporters in two halves -- values fetched asynchronously behind the launch
+    (awsem_snapshot_begin, pinned host memory), files written by a worker thread after the next launches have been queued -- where the
+    reference's OpenMM reporters run synchronously inside simulation.step (scripts/mm_run.py:157-175).  Same values, same order: every
+    file of a run must equal, byte for byte, what AWSEM_ASYNC_REPORT=0 (synchronous reporting) writes."""
+    from openawsem_amd.scripts import mm_run
+    d = tmp_path / "1r69"
+    shutil.copytree(data_path.data / "1r69", d, ignore=shutil.ignore_patterns("fraglib", "frags.mem"))
+    shutil.copy(d / "1r69.fasta", d / "crystal_structure.fasta")
+    seq = "".join(ln.strip() for ln in open(d / "1r69.fasta") if not ln.startswith(">"))
+    (d / "charge.txt").write_text("".join(f"{i} {1.0 if a in 'RK' else (-1.0 if a in 'DE' else 0.0)}\n" for i, a in enumerate(seq)))
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AWSEM_ASYNC_REPORT", mode)
+        monkeypatch.chdir(d)
+        out = tmp_path / f"run_async{mode}"
+        sim = mm_run.main(["1r69", "--to", str(out), "-s", "4000", "--tempStart", "700", "--tempEnd", "300", "--replicas", "16", "--seed", "11",
+                           "-f", os.path.join(os.path.dirname(mm_run.__file__), "forces_setup.py")])
+        assert (sim._worker is not None) == (mode == "1")
+        outs.append(out)
+    monkeypatch.delenv("AWSEM_ASYNC_REPORT", raising=False)
+    for f in ("native.pdb", "movie.dcd", "output.log", "checkpnt.chk"):
+        a, b = (outs[0] / f).read_bytes(), (outs[1] / f).read_bytes()
+        assert len(a) > 100 and a == b, f
+    with np.load(outs[0] / "ensemble_final.npz") as za, np.load(outs[1] / "ensemble_final.npz") as zb:
+        assert np.array_equal(za["positions"], zb["positions"]) and np.array_equal(za["energies"], zb["energies"])
+
+
 def test_awsem_remd_runs_a_ladder_and_restarts(tmp_path, monkeypatch):
     """mm_remd.py of the reference delegates to openmmtools (absent here; its output.nc is not reproduced): outputs are
     checked for shape, label bookkeeping and restart ("parity unpinned"; the Metropolis rule itself is tested in test_ensemble.py)."""
