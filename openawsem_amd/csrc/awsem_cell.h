@@ -63,6 +63,12 @@ template <class real> struct CellSys {
     int* status;                // bit 1: neighbour row overflow
     u64* cm;                    // [2][R][nblk_int][3] per-workgroup momentum sums of the integrator (Q31.32), by step parity (CMMotionRemover)
     int nblk_int;               // workgroups per replica of the integrator's grid
+    // round 3: the step as five launches.  The integrator also does the next step's "pre" work (member records,
+    // displacement flag, bounding box), the window kernel places the virtual sites it stages, and ONE launch rebuilds the lists.
+    const int* member_of[2];    // [natoms] atom -> member of bin 0 / bin 1, -1 if none
+    const int* vs_of;           // [natoms] atom -> index into DevSys::vs, -1 if not a virtual site
+    int nblk_box;               // bounding boxes kept per replica: max(nblk_pre, nblk_int); unused ones stay neutral
+    unsigned* bar;              // [R][2][4] arrival counters of the rebuild kernel's grid barriers, per (replica, bin)
 };
 
 __device__ __forceinline__ int ordered_int(float f) { int o = __float_as_int(f); return o >= 0 ? o : o ^ 0x7fffffff; }
@@ -151,7 +157,7 @@ template <bool STEP, class real> __global__ void cell_pre_kernel(DevSys<real> S,
         }
     }
     __syncthreads();
-    int* bb = C.bbox + ((size_t)rep * C.nblk_pre + blockIdx.x) * 8;   // read by cell_geom_kernel of this step only
+    int* bb = C.bbox + ((size_t)rep * C.nblk_box + blockIdx.x) * 8;   // read by the geometry pass of this step only
     if (threadIdx.x < 3) { bb[threadIdx.x] = slo[threadIdx.x]; bb[4 + threadIdx.x] = shi[threadIdx.x]; }
     if (blockIdx.x == 0 && threadIdx.x == 0) C.flag[2 * rep + (cur ^ 1)] = 0;   // nobody reads or writes the other flag during this step
     if (blockIdx.x == 0 && (int)threadIdx.x < C.n_cv) C.cv[(size_t)rep * C.n_cv + threadIdx.x] = 0;
@@ -172,8 +178,8 @@ template <class real> __global__ void cell_geom_kernel(CellSys<real> C, int cur,
     __syncthreads();
     for (int k = 0; k < 3; k++) {
         int lo = 0x7fffffff, hi = (int)0x80000000;
-        for (int w = threadIdx.x; w < C.nblk_pre; w += blockDim.x) {
-            const int* bb = C.bbox + ((size_t)rep * C.nblk_pre + w) * 8;
+        for (int w = threadIdx.x; w < C.nblk_box; w += blockDim.x) {
+            const int* bb = C.bbox + ((size_t)rep * C.nblk_box + w) * 8;
             lo = min(lo, bb[k]); hi = max(hi, bb[4 + k]);
         }
         for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off)); hi = max(hi, __shfl_down(hi, off)); }
@@ -279,16 +285,23 @@ template <class real> __global__ void cell_fill_kernel(CellSys<real> C, int cur,
     }
 }
 
+// restores the invariant (zero counts) for the next sort; called by whoever builds the rows of (rep, bin) -- nobody reads the counts then
+template <class real> __device__ __forceinline__ void cell_zero_counts(const CellSys<real>& C, int rep, int b, int bx, int nbx) {
+    const CellBin<real>& B = C.bin[b];
+    const int ncell = B.dims[4 * rep + 3];
+    int* cnt = B.cell_count + (size_t)rep * AWSEM_CELL_MAXCELLS;
+    for (int c = bx * (int)blockDim.x + (int)threadIdx.x; c < ncell; c += nbx * (int)blockDim.x) cnt[c] = 0;
+    if (bx == 0) for (int t = threadIdx.x; t < AWSEM_CELL_MAXCELLS / 1024; t += blockDim.x) B.tile_sum[(size_t)rep * (AWSEM_CELL_MAXCELLS / 1024) + t] = 0;
+}
+
 // Neighbour rows.  16 lanes per member (members taken in cell order, so a wave works on four neighbours in space):
 // the 27 cells around the member are 9 runs of 3 consecutive cells in the sorted member array; the 16 lanes test 16
 // candidates at a time and the passing ones are compacted into the member's row with a ballot -- the row count is a
 // register of the row, no atomics.  blockIdx.y = 2 * rep + bin.
 //   bin 0 (contact): entry = site_j | in_density << 30 | has_pair_energy << 31
 //   bin 1 (excl):    entry = member_j   (same class, not an excluded partner)
-template <class real> __global__ void cell_rows_kernel(DevSys<real> S, CellSys<real> C, int cur, int force) {
-    const int rep = blockIdx.y >> 1, b = blockIdx.y & 1;
+template <class real> __device__ __forceinline__ void cell_rows_body(const DevSys<real>& S, const CellSys<real>& C, int rep, int b, int bx, int nbx) {
     const CellBin<real>& B = C.bin[b];
-    if (!cell_rebuild(C, rep, cur, force)) return;
     const Rec<real>* rec = (const Rec<real>*)B.rec + (size_t)rep * B.n;
     const int* sorted = B.sorted + (size_t)rep * B.n;
     const int* cstart = B.cell_start + (size_t)rep * (AWSEM_CELL_MAXCELLS + 1);
@@ -296,7 +309,7 @@ template <class real> __global__ void cell_rows_kernel(DevSys<real> S, CellSys<r
     const int nx = B.dims[4 * rep], ny = B.dims[4 * rep + 1], nz = B.dims[4 * rep + 2];
     const int sub = threadIdx.x & (AWSEM_ROW - 1), row_in_wave = (threadIdx.x & 63) / AWSEM_ROW;
     const int nrows_total = (B.n + 3) & ~3;   // whole waves: the ballots are wave collectives
-    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows_total; k += gridDim.x * blockDim.x / AWSEM_ROW) {
+    for (int k = (bx * (int)blockDim.x + (int)threadIdx.x) / AWSEM_ROW; k < nrows_total; k += nbx * (int)blockDim.x / AWSEM_ROW) {
         const bool vi = k < B.n;
         const int i = vi ? sorted[k] : 0;
         const Rec<real> ri = rec[i];
@@ -345,6 +358,12 @@ template <class real> __global__ void cell_rows_kernel(DevSys<real> S, CellSys<r
         if (vi && sub == 0) B.row_count[(size_t)rep * B.n + i] = min(cnt, B.stride);
     }
 }
+template <class real> __global__ void cell_rows_kernel(DevSys<real> S, CellSys<real> C, int cur, int force) {
+    const int rep = blockIdx.y >> 1, b = blockIdx.y & 1;
+    if (!cell_rebuild(C, rep, cur, force)) return;
+    cell_zero_counts(C, rep, b, (int)blockIdx.x, (int)gridDim.x);
+    cell_rows_body(S, C, rep, b, (int)blockIdx.x, (int)gridDim.x);
+}
 
 // ------------------------------------------------------------------ evaluation from the rows (grid (blocks, R))
 // The leader of a row adds the row's force to the owner's accumulator: a plain read-modify-write, because within one
@@ -357,20 +376,95 @@ template <class real> __device__ __forceinline__ void owner_add_force(const Cell
     const int nrows_ = ((B).n + 3) & ~3;                                                                                  \
     for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows_; k += gridDim.x * blockDim.x / AWSEM_ROW)
 
+// Bonded terms, window by window: a workgroup stages the positions of AWSEM_WIN_SPAN consecutive atoms in LDS, runs
+// every item whose lowest atom lies in its window (the item lists are sorted by window at finalize) with LDS
+// accumulators, and flushes the touched atoms with one global atomic per component -- a fifth of the global atomics of
+// the item-by-item kernel above, which keeps the items that do not fit a window.
+// wstart[slot][w]: first item of window w in the slot's term; slots run over harm, chi, rama, helical, fm, memb.
+template <class real> struct WinView : ViewCommon<real>, SoaOps<real> { typedef real real_t; };
+// VS (dynamics, round 3): the window PLACES the virtual sites among the atoms it stages, from the parents' coordinates in global memory
+// (massive particles, final since the integrator), and stores those of its own 512 atoms back for the kernels that follow -- the
+// separate virtual-site pass of the pre kernel is gone.  Sites in the forward half window are recomputed by the next window as well:
+// the same three products in the same order, the same bits.
+// Dynamics (round 3) runs the windows as extra workgroups of cell_density_excl_kernel: the bonded terms need nothing from the contact
+// passes and the contact passes nothing from them, so the two share a launch.
+template <bool ENERGY, bool VS, class real> __device__ void cell_window_body(const DevSys<real>& S, const CellSys<real>& C, real* __restrict__ pos, const int* __restrict__ wstart, int nwin, unsigned mask, int rep, int w) {
+    __shared__ real sp[3][AWSEM_WIN_SPAN];
+    __shared__ u64 sf[3][AWSEM_WIN_SPAN];
+    const int n = C.natoms;
+    const int a0 = w * AWSEM_WIN, na = min(AWSEM_WIN_SPAN, n - a0);
+    real* p = pos + (size_t)rep * 3 * n;
+    for (int i = threadIdx.x; i < na; i += blockDim.x) {
+        const int t = VS ? C.vs_of[a0 + i] : -1;
+        if (t >= 0) {
+            const Int4 v = S.vs[t];
+            const real w0 = S.vs_w[3 * t], w1 = S.vs_w[3 * t + 1], w2 = S.vs_w[3 * t + 2];
+            for (int k = 0; k < 3; k++) {
+                const real x = w0 * p[(size_t)k * n + v.y] + w1 * p[(size_t)k * n + v.z] + w2 * p[(size_t)k * n + v.w];
+                sp[k][i] = x; sf[k][i] = 0;
+                if (i < AWSEM_WIN) p[(size_t)k * n + a0 + i] = x;
+            }
+        } else
+            for (int k = 0; k < 3; k++) { sp[k][i] = p[(size_t)k * n + a0 + i]; sf[k][i] = 0; }
+    }
+    WinView<real> L;
+    L.nthr = blockDim.x; L.ramap = nullptr;
+    L.px = &sp[0][0] - a0; L.py = &sp[1][0] - a0; L.pz = &sp[2][0] - a0;
+    L.fx = &sf[0][0] - a0; L.fy = &sf[1][0] - a0; L.fz = &sf[2][0] - a0;
+    L.rho = L.drho = nullptr; L.rhov = L.alpha = L.dalpha = L.gamma = nullptr; L.satom = nullptr; L.cv = nullptr;
+    L.lcount = nullptr; L.flag = nullptr; L.lists = nullptr;
+    L.eg = C.eg + (size_t)rep * AWSEM_NGROUPS;
+    __syncthreads();
+    const int* ws = wstart + w;
+    const int stride = nwin + 1;
+    for (int t = 0; t < S.n_harm; t++, ws += stride) { HarmD<real> d = S.harm[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.items += ws[0]; d.n = ws[1] - ws[0]; term_harmonic<ENERGY>(d, L); }
+    for (int t = 0; t < S.n_chi; t++, ws += stride) { ChiD<real> d = S.chi[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.atoms += ws[0]; d.n = ws[1] - ws[0]; term_chi<ENERGY>(d, L); }
+    for (int t = 0; t < S.n_rama; t++, ws += stride) { RamaD<real> d = S.rama[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.atoms += ws[0]; d.bw += (size_t)ws[0] * d.nwell; d.n = ws[1] - ws[0]; term_rama<ENERGY>(d, L); }
+    for (int t = 0; t < S.n_helical; t++, ws += stride) { HelicalD<real> d = S.helical[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.items += ws[0]; if (d.zitems) d.zitems += ws[0]; d.n = ws[1] - ws[0]; term_helical<ENERGY>(d, L); }
+    for (int t = 0; t < S.n_fm; t++, ws += stride) { FmD<real> d = S.fm[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.pairs2 += 2 * (size_t)ws[0]; d.table2 += (size_t)ws[0] * (d.ntab - 1); d.n = ws[1] - ws[0]; term_fm<ENERGY, false>(d, L); }
+    for (int t = 0; t < S.n_memb; t++, ws += stride) { MembD<real> d = S.memb[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.items += ws[0]; d.n = ws[1] - ws[0]; term_memb<ENERGY>(d, L); }
+    __syncthreads();
+    u64* f = C.f + (size_t)rep * 3 * n;
+    for (int i = threadIdx.x; i < na; i += blockDim.x)
+        for (int k = 0; k < 3; k++) { const u64 v = sf[k][i]; if (v) fixed_add(&f[(size_t)k * n + a0 + i], v); }
+}
+
+template <bool ENERGY, bool VS, class real> __global__ __launch_bounds__(256) void cell_window_kernel(DevSys<real> S, CellSys<real> C, real* __restrict__ pos, const int* __restrict__ wstart, int nwin, unsigned mask) {
+    cell_window_body<ENERGY, VS>(S, C, pos, wstart, nwin, mask, (int)blockIdx.y, (int)blockIdx.x);
+}
+
 // pass 1: rho_i, then the per-site pass (burial wells, water switch, dE/drho seed) by the row leader;
 // blocks from `nb_contact` on evaluate the excluded volume (its rows live in bin 1).
-template <bool ENERGY, class real> __global__ void cell_density_excl_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos, int nb_contact, unsigned mask) {
+// rows_cur >= 0 (dynamics, round 3): when the replica's flag is set, every 16-lane group first BUILDS the rows it is about to walk (the
+// sort ran in the launch before); the same mapping of groups to rows serves both loops.
+// WIN (dynamics): blocks from nb_contact + nb_excl on are the windows of the bonded terms (cell_window_body: places the virtual sites); the
+// excluded-volume leaders then add with atomics, because a window may be adding to the same atom.
+template <bool ENERGY, bool WIN, class real> __global__ __launch_bounds__(256) void cell_density_excl_kernel(DevSys<real> S, CellSys<real> C, real* __restrict__ pos, int nb_contact, int nb_excl, unsigned mask,
+                                                                            int rows_cur, int rows_force, const int* __restrict__ wstart, int nwin) {
     const int rep = blockIdx.y;
+    // the windows take the FIRST block indices: theirs is the longest chain of dependent loads in this launch, so they start at once and
+    // the row walks fill in around them (dispatched last they ran after everybody else: measured, 28.6 us against 17.3 + 11)
+    if (WIN && (int)blockIdx.x < nwin) {
+        cell_window_body<ENERGY, true>(S, C, pos, wstart, nwin, mask, rep, (int)blockIdx.x);
+        return;
+    }
+    const int bx = (int)blockIdx.x - (WIN ? nwin : 0);
     const CellView<real> L = cell_view(S, C, pos, rep);
     Energy en;
-    if ((int)blockIdx.x < nb_contact) {
+    const bool build = rows_cur >= 0 && cell_rebuild(C, rep, rows_cur, rows_force);   // uniform over the replica
+    if (bx < nb_contact) {
         const ContactD<real>& d = S.contact[0];
         const CellBin<real>& B = C.bin[0];
+        if (build) {
+            cell_zero_counts(C, rep, 0, bx, nb_contact);
+            cell_rows_body(S, C, rep, 0, bx, nb_contact);
+            __syncthreads();   // the rows and their counts are read back by other lanes of the group
+        }
         const Rec<real>* rec = (const Rec<real>*)B.rec + (size_t)rep * B.n;
         const int* sorted = B.sorted + (size_t)rep * B.n;
         const unsigned* rows = B.rows + (size_t)rep * B.n * B.stride;
         const int sub = threadIdx.x & (AWSEM_ROW - 1), nrows = (B.n + 3) & ~3;
-        for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows; k += nb_contact * blockDim.x / AWSEM_ROW) {
+        for (int k = (bx * (int)blockDim.x + (int)threadIdx.x) / AWSEM_ROW; k < nrows; k += nb_contact * (int)blockDim.x / AWSEM_ROW) {
             const bool vi = k < B.n;
             const int i = vi ? sorted[k] : 0;
             const Rec<real> ri = rec[i];
@@ -396,12 +490,17 @@ template <bool ENERGY, class real> __global__ void cell_density_excl_kernel(DevS
         const ExclD<real>& d = S.excl[0];
         if (!AWSEM_ON(d)) return;
         const CellBin<real>& B = C.bin[1];
+        if (build) {
+            cell_zero_counts(C, rep, 1, bx - nb_contact, nb_excl);
+            cell_rows_body(S, C, rep, 1, bx - nb_contact, nb_excl);
+            __syncthreads();
+        }
         const Rec<real>* rec = (const Rec<real>*)B.rec + (size_t)rep * B.n;
         const int* sorted = B.sorted + (size_t)rep * B.n;
         const unsigned* rows = B.rows + (size_t)rep * B.n * B.stride;
-        const int sub = threadIdx.x & (AWSEM_ROW - 1), nrows = (B.n + 3) & ~3, nb = gridDim.x - nb_contact;
+        const int sub = threadIdx.x & (AWSEM_ROW - 1), nrows = (B.n + 3) & ~3, nb = nb_excl;
         const real r02 = d.r0 * d.r0;
-        for (int k = ((blockIdx.x - nb_contact) * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows; k += nb * blockDim.x / AWSEM_ROW) {
+        for (int k = ((bx - nb_contact) * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows; k += nb * blockDim.x / AWSEM_ROW) {
             const bool vi = k < B.n;
             const int i = vi ? sorted[k] : 0;
             const Rec<real> ri = rec[i];
@@ -419,7 +518,11 @@ template <bool ENERGY, class real> __global__ void cell_density_excl_kernel(DevS
             }
             if (__ballot((X | Y | Z) != 0) == 0) continue;   // clashes are rare
             X = row_sum(X); Y = row_sum(Y); Z = row_sum(Z);
-            if (vi && sub == 0 && (X | Y | Z) != 0) owner_add_force(L, tag_bits(ri.tag), X, Y, Z);
+            if (vi && sub == 0 && (X | Y | Z) != 0) {
+                const int a = tag_bits(ri.tag);
+                if (WIN) { fixed_add(&L.fx[a], X); fixed_add(&L.fy[a], Y); fixed_add(&L.fz[a], Z); }
+                else owner_add_force(L, a, X, Y, Z);
+            }
         }
         flush_energy<ENERGY>(L, d.group, en);
     }
@@ -584,6 +687,153 @@ template <class real> __global__ void cell_hb_rows_kernel(HbTerms<real> T, CellS
     else { const PapD<real> d = T.pap[t - T.n_beta]; hb_rows_body(d, C, H, pos, rc2, rep); }
 }
 
+// ------------------------------------------------------------------ the rebuild without launches of its own (round 3)
+// The five kernels above cost a launch each on every step although they exit at once on all but one step in twenty or more.  Now:
+//   * SORT (geometry -> count -> scan -> fill) is the work of G = 32 small workgroups per (replica, bin) that synchronise among
+//     themselves with three grid barriers of their own (cell_grid_barrier: arrival counters in device memory, agent-scope fences;
+//     a wait is BOUNDED -- after ~1 s bit 3 of the status word is set, every later phase is skipped and the next synchronisation
+//     raises: a hang is impossible).  They ride along as extra workgroups of the window kernel (cell_window_kernel; a launch of their own,
+//     cell_sort_kernel, where there is no window kernel) and leave at once unless the replica's flag is set.  (All workgroups of one
+//     launch doing all four phases was measured first: with 768 workgroups per group a barrier costs ~280 us -- same-address arrivals
+//     serialise at ~0.1 us each and the pollers crowd them out; with 32 it is a few us.)
+//   * ROWS are per owner and need nothing but the sorted arrays: the 16 lanes that are about to walk row i in the density pass (the
+//     excluded-volume pass, the hydrogen-bond pass) build it first when the flag is set -- full occupancy, no launch.
+// Invariant between rebuilds: cell_count[0 .. ncell) and tile_sum are zero (set at allocation, restored by whoever builds the rows).
+#define AWSEM_BAR_SPINS (1u << 20)
+#define AWSEM_SORT_G 32
+__device__ __forceinline__ bool cell_grid_barrier(unsigned* counter, unsigned nwg, unsigned* reset, int* status, int* sh_ok) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every wave: its stores are visible device-wide before the arrival
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nwg) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > AWSEM_BAR_SPINS) { ok = 0; atomicOr(status, 8); break; }
+        }
+        *sh_ok = ok;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every wave: no stale lines of what the others wrote
+    // everyone has passed the PREVIOUS barrier (they all arrived at this one): its counter goes back to zero
+    if (*sh_ok && reset && threadIdx.x == 0) __hip_atomic_store(reset, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *sh_ok != 0;
+}
+template <class real> struct CellGeo { real lo[3], inv; int nd[3], ncell; };
+template <class real> __device__ __forceinline__ void cell_coords_geo(const CellGeo<real>& g, real x, real y, real z, int c[3]) {
+    const real v[3] = {x, y, z};
+    for (int k = 0; k < 3; k++) {
+        int t = (int)M<real>::floor((v[k] - g.lo[k]) * g.inv);
+        c[k] = t < 0 ? 0 : (t >= g.nd[k] ? g.nd[k] - 1 : t);
+    }
+}
+// workgroup g of G (256 threads each) of the group (rep, bin b); every workgroup of the group must call it (grid barriers)
+template <class real> __device__ void cell_sort_body(const CellSys<real>& C, const real* __restrict__ pos, int rep, int b, int g, int G, int cur, int force) {
+    const int n = C.natoms;
+    const CellBin<real>& B = C.bin[b];
+    if (B.n == 0 || !cell_rebuild(C, rep, cur, force)) return;
+    unsigned* bar = C.bar + ((size_t)rep * 2 + b) * 4;
+    __shared__ int slo[3], shi[3], sh_ok, sh_base;
+    __shared__ int hist[AWSEM_CELL_MAXCELLS / 1024];
+    __shared__ int wsum[4];
+    __shared__ CellGeo<real> geo;
+    // ---- geometry: every workgroup works it out for itself from the per-workgroup boxes (a few KB out of L2)
+    if (threadIdx.x < 3) { slo[threadIdx.x] = 0x7fffffff; shi[threadIdx.x] = (int)0x80000000; }
+    for (int t = threadIdx.x; t < AWSEM_CELL_MAXCELLS / 1024; t += blockDim.x) hist[t] = 0;
+    __syncthreads();
+    for (int k = 0; k < 3; k++) {
+        int lo = 0x7fffffff, hi = (int)0x80000000;
+        for (int w = threadIdx.x; w < C.nblk_box; w += blockDim.x) {
+            const int* bb = C.bbox + ((size_t)rep * C.nblk_box + w) * 8;
+            lo = min(lo, bb[k]); hi = max(hi, bb[4 + k]);
+        }
+        for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off)); hi = max(hi, __shfl_down(hi, off)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&slo[k], lo); atomicMax(&shi[k], hi); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {   // the arithmetic of cell_geom_kernel
+        float lo[3], ext = 0;
+        for (int k = 0; k < 3; k++) { lo[k] = ordered_float(slo[k]) - 1e-3f; ext = fmaxf(ext, ordered_float(shi[k]) + 1e-3f - lo[k]); }
+        const float edge = fmaxf((float)B.edge_min, ext / (float)AWSEM_CELL_MAXDIM * 1.0001f);
+        for (int k = 0; k < 3; k++) {
+            int nd = (int)floorf((ordered_float(shi[k]) + 1e-3f - lo[k]) / edge) + 1;
+            geo.nd[k] = nd > AWSEM_CELL_MAXDIM ? AWSEM_CELL_MAXDIM : nd;
+            geo.lo[k] = (real)lo[k];
+        }
+        geo.inv = (real)(1.0f / edge);
+        geo.ncell = geo.nd[0] * geo.nd[1] * geo.nd[2];
+        if (g == 0) {
+            for (int k = 0; k < 3; k++) { B.grid[4 * rep + k] = geo.lo[k]; B.dims[4 * rep + k] = geo.nd[k]; }
+            B.grid[4 * rep + 3] = geo.inv; B.dims[4 * rep + 3] = geo.ncell;
+        }
+    }
+    __syncthreads();
+    const int ncell = geo.ncell, nx = geo.nd[0], ny = geo.nd[1];
+    int* cnt = B.cell_count + (size_t)rep * AWSEM_CELL_MAXCELLS;
+    int* start = B.cell_start + (size_t)rep * (AWSEM_CELL_MAXCELLS + 1);
+    int* ts = B.tile_sum + (size_t)rep * (AWSEM_CELL_MAXCELLS / 1024);
+    // ---- count: cell of every member, cell and tile populations, new reference positions
+    {
+        const real* p = pos + (size_t)rep * 3 * n;
+        real* q = C.ref + (size_t)rep * 3 * n;
+        for (int m = g * blockDim.x + threadIdx.x; m < B.n; m += G * blockDim.x) {
+            const int a = B.atom[m];
+            const real x = p[a], y = p[n + a], z = p[2 * (size_t)n + a];
+            q[a] = x; q[n + a] = y; q[2 * (size_t)n + a] = z;
+            int c[3];
+            cell_coords_geo(geo, x, y, z, c);
+            const int cell = (c[2] * ny + c[1]) * nx + c[0];
+            B.cell_of[(size_t)rep * B.n + m] = cell;
+            atomicAdd(&cnt[cell], 1);
+            atomicAdd(&hist[cell >> 10], 1);
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < AWSEM_CELL_MAXCELLS / 1024; t += blockDim.x) if (hist[t]) atomicAdd(&ts[t], hist[t]);
+    }
+    if (!cell_grid_barrier(&bar[0], (unsigned)G, &bar[2], C.status, &sh_ok)) return;
+    // ---- scan: exclusive prefix of the cell populations, a tile of 1024 cells at a time (four cells per thread); the counts go
+    // back to zero for the fill pass
+    for (int tile = g; tile * 1024 < ncell; tile += G) {
+        if (threadIdx.x == 0) sh_base = 0;
+        __syncthreads();
+        int before = (int)threadIdx.x < tile ? ts[threadIdx.x] : 0;   // at most 256 tiles
+        for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+        if ((threadIdx.x & 63) == 0 && before) atomicAdd(&sh_base, before);
+        const int c0 = tile * 1024 + 4 * threadIdx.x;
+        int v[4], mine = 0;
+        for (int u = 0; u < 4; u++) { v[u] = c0 + u < ncell ? cnt[c0 + u] : 0; mine += v[u]; }
+        int incl = mine;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int run = sh_base + incl - mine;
+        for (int w = 0; w < wave; w++) run += wsum[w];
+        for (int u = 0; u < 4; u++) {
+            if (c0 + u < ncell) { start[c0 + u] = run; cnt[c0 + u] = 0; }
+            run += v[u];
+            if (c0 + u == ncell - 1) start[ncell] = run;
+        }
+        __syncthreads();
+    }
+    if (!cell_grid_barrier(&bar[1], (unsigned)G, &bar[0], C.status, &sh_ok)) return;
+    // ---- fill: members into cell order
+    for (int m = g * blockDim.x + threadIdx.x; m < B.n; m += G * blockDim.x) {
+        const int cell = B.cell_of[(size_t)rep * B.n + m];
+        B.sorted[(size_t)rep * B.n + start[cell] + atomicAdd(&cnt[cell], 1)] = m;
+    }
+    // Nobody waits for the fill (the kernel boundary orders the rows after it); the third counter only closes the cycle of counter
+    // resets: whoever arrives LAST knows that everyone has passed barrier 1 and puts its counter back to zero.  (Counter 2 itself
+    // goes back to zero behind barrier 0 of the next rebuild.)
+    __syncthreads();
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(&bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)G - 1u)
+        __hip_atomic_store(&bar[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// grid (AWSEM_SORT_G, 2 R): the sort as a launch of its own (systems without window-local bonded terms; the evaluation API)
+template <class real> __global__ __launch_bounds__(256) void cell_sort_kernel(CellSys<real> C, const real* __restrict__ pos, int cur, int force) {
+    cell_sort_body(C, pos, (int)blockIdx.y >> 1, (int)blockIdx.y & 1, (int)blockIdx.x, (int)gridDim.x, cur, force);
+}
 template <bool ENERGY, class real, class Desc> __device__ __forceinline__ void hb_eval_body(const Desc& d, const CellSys<real>& C, const HbRows& H, const real* __restrict__ pos, int rep) {
     const CellView<real> L = cell_view_plain(C, pos, rep);
     const int sub = threadIdx.x & (AWSEM_ROW - 1);
@@ -598,11 +848,20 @@ template <bool ENERGY, class real, class Desc> __device__ __forceinline__ void h
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
-template <bool ENERGY, class real> __global__ void cell_hb_eval_kernel(HbTerms<real> T, CellSys<real> C, const real* __restrict__ pos, unsigned mask) {
+template <bool ENERGY, class real> __global__ void cell_hb_eval_kernel(HbTerms<real> T, CellSys<real> C, const real* __restrict__ pos, unsigned mask,
+                                                                       int rows_cur, int rows_force) {
     const int rep = blockIdx.y, t = blockIdx.z;
     const HbRows H = T.rows[t];
-    if (t < T.n_beta) { const BetaD<real> d = T.beta[t]; if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, rep); }
-    else { const PapD<real> d = T.pap[t - T.n_beta]; if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, rep); }
+    const bool build = rows_cur >= 0 && cell_rebuild(C, rep, rows_cur, rows_force);   // as in cell_density_excl_kernel
+    if (t < T.n_beta) {
+        const BetaD<real> d = T.beta[t];
+        if (build) { hb_rows_body(d, C, H, pos, T.rc2[t], rep); __syncthreads(); }
+        if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, rep);
+    } else {
+        const PapD<real> d = T.pap[t - T.n_beta];
+        if (build) { hb_rows_body(d, C, H, pos, T.rc2[t], rep); __syncthreads(); }
+        if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, rep);
+    }
 }
 
 // Bonded terms: one workgroup per 256 items of one term (job table built at finalize).
@@ -627,42 +886,6 @@ template <bool ENERGY, class real> __global__ void cell_bonded_kernel(DevSys<rea
     case CJ_CV_APPLY: { GaussD<real> d = S.gauss[job.term]; if (!AWSEM_ON(d)) return; d.items += f; d.n = min(256, d.n - f);
                         if (f == 0) cv_apply<ENERGY>(d, L); else cv_apply<false>(d, L); } break;
     }
-}
-
-// Bonded terms, window by window: a workgroup stages the positions of AWSEM_WIN_SPAN consecutive atoms in LDS, runs
-// every item whose lowest atom lies in its window (the item lists are sorted by window at finalize) with LDS
-// accumulators, and flushes the touched atoms with one global atomic per component -- a fifth of the global atomics of
-// the item-by-item kernel above, which keeps the items that do not fit a window.
-// wstart[slot][w]: first item of window w in the slot's term; slots run over harm, chi, rama, helical, fm, memb.
-template <class real> struct WinView : ViewCommon<real>, SoaOps<real> { typedef real real_t; };
-template <bool ENERGY, class real> __global__ void cell_window_kernel(DevSys<real> S, CellSys<real> C, const real* __restrict__ pos, const int* __restrict__ wstart, int nwin, unsigned mask) {
-    __shared__ real sp[3][AWSEM_WIN_SPAN];
-    __shared__ u64 sf[3][AWSEM_WIN_SPAN];
-    const int rep = blockIdx.y, w = blockIdx.x, n = C.natoms;
-    const int a0 = w * AWSEM_WIN, na = min(AWSEM_WIN_SPAN, n - a0);
-    const real* p = pos + (size_t)rep * 3 * n;
-    for (int i = threadIdx.x; i < na; i += blockDim.x)
-        for (int k = 0; k < 3; k++) { sp[k][i] = p[(size_t)k * n + a0 + i]; sf[k][i] = 0; }
-    WinView<real> L;
-    L.nthr = blockDim.x; L.ramap = nullptr;
-    L.px = &sp[0][0] - a0; L.py = &sp[1][0] - a0; L.pz = &sp[2][0] - a0;
-    L.fx = &sf[0][0] - a0; L.fy = &sf[1][0] - a0; L.fz = &sf[2][0] - a0;
-    L.rho = L.drho = nullptr; L.rhov = L.alpha = L.dalpha = L.gamma = nullptr; L.satom = nullptr; L.cv = nullptr;
-    L.lcount = nullptr; L.flag = nullptr; L.lists = nullptr;
-    L.eg = C.eg + (size_t)rep * AWSEM_NGROUPS;
-    __syncthreads();
-    const int* ws = wstart + w;
-    const int stride = nwin + 1;
-    for (int t = 0; t < S.n_harm; t++, ws += stride) { HarmD<real> d = S.harm[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.items += ws[0]; d.n = ws[1] - ws[0]; term_harmonic<ENERGY>(d, L); }
-    for (int t = 0; t < S.n_chi; t++, ws += stride) { ChiD<real> d = S.chi[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.atoms += ws[0]; d.n = ws[1] - ws[0]; term_chi<ENERGY>(d, L); }
-    for (int t = 0; t < S.n_rama; t++, ws += stride) { RamaD<real> d = S.rama[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.atoms += ws[0]; d.bw += (size_t)ws[0] * d.nwell; d.n = ws[1] - ws[0]; term_rama<ENERGY>(d, L); }
-    for (int t = 0; t < S.n_helical; t++, ws += stride) { HelicalD<real> d = S.helical[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.items += ws[0]; if (d.zitems) d.zitems += ws[0]; d.n = ws[1] - ws[0]; term_helical<ENERGY>(d, L); }
-    for (int t = 0; t < S.n_fm; t++, ws += stride) { FmD<real> d = S.fm[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.pairs2 += 2 * (size_t)ws[0]; d.table2 += (size_t)ws[0] * (d.ntab - 1); d.n = ws[1] - ws[0]; term_fm<ENERGY, false>(d, L); }
-    for (int t = 0; t < S.n_memb; t++, ws += stride) { MembD<real> d = S.memb[t]; if (!AWSEM_ON(d) || ws[1] == ws[0]) continue; d.items += ws[0]; d.n = ws[1] - ws[0]; term_memb<ENERGY>(d, L); }
-    __syncthreads();
-    u64* f = C.f + (size_t)rep * 3 * n;
-    for (int i = threadIdx.x; i < na; i += blockDim.x)
-        for (int k = 0; k < 3; k++) { const u64 v = sf[k][i]; if (v) fixed_add(&f[(size_t)k * n + a0 + i], v); }
 }
 
 template <class T> __global__ void cell_set_word_kernel(T* p, T v) { *p = v; }
@@ -732,9 +955,14 @@ __global__ void cell_momentum_kernel(DevSys<real> S, CellSys<real> C, const real
 }
 // Langevin update; every massive particle gathers the forces of the virtual sites it parents (no atomics) and clears
 // its own accumulator (those of the sites are cleared by the next step's pre kernel, once every parent has read them).
+// next_cur >= 0 (round 3): the integrator also does what the NEXT step's pre kernel would do -- member records, displacement flag
+// (written to flag[next_cur]; flag[next_cur ^ 1], which this step's rebuild has read, is reset), per-workgroup bounding boxes -- and
+// clears the accumulators of the virtual sites and the massless particles in the OTHER parity's force array `f_other`, the one the next
+// step sums into (this step's are still being gathered by the sites' parents in other workgroups).
 template <class real>
 __global__ void cell_integrate_kernel(DevSys<real> S, CellSys<real> C, real* __restrict__ pos, real* __restrict__ vel, const double* __restrict__ T,
-                                      double dt, double friction, unsigned long long seed, const long long* __restrict__ step_base, int step_offset) {
+                                      double dt, double friction, unsigned long long seed, const long long* __restrict__ step_base, int step_offset,
+                                      int next_cur, u64* __restrict__ f_other) {
     const long long step = *step_base + step_offset;   // the base lives in device memory so that a captured graph of several steps can be replayed
     const int rep = blockIdx.y, n = C.natoms;
     const CellView<real> L = cell_view(S, C, pos, rep);
@@ -755,6 +983,10 @@ __global__ void cell_integrate_kernel(DevSys<real> S, CellSys<real> C, real* __r
         const double f = (double)S.inv_total_mass / AWSEM_FIXED_SCALE;
         vcx = (real)((double)(long long)s[0] * f); vcy = (real)((double)(long long)s[1] * f); vcz = (real)((double)(long long)s[2] * f);
     }
+    const bool pre = next_cur >= 0;   // uniform
+    bool moved = false;
+    float blo[3] = {3e38f, 3e38f, 3e38f}, bhi[3] = {-3e38f, -3e38f, -3e38f};
+    const real* qref = C.ref + (size_t)rep * 3 * n;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S.nmassive; k += gridDim.x * blockDim.x) {
         const MassiveItem<real> mi = S.massive[k];
         const GatherItem<real> gi = S.gather[k];
@@ -774,13 +1006,43 @@ __global__ void cell_integrate_kernel(DevSys<real> S, CellSys<real> C, real* __r
         const real vy = a * (v[n + i] - vcy) + im * F.y + sq * g[1];
         const real vz = a * (v[2 * (size_t)n + i] - vcz) + im * F.z + sq * g[2];
         v[i] = vx; v[n + i] = vy; v[2 * (size_t)n + i] = vz;
-        L.px[i] += dtr * vx; L.py[i] += dtr * vy; L.pz[i] += dtr * vz;
+        const real x = L.px[i] + dtr * vx, y = L.py[i] + dtr * vy, z = L.pz[i] + dtr * vz;
+        L.px[i] = x; L.py[i] = y; L.pz[i] = z;
         if (cmr) {
             const double m = 1.0 / (double)mi.inv_mass;
             mom[0] += (u64)__double2ll_rn(m * (double)vx * AWSEM_FIXED_SCALE);
             mom[1] += (u64)__double2ll_rn(m * (double)vy * AWSEM_FIXED_SCALE);
             mom[2] += (u64)__double2ll_rn(m * (double)vz * AWSEM_FIXED_SCALE);
         }
+        if (pre) {   // list members are massive particles (checked at finalize): every member passes through here
+            const int m0 = C.member_of[0][i], m1 = C.member_of[1][i];
+            if (m0 >= 0 || m1 >= 0) {
+                moved = moved || (float)dist2(x - qref[i], y - qref[n + i], z - qref[2 * (size_t)n + i]) > (float)C.skin_half2;
+                blo[0] = fminf(blo[0], (float)x); bhi[0] = fmaxf(bhi[0], (float)x);
+                blo[1] = fminf(blo[1], (float)y); bhi[1] = fmaxf(bhi[1], (float)y);
+                blo[2] = fminf(blo[2], (float)z); bhi[2] = fmaxf(bhi[2], (float)z);
+                if (m0 >= 0) ((Rec<real>*)C.bin[0].rec + (size_t)rep * C.bin[0].n)[m0] = Rec<real>{x, y, z, make_tag(S.contact[0].info[m0], (real)0)};
+                if (m1 >= 0) ((Rec<real>*)C.bin[1].rec + (size_t)rep * C.bin[1].n)[m1] = Rec<real>{x, y, z, make_tag(i, (real)0)};
+            }
+        }
+    }
+    if (pre) {
+        __shared__ int slo[3], shi[3];
+        if (threadIdx.x < 3) { slo[threadIdx.x] = 0x7fffffff; shi[threadIdx.x] = (int)0x80000000; }
+        __syncthreads();
+        if (__ballot(moved) && (threadIdx.x & 63) == 0) C.flag[2 * rep + next_cur] = 1u;   // same value from every writer: no atomic needed
+        for (int k = 0; k < 3; k++) {
+            for (int off = 32; off > 0; off >>= 1) { blo[k] = fminf(blo[k], __shfl_down(blo[k], off)); bhi[k] = fmaxf(bhi[k], __shfl_down(bhi[k], off)); }
+            if ((threadIdx.x & 63) == 0 && blo[k] <= bhi[k]) { atomicMin(&slo[k], ordered_int(blo[k])); atomicMax(&shi[k], ordered_int(bhi[k])); }
+        }
+        __syncthreads();
+        int* bb = C.bbox + ((size_t)rep * C.nblk_box + blockIdx.x) * 8;
+        if (threadIdx.x < 3) { bb[threadIdx.x] = slo[threadIdx.x]; bb[4 + threadIdx.x] = shi[threadIdx.x]; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) C.flag[2 * rep + (next_cur ^ 1)] = 0;
+        if (blockIdx.x == 0 && (int)threadIdx.x < C.n_cv) C.cv[(size_t)rep * C.n_cv + threadIdx.x] = 0;
+        u64* fo = f_other + (size_t)rep * 3 * n;
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < S.nvs; t += gridDim.x * blockDim.x) { const int a = S.vs[t].x; fo[a] = 0; fo[n + a] = 0; fo[2 * (size_t)n + a] = 0; }
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < S.nfixed; t += gridDim.x * blockDim.x) { const int a = S.fixed[t]; fo[a] = 0; fo[n + a] = 0; fo[2 * (size_t)n + a] = 0; }
     }
     if (cmr) {   // this workgroup's share of the new momentum, for the next step (the other parity: nobody reads it during this kernel)
         cell_block_sum(mom, sh);

@@ -619,6 +619,11 @@ private:
                 cell_stale_ = true; lists_valid_ = false;
                 throw std::string("neighbour list overflow on the cell-list path outside a replayable launch sequence: raise AWSEM_CELL_NEIGHBORS (partners reserved per contact site, default 96, grown to twice the fullest row when dynamics start)");
             }
+            if (st & 8) {
+                cell_stale_ = true; lists_valid_ = false;
+                throw std::string("cell-list path: a grid barrier of the list rebuild timed out (its workgroups were not all resident: is the GPU shared with other work?); "
+                                  "AWSEM_CELL_FUSED=0 selects the multi-kernel rebuild");
+            }
             if (st & 4) throw std::string("a force exceeded the range of the fp32 fixed-point accumulators (2.6e5 kJ/mol/nm): overlapping atoms or an exploding "
                                           "trajectory -- minimise the structure first (awsem_minimize), reduce the time step, or use the fp64 mode");
             throw std::string("pair list overflow on the device (internal error: list capacity below the candidate pair count)");
@@ -766,7 +771,7 @@ private:
     void cell_alloc_lists();
     void cell_pre(bool step);
     void cell_refresh(const CellSys<real>& C);
-    void cell_forces_pass(bool energy, unsigned mask);
+    void cell_forces_pass(bool energy, unsigned mask, const CellSys<real>* Cp = nullptr, bool window = true, int rows_cur = -1, int rows_force = 0);
     void cell_evaluate(bool energy, unsigned mask, int redistribute, double* e, double* f);
     void cell_step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0);
     // A neighbour row that overflows in the middle of a trajectory (the chains became denser than the rows were sized for) drops
@@ -791,7 +796,10 @@ private:
     long long* cell_step_base_ = nullptr;
     int cell_neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity);
     dim3 cell_grid(long long n) const { long long b = (n + 255) / 256; return dim3((unsigned)std::max(1LL, std::min(b, 2048LL)), nrep_); }
-    bool cell_mode_ = false, cell_stale_ = true;
+    bool cell_mode_ = false, cell_stale_ = true, cell_fused_ = true;
+    std::vector<int> vs_dev_site_;   // DevSys::vs[i].x on the host
+    // the sort's workgroups wait for one another: 2 x 32 x replicas of them (256 threads, 2 KB of LDS) must be resident at once -- a quarter of what the device holds
+    bool cell_sort_ok() const { return cell_fused_ && (long long)2 * AWSEM_SORT_G * nrep_ <= 2LL * (long long)n_cu_; }
     CellSys<real> cell_;
     const CellJob* cell_jobs_ = nullptr;
     int cell_njobs_ = 0, cell_per_site_ = 96, cell_cur_ = 0;
@@ -1033,6 +1041,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         std::vector<Int4> vs(S.nvs);
         for (int i = 0; i < S.nvs; i++) { int o = perm[i]; vs[i] = Int4{H.vs_site[o], H.vs_par[3 * o], H.vs_par[3 * o + 1], H.vs_par[3 * o + 2]}; }
         S.vs = upload(vs);
+        vs_dev_site_.resize(S.nvs);
+        for (int i = 0; i < S.nvs; i++) vs_dev_site_[i] = vs[i].x;
         S.vs_w = upload_real(permuted(H.vs_w, perm, 3));
     }
     {   // harmonic
@@ -1591,7 +1601,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     dT_ = dalloc<double>(nrep_); dtmp_ = dalloc<double>(nrep_); dE_ = dalloc<double>((size_t)nrep_ * AWSEM_NGROUPS); dF_ = dalloc<double>(nstate);
 
     if (cell_mode_) {   // the cell-list kernels use no dynamic LDS
-        cell_.f = dalloc<u64>(nstate);
+        cell_.f = dalloc<u64>(2 * nstate);   // two parities: a step sums into one while the integrator clears the other for the next (cell_integrate_kernel)
+        HIP_TRY(hipMemset(cell_.f, 0, 2 * nstate * sizeof(u64)));
         cell_.ref = dalloc<real>(nstate);
         return;
     }
@@ -1780,6 +1791,25 @@ template <class real> void Engine<real>::cell_setup(DevSys<real>& S, const HostS
     C.flag = dalloc<unsigned>(R * 2);
     HIP_TRY(hipMemset(C.flag, 0, R * 2 * sizeof(unsigned)));
     C.nblk_int = (int)cell_grid(S.nmassive).x;
+    {   // round 3: what the fused step needs (awsem_cell.h: cell_integrate_kernel with next_cur, cell_window_kernel<VS>, cell_rebuild_kernel)
+        C.nblk_box = std::max(C.nblk_pre, C.nblk_int);
+        std::vector<int> box((size_t)R * C.nblk_box * 8, 0);
+        for (size_t w = 0; w < (size_t)R * C.nblk_box; w++) for (int k = 0; k < 3; k++) { box[8 * w + k] = 0x7fffffff; box[8 * w + 4 + k] = (int)0x80000000; }
+        dfree(C.bbox);
+        C.bbox = const_cast<int*>(upload(box));   // boxes nobody writes stay neutral
+        std::vector<int> m0(natoms_, -1), m1(natoms_, -1), vso(natoms_, -1);
+        for (int i = 0; i < B0.n; i++) m0[H.contact[0].atom[i]] = i;
+        for (int i = 0; i < B1.n; i++) m1[excl_sorted_atom_[i]] = i;
+        for (size_t t = 0; t < vs_dev_site_.size(); t++) vso[vs_dev_site_[t]] = (int)t;   // index into DevSys::vs (its own order)
+        C.member_of[0] = upload(m0); C.member_of[1] = upload(m1); C.vs_of = upload(vso);
+        C.bar = dalloc<unsigned>(R * 2 * 4);
+        HIP_TRY(hipMemset(C.bar, 0, R * 2 * 4 * sizeof(unsigned)));
+        for (int b = 0; b < 2; b++) {   // the rebuild kernel's invariant: counts are zero between rebuilds
+            HIP_TRY(hipMemset(C.bin[b].cell_count, 0, R * AWSEM_CELL_MAXCELLS * sizeof(int)));
+            HIP_TRY(hipMemset(C.bin[b].tile_sum, 0, R * (AWSEM_CELL_MAXCELLS / 1024) * sizeof(int)));
+        }
+        cell_fused_ = !(getenv("AWSEM_CELL_FUSED") && atoi(getenv("AWSEM_CELL_FUSED")) == 0);
+    }
     C.cm = dalloc<u64>(2 * R * C.nblk_int * 3);
     HIP_TRY(hipMemset(C.cm, 0, 2 * R * C.nblk_int * 3 * sizeof(u64)));
     C.eg = dalloc<u64>(R * AWSEM_NGROUPS);
@@ -1871,6 +1901,20 @@ template <class real> void Engine<real>::cell_refresh(const CellSys<real>& C) {
     const long long nm = std::max(C.bin[0].n, C.bin[1].n);
     const dim3 gm((unsigned)std::max(1LL, std::min((nm + 255) / 256, 4096LL)), 2 * nrep_), b(256);
     const dim3 gr((unsigned)std::max(1LL, std::min((nm * AWSEM_ROW + 255) / 256, 16384LL)), 2 * nrep_);
+    // Round 3: the sort (geometry, count, scan, fill) is one launch of 32 workgroups per (replica, bin) that synchronise among
+    // themselves (cell_sort_kernel: all of them must be resident at once, which the replica count bounds); the rows follow as before.
+    // cell_one_step does without these launches altogether (the sort rides in the window kernel, the rows are built where they are walked).
+    if (cell_sort_ok()) {
+        hipLaunchKernelGGL(cell_sort_kernel<real>, dim3(AWSEM_SORT_G, 2 * nrep_), b, 0, stream_, C, (const real*)pos_, cur, force);
+        hipLaunchKernelGGL(cell_rows_kernel<real>, gr, b, 0, stream_, dsys_, C, cur, force);
+        if (cell_hb_.n_beta + cell_hb_.n_pap) {
+            const dim3 gh((unsigned)std::max(1LL, std::min(((long long)cell_hb_maxacc_ * AWSEM_ROW + 255) / 256, 16384LL)), nrep_, cell_hb_.n_beta + cell_hb_.n_pap);
+            hipLaunchKernelGGL(cell_hb_rows_kernel<real>, gh, b, 0, stream_, cell_hb_, C, pos_, cur, force);
+        }
+        HIP_TRY(hipGetLastError());
+        cell_stale_ = false;
+        return;
+    }
     hipLaunchKernelGGL(cell_geom_kernel<real>, dim3(2 * nrep_), dim3(1024), 0, stream_, C, cur, force);
     hipLaunchKernelGGL(cell_count_kernel<real>, dim3(std::min(gm.x, 64u), gm.y), b, 0, stream_, C, pos_, cur, force);   // few workgroups: see the tile histogram
     hipLaunchKernelGGL(cell_scan_kernel<real>, dim3(AWSEM_CELL_MAXCELLS / 1024, 2 * nrep_), dim3(1024), 0, stream_, C, cur, force);
@@ -1883,35 +1927,44 @@ template <class real> void Engine<real>::cell_refresh(const CellSys<real>& C) {
     HIP_TRY(hipGetLastError());
     cell_stale_ = false;
 }
-template <class real> void Engine<real>::cell_forces_pass(bool energy, unsigned mask) {
-    const CellSys<real>& C = cell_;
+template <class real> void Engine<real>::cell_forces_pass(bool energy, unsigned mask, const CellSys<real>* Cp, bool window, int rows_cur, int rows_force) {
+    const CellSys<real>& C = Cp ? *Cp : cell_;
     const DevSys<real>& S = dsys_;
     const dim3 b(256);
-    if (cell_nslots_) {
-        if (energy) hipLaunchKernelGGL((cell_window_kernel<true, real>), dim3(cell_nwin_, nrep_), b, 0, stream_, S, C, pos_, cell_wstart_dev_, cell_nwin_, mask);
-        else hipLaunchKernelGGL((cell_window_kernel<false, real>), dim3(cell_nwin_, nrep_), b, 0, stream_, S, C, pos_, cell_wstart_dev_, cell_nwin_, mask);
+    if (cell_nslots_ && window) {
+        if (energy) hipLaunchKernelGGL((cell_window_kernel<true, false, real>), dim3(cell_nwin_, nrep_), b, 0, stream_, S, C, pos_, cell_wstart_dev_, cell_nwin_, mask);
+        else hipLaunchKernelGGL((cell_window_kernel<false, false, real>), dim3(cell_nwin_, nrep_), b, 0, stream_, S, C, pos_, cell_wstart_dev_, cell_nwin_, mask);
     }
-    if (cell_njobs_) {
-        if (energy) hipLaunchKernelGGL((cell_bonded_kernel<true, real>), dim3(cell_njobs_, nrep_), b, 0, stream_, S, C, pos_, cell_jobs_, mask);
-        else hipLaunchKernelGGL((cell_bonded_kernel<false, real>), dim3(cell_njobs_, nrep_), b, 0, stream_, S, C, pos_, cell_jobs_, mask);
-    }
-    if (cell_ncvjobs_) {
-        if (energy) {
-            hipLaunchKernelGGL((cell_bonded_kernel<true, real>), dim3(cell_ncvjobs_, nrep_), b, 0, stream_, S, C, pos_, cell_cv_sum_jobs_, mask);
-            hipLaunchKernelGGL((cell_bonded_kernel<true, real>), dim3(cell_ncvjobs_, nrep_), b, 0, stream_, S, C, pos_, cell_cv_apply_jobs_, mask);
-        } else {
-            hipLaunchKernelGGL((cell_bonded_kernel<false, real>), dim3(cell_ncvjobs_, nrep_), b, 0, stream_, S, C, pos_, cell_cv_sum_jobs_, mask);
-            hipLaunchKernelGGL((cell_bonded_kernel<false, real>), dim3(cell_ncvjobs_, nrep_), b, 0, stream_, S, C, pos_, cell_cv_apply_jobs_, mask);
+    auto launch_jobs = [&]() {
+        if (cell_njobs_) {
+            if (energy) hipLaunchKernelGGL((cell_bonded_kernel<true, real>), dim3(cell_njobs_, nrep_), b, 0, stream_, S, C, pos_, cell_jobs_, mask);
+            else hipLaunchKernelGGL((cell_bonded_kernel<false, real>), dim3(cell_njobs_, nrep_), b, 0, stream_, S, C, pos_, cell_jobs_, mask);
         }
-    }
+        if (cell_ncvjobs_) {
+            if (energy) {
+                hipLaunchKernelGGL((cell_bonded_kernel<true, real>), dim3(cell_ncvjobs_, nrep_), b, 0, stream_, S, C, pos_, cell_cv_sum_jobs_, mask);
+                hipLaunchKernelGGL((cell_bonded_kernel<true, real>), dim3(cell_ncvjobs_, nrep_), b, 0, stream_, S, C, pos_, cell_cv_apply_jobs_, mask);
+            } else {
+                hipLaunchKernelGGL((cell_bonded_kernel<false, real>), dim3(cell_ncvjobs_, nrep_), b, 0, stream_, S, C, pos_, cell_cv_sum_jobs_, mask);
+                hipLaunchKernelGGL((cell_bonded_kernel<false, real>), dim3(cell_ncvjobs_, nrep_), b, 0, stream_, S, C, pos_, cell_cv_apply_jobs_, mask);
+            }
+        }
+    };
+    // dynamics: the windows (which place the virtual sites) ride in the density launch below, so the item-by-item jobs, which may read
+    // virtual sites, follow it
+    const bool jobs_after = rows_cur >= 0 && cell_nslots_ > 0 && !window;
+    if (!jobs_after) launch_jobs();
     auto row_blocks = [](int n) { return (int)std::max(1LL, std::min(((long long)n * AWSEM_ROW + 255) / 256, 16384LL)); };
     const bool contact_on = S.n_contact && ((mask >> S.contact[0].group) & 1u);
     const bool excl_on = S.n_excl && ((mask >> S.excl[0].group) & 1u);
     if (contact_on || excl_on) {
         const int nbc = contact_on ? row_blocks(C.bin[0].n) : 0, nbx = excl_on ? row_blocks(C.bin[1].n) : 0;
-        if (energy) hipLaunchKernelGGL((cell_density_excl_kernel<true, real>), dim3(nbc + nbx, nrep_), b, 0, stream_, S, C, pos_, nbc, mask);
-        else hipLaunchKernelGGL((cell_density_excl_kernel<false, real>), dim3(nbc + nbx, nrep_), b, 0, stream_, S, C, pos_, nbc, mask);
+        const bool win = rows_cur >= 0 && cell_nslots_ > 0;   // dynamics: the bonded windows ride in this launch (cell_one_step)
+        if (energy) hipLaunchKernelGGL((cell_density_excl_kernel<true, false, real>), dim3(nbc + nbx, nrep_), b, 0, stream_, S, C, pos_, nbc, nbx, mask, rows_cur, rows_force, (const int*)nullptr, 0);
+        else if (win) hipLaunchKernelGGL((cell_density_excl_kernel<false, true, real>), dim3(nbc + nbx + cell_nwin_, nrep_), b, 0, stream_, S, C, pos_, nbc, nbx, mask, rows_cur, rows_force, cell_wstart_dev_, cell_nwin_);
+        else hipLaunchKernelGGL((cell_density_excl_kernel<false, false, real>), dim3(nbc + nbx, nrep_), b, 0, stream_, S, C, pos_, nbc, nbx, mask, rows_cur, rows_force, (const int*)nullptr, 0);
     }
+    if (jobs_after) launch_jobs();
     if (contact_on) {
         const dim3 g(row_blocks(C.bin[0].n), nrep_);
         if (!(S.contact[0].flags & 2)) {
@@ -1922,8 +1975,8 @@ template <class real> void Engine<real>::cell_forces_pass(bool energy, unsigned 
     }
     if (cell_hb_.n_beta + cell_hb_.n_pap) {
         const dim3 g(row_blocks(cell_hb_maxacc_), nrep_, cell_hb_.n_beta + cell_hb_.n_pap);
-        if (energy) hipLaunchKernelGGL((cell_hb_eval_kernel<true, real>), g, b, 0, stream_, cell_hb_, C, pos_, mask);
-        else hipLaunchKernelGGL((cell_hb_eval_kernel<false, real>), g, b, 0, stream_, cell_hb_, C, pos_, mask);
+        if (energy) hipLaunchKernelGGL((cell_hb_eval_kernel<true, real>), g, b, 0, stream_, cell_hb_, C, pos_, mask, rows_cur, rows_force);
+        else hipLaunchKernelGGL((cell_hb_eval_kernel<false, real>), g, b, 0, stream_, cell_hb_, C, pos_, mask, rows_cur, rows_force);
     }
     HIP_TRY(hipGetLastError());
 }
@@ -1956,11 +2009,45 @@ template <class real> void Engine<real>::cell_evaluate(bool energy, unsigned mas
 }
 // one MD step on the stream; `offset` is added to the device-resident step base by the integrator
 template <class real> void Engine<real>::cell_one_step(double dt, double friction, uint64_t seed, int offset) {
-    cell_pre(true);
-    cell_refresh(cell_);
-    cell_forces_pass(false, 0xffffffffu);
-    hipLaunchKernelGGL(cell_integrate_kernel<real>, cell_grid(dsys_.nmassive), dim3(256), 0, stream_, dsys_, cell_, pos_, vel_, dT_, dt, friction,
-                       (unsigned long long)seed, (const long long*)cell_step_base_, offset);
+    if (!cell_fused_) {   // AWSEM_CELL_FUSED=0: the eleven-launch step of rounds 1 and 2
+        cell_pre(true);
+        cell_refresh(cell_);
+        cell_forces_pass(false, 0xffffffffu);
+        hipLaunchKernelGGL(cell_integrate_kernel<real>, cell_grid(dsys_.nmassive), dim3(256), 0, stream_, dsys_, cell_, pos_, vel_, dT_, dt, friction,
+                           (unsigned long long)seed, (const long long*)cell_step_base_, offset, -1, (u64*)nullptr);
+        return;
+    }
+    // Round 3: window kernel (bonded terms; places the virtual sites) -> ONE rebuild launch (leaves at once unless a member moved
+    // skin/2) -> density + excluded volume -> pair pass -> chain rule [-> hydrogen bonds] -> integrator, which also leaves the member
+    // records, the displacement flag and the bounding boxes of the NEXT step and clears that step's virtual-site accumulators (the
+    // force arrays alternate with the flag parity).  The launch-start cell_pre(true) of cell_step stands in for a preceding integrator.
+    const size_t fstride = (size_t)nrep_ * 3 * natoms_;
+    const int cur = cell_cur_;
+    CellSys<real> C = cell_;
+    C.f = cell_.f + (size_t)cur * fstride;
+    const int force = cell_stale_ ? 1 : 0;
+    // a replica whose contact or excluded-volume term is switched off would never have its rows rebuilt where they are walked
+    const bool inline_rows = cell_sort_ok() && (!dsys_.n_contact || dsys_.contact[0].group >= 0) && (!dsys_.n_excl || dsys_.excl[0].group >= 0);
+    if (inline_rows) {
+        // the sort: 64 small workgroups that leave at once on most steps; then the contact / excluded-volume / bonded launch builds the rows
+        // where it walks them and places the virtual sites in its windows
+        const bool win_rides = cell_nslots_ > 0 && (dsys_.n_contact > 0 || dsys_.n_excl > 0);
+        if (!win_rides) {
+            if (cell_nslots_) hipLaunchKernelGGL((cell_window_kernel<false, true, real>), dim3(cell_nwin_, nrep_), dim3(256), 0, stream_, dsys_, C, pos_, cell_wstart_dev_, cell_nwin_, 0xffffffffu);
+            else hipLaunchKernelGGL(cell_vsite_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, pos_);
+        }
+        hipLaunchKernelGGL(cell_sort_kernel<real>, dim3(AWSEM_SORT_G, 2 * nrep_), dim3(256), 0, stream_, C, (const real*)pos_, cur, force);
+        cell_stale_ = false;
+        cell_forces_pass(false, 0xffffffffu, &C, false, cur, force);
+    } else {
+        if (cell_nslots_) hipLaunchKernelGGL((cell_window_kernel<false, true, real>), dim3(cell_nwin_, nrep_), dim3(256), 0, stream_, dsys_, C, pos_, cell_wstart_dev_, cell_nwin_, 0xffffffffu);
+        else hipLaunchKernelGGL(cell_vsite_kernel<real>, cell_grid(dsys_.nvs), dim3(256), 0, stream_, dsys_, pos_);
+        cell_refresh(C);
+        cell_forces_pass(false, 0xffffffffu, &C, false);
+    }
+    hipLaunchKernelGGL(cell_integrate_kernel<real>, cell_grid(dsys_.nmassive), dim3(256), 0, stream_, dsys_, C, pos_, vel_, dT_, dt, friction,
+                       (unsigned long long)seed, (const long long*)cell_step_base_, offset, cur ^ 1, cell_.f + (size_t)(cur ^ 1) * fstride);
+    cell_cur_ = cur ^ 1;
 }
 // A launch of `nsteps` is played as captured HIP graphs of AWSEM_CELL_CHUNK steps (the ~11 kernels of a step cost more
 // to enqueue from the host than to run) plus single steps for the remainder; AWSEM_CELL_GRAPH=0 disables the graphs.
@@ -2045,7 +2132,8 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
     else cell_pending_.clear();   // device-resident temperatures (replica exchange): the sweeps in between are not recorded, so such a launch is not replayable
     begin_async(T);
     static const bool use_graph = !(getenv("AWSEM_CELL_GRAPH") && atoi(getenv("AWSEM_CELL_GRAPH")) == 0);
-    HIP_TRY(hipMemsetAsync(cell_.f, 0, (size_t)nrep_ * 3 * natoms_ * sizeof(u64), stream_));
+    HIP_TRY(hipMemsetAsync(cell_.f, 0, (size_t)2 * nrep_ * 3 * natoms_ * sizeof(u64), stream_));
+    if (cell_fused_ && nsteps > 0) { cell_pre(true); HIP_TRY(hipGetLastError()); }   // what the integrator of a preceding step would have left (cell_one_step)
     int s = 0;
     auto set_base = [&](long long v) { hipLaunchKernelGGL(cell_set_word_kernel<long long>, dim3(1), dim3(1), 0, stream_, cell_step_base_, v); };
     if (dsys_.remove_cm) {   // the momentum the first step removes (later steps get it from the integrator before them)

@@ -276,3 +276,34 @@ def test_full_size_synthetic_system_rows_energies_forces_and_dynamics():
     cpu.set_positions(x1)
     a, b = gpu.neighbors(_capi.LIST_CONTACT, 0, 0, 0.15, capacity=1 << 19), cpu.neighbors(_capi.LIST_CONTACT, 0, 0, 0.15, capacity=1 << 19)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_five_launch_step_equals_the_eleven_launch_step_bit_for_bit(precision, monkeypatch):
+    """Round 3: a cell-list step is window kernel (bonded terms, places the virtual sites) -> ONE rebuild launch (grid barriers of its
+    own, leaves at once on most steps) -> density + excluded volume -> pairs -> chain rule -> hydrogen bonds -> integrator (which also
+    leaves the next step's member records, displacement flag and bounding boxes); rounds 1 and 2 ran pre / geometry / count / scan /
+    fill / rows / hydrogen-bond rows as launches of their own (AWSEM_CELL_FUSED=0).  Counter-based random numbers and fixed-point sums:
+    both must produce the SAME trajectory, bit for bit, through list rebuilds (700 K), graph replays (>= 10 steps) and single steps,
+    with all terms (hydrogen bonds included) and with centre-of-mass removal."""
+    oa, traj, _ = golden_system("1brs")
+    system = _full_system(oa)
+    T = np.array([300.0, 700.0, 500.0])
+    out = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("AWSEM_CELL_FUSED", fused)
+        ctx = _ctx(system, 3, precision, True, monkeypatch)
+        ctx.set_positions(traj[2], replica=-1)
+        ctx.set_velocities_to_temperature(T, 4)
+        log = []
+        for chunk in (7, 30, 123):
+            ctx.step(chunk, T, 0.002, 1.0, 21)
+            log.append(ctx.energy_by_group())
+        ctx.synchronize()
+        out.append((ctx.get_state(), log))
+        ctx.close()
+    monkeypatch.delenv("AWSEM_CELL_FUSED", raising=False)
+    assert np.array_equal(out[0][0][0], out[1][0][0]) and np.array_equal(out[0][0][1], out[1][0][1])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b)
+    assert np.abs(out[0][0][0][1] - traj[2]).max() > 0.05
