@@ -19,6 +19,7 @@
 #define AWSEM_CELL_MAXDIM 64
 #define AWSEM_CELL_MAXCELLS (AWSEM_CELL_MAXDIM * AWSEM_CELL_MAXDIM * AWSEM_CELL_MAXDIM)
 #define AWSEM_ROW 16   // lanes that share one list row
+#define AWSEM_ROW_X 4   // ... of the excluded-volume bin: an atom has about ten partners inside 0.35 nm + skin, sixteen lanes idled on them (round 3)
 #define AWSEM_WIN 512        // atoms per window of the bonded-term kernel
 #define AWSEM_WIN_SPAN 768   // atoms a window's LDS holds: its own and the next half window (items reach forward along the chain)
 
@@ -39,8 +40,9 @@ template <class real> struct CellBin {
     int* cell_of;               // [R][n]
     int* sorted;                // [R][n] member ids in cell order
     real* rec;                  // [R][n][4] packed member records: x, y, z, tag (bits)
-    unsigned* rows;             // [R][n][stride] neighbour rows (member ids, flags in the top bits)
-    int* row_count;             // [R][n]
+    unsigned* rows;             // [R][n][stride] neighbour rows (member ids, flags in the top bits); row k belongs to member sorted[k] (round 3: the
+                                // walks read rows and counts by their own loop index, one dependent load fewer than through the member id)
+    int* row_count;             // [R][n], in the same order
 };
 
 template <class real> struct CellSys {
@@ -65,7 +67,7 @@ template <class real> struct CellSys {
     int nblk_int;               // workgroups per replica of the integrator's grid
     // round 3: the step as five launches.  The integrator also does the next step's "pre" work (member records,
     // displacement flag, bounding box), the window kernel places the virtual sites it stages, and ONE launch rebuilds the lists.
-    const int* member_of[2];    // [natoms] atom -> member of bin 0 / bin 1, -1 if none
+    const Int4* pre_items;      // [nmassive] per massive particle: member of bin 0 (-1: none), member of bin 1, the bin-0 record's tag, -
     const int* vs_of;           // [natoms] atom -> index into DevSys::vs, -1 if not a virtual site
     int nblk_box;               // bounding boxes kept per replica: max(nblk_pre, nblk_int); unused ones stay neutral
     unsigned* bar;              // [R][2][4] arrival counters of the rebuild kernel's grid barriers, per (replica, bin)
@@ -105,9 +107,9 @@ __device__ __forceinline__ float make_tag(int b, float) { return __int_as_float(
 __device__ __forceinline__ double make_tag(int b, double) { return __longlong_as_double((long long)(unsigned)b); }
 
 // sum over the 16 lanes of a row; every lane of the row receives the total
-__device__ __forceinline__ u64 row_sum(u64 v) {
+template <int ROW = AWSEM_ROW> __device__ __forceinline__ u64 row_sum(u64 v) {
 #pragma unroll
-    for (int off = 1; off < AWSEM_ROW; off <<= 1) v += __shfl_xor(v, off);
+    for (int off = 1; off < ROW; off <<= 1) v += __shfl_xor(v, off);
     return v;
 }
 
@@ -300,16 +302,16 @@ template <class real> __device__ __forceinline__ void cell_zero_counts(const Cel
 // register of the row, no atomics.  blockIdx.y = 2 * rep + bin.
 //   bin 0 (contact): entry = site_j | in_density << 30 | has_pair_energy << 31
 //   bin 1 (excl):    entry = member_j   (same class, not an excluded partner)
-template <class real> __device__ __forceinline__ void cell_rows_body(const DevSys<real>& S, const CellSys<real>& C, int rep, int b, int bx, int nbx) {
+template <int ROW, class real> __device__ __forceinline__ void cell_rows_body_n(const DevSys<real>& S, const CellSys<real>& C, int rep, int b, int bx, int nbx) {
     const CellBin<real>& B = C.bin[b];
     const Rec<real>* rec = (const Rec<real>*)B.rec + (size_t)rep * B.n;
     const int* sorted = B.sorted + (size_t)rep * B.n;
     const int* cstart = B.cell_start + (size_t)rep * (AWSEM_CELL_MAXCELLS + 1);
     unsigned* rows = B.rows + (size_t)rep * B.n * B.stride;
     const int nx = B.dims[4 * rep], ny = B.dims[4 * rep + 1], nz = B.dims[4 * rep + 2];
-    const int sub = threadIdx.x & (AWSEM_ROW - 1), row_in_wave = (threadIdx.x & 63) / AWSEM_ROW;
-    const int nrows_total = (B.n + 3) & ~3;   // whole waves: the ballots are wave collectives
-    for (int k = (bx * (int)blockDim.x + (int)threadIdx.x) / AWSEM_ROW; k < nrows_total; k += nbx * (int)blockDim.x / AWSEM_ROW) {
+    const int sub = threadIdx.x & (ROW - 1), row_in_wave = (threadIdx.x & 63) / ROW;
+    const int nrows_total = (B.n + 64 / ROW - 1) & ~(64 / ROW - 1);   // whole waves: the ballots are wave collectives
+    for (int k = (bx * (int)blockDim.x + (int)threadIdx.x) / ROW; k < nrows_total; k += nbx * (int)blockDim.x / ROW) {
         const bool vi = k < B.n;
         const int i = vi ? sorted[k] : 0;
         const Rec<real> ri = rec[i];
@@ -330,7 +332,7 @@ template <class real> __device__ __forceinline__ void cell_rows_body(const DevSy
             while (__ballot(q < qe)) {
                 const bool vq = q < qe;
                 const int j = vq ? sorted[q] : i;
-                q += AWSEM_ROW;
+                q += ROW;
                 const Rec<real> rj = rec[j];
                 const real r2 = dist2(ri.x - rj.x, ri.y - rj.y, ri.z - rj.z);
                 bool pass = vq && j != i && r2 < B.rc2;
@@ -346,17 +348,22 @@ template <class real> __device__ __forceinline__ void cell_rows_body(const DevSy
                     const int aj = tag_bits(rj.tag);
                     pass = C.x_class[j] == cls_i && part.x != aj && part.y != aj && part.z != aj && part.w != aj;
                 }
-                const unsigned rowmask = (unsigned)(__ballot(pass) >> (row_in_wave * AWSEM_ROW)) & 0xffffu;
+                const unsigned rowmask = (unsigned)(__ballot(pass) >> (row_in_wave * ROW)) & ((1u << ROW) - 1u);
                 if (pass) {
                     const int slot = cnt + __popc(rowmask & ((1u << sub) - 1u));
-                    if (slot < B.stride) rows[(size_t)i * B.stride + slot] = ent;
+                    if (slot < B.stride) rows[(size_t)k * B.stride + slot] = ent;
                     else atomicOr(C.status, 2);
                 }
                 cnt += __popc(rowmask);
             }
         }
-        if (vi && sub == 0) B.row_count[(size_t)rep * B.n + i] = min(cnt, B.stride);
+        if (vi && sub == 0) B.row_count[(size_t)rep * B.n + k] = min(cnt, B.stride);
     }
+}
+// bin 0 (contact sites) walks with 16 lanes per row, bin 1 (excluded-volume atoms) with 4
+template <class real> __device__ __forceinline__ void cell_rows_body(const DevSys<real>& S, const CellSys<real>& C, int rep, int b, int bx, int nbx) {
+    if (b == 0) cell_rows_body_n<AWSEM_ROW>(S, C, rep, b, bx, nbx);
+    else cell_rows_body_n<AWSEM_ROW_X>(S, C, rep, b, bx, nbx);
 }
 template <class real> __global__ void cell_rows_kernel(DevSys<real> S, CellSys<real> C, int cur, int force) {
     const int rep = blockIdx.y >> 1, b = blockIdx.y & 1;
@@ -468,10 +475,10 @@ template <bool ENERGY, bool WIN, class real> __global__ __launch_bounds__(256) v
             const bool vi = k < B.n;
             const int i = vi ? sorted[k] : 0;
             const Rec<real> ri = rec[i];
-            const int cnt = vi ? B.row_count[(size_t)rep * B.n + i] : 0;
+            const int cnt = vi ? B.row_count[(size_t)rep * B.n + k] : 0;
             u64 acc = 0;
             for (int s = sub; s < cnt; s += AWSEM_ROW) {
-                const unsigned ent = rows[(size_t)i * B.stride + s];
+                const unsigned ent = rows[(size_t)k * B.stride + s];
                 if (!(ent & 0x40000000u)) continue;
                 const Rec<real> rj = rec[ent & 0xffffffu];
                 const real r2 = dist2(ri.x - rj.x, ri.y - rj.y, ri.z - rj.z);
@@ -498,16 +505,17 @@ template <bool ENERGY, bool WIN, class real> __global__ __launch_bounds__(256) v
         const Rec<real>* rec = (const Rec<real>*)B.rec + (size_t)rep * B.n;
         const int* sorted = B.sorted + (size_t)rep * B.n;
         const unsigned* rows = B.rows + (size_t)rep * B.n * B.stride;
-        const int sub = threadIdx.x & (AWSEM_ROW - 1), nrows = (B.n + 3) & ~3, nb = nb_excl;
+        constexpr int RX = AWSEM_ROW_X;
+        const int sub = threadIdx.x & (RX - 1), nrows = (B.n + 64 / RX - 1) & ~(64 / RX - 1), nb = nb_excl;
         const real r02 = d.r0 * d.r0;
-        for (int k = ((bx - nb_contact) * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows; k += nb * blockDim.x / AWSEM_ROW) {
+        for (int k = ((bx - nb_contact) * blockDim.x + threadIdx.x) / RX; k < nrows; k += nb * blockDim.x / RX) {
             const bool vi = k < B.n;
             const int i = vi ? sorted[k] : 0;
             const Rec<real> ri = rec[i];
-            const int cnt = vi ? B.row_count[(size_t)rep * B.n + i] : 0;
+            const int cnt = vi ? B.row_count[(size_t)rep * B.n + k] : 0;
             u64 X = 0, Y = 0, Z = 0;
-            for (int s = sub; s < cnt; s += AWSEM_ROW) {
-                const Rec<real> rj = rec[rows[(size_t)i * B.stride + s]];
+            for (int s = sub; s < cnt; s += RX) {
+                const Rec<real> rj = rec[rows[(size_t)k * B.stride + s]];
                 const real dx = ri.x - rj.x, dy = ri.y - rj.y, dz = ri.z - rj.z;
                 const real r2 = dist2(dx, dy, dz);
                 if (!(r2 < r02)) continue;
@@ -517,7 +525,7 @@ template <bool ENERGY, bool WIN, class real> __global__ __launch_bounds__(256) v
                 X += to_fixed_scaled(t * dx); Y += to_fixed_scaled(t * dy); Z += to_fixed_scaled(t * dz);
             }
             if (__ballot((X | Y | Z) != 0) == 0) continue;   // clashes are rare
-            X = row_sum(X); Y = row_sum(Y); Z = row_sum(Z);
+            X = row_sum<RX>(X); Y = row_sum<RX>(Y); Z = row_sum<RX>(Z);
             if (vi && sub == 0 && (X | Y | Z) != 0) {
                 const int a = tag_bits(ri.tag);
                 if (WIN) { fixed_add(&L.fx[a], X); fixed_add(&L.fy[a], Y); fixed_add(&L.fz[a], Z); }
@@ -543,12 +551,12 @@ template <bool ENERGY, class real> __global__ void cell_pairs_kernel(DevSys<real
         const bool vi = k < B.n;
         const int i = vi ? sorted[k] : 0;
         const Rec<real> ri = rec[i];
-        const int cnt = vi ? B.row_count[(size_t)rep * B.n + i] : 0;
+        const int cnt = vi ? B.row_count[(size_t)rep * B.n + k] : 0;
         const int ti = (tag_bits(ri.tag) >> 27) & 31;
         const real si = L.rhov[i], ai = zdep ? L.alpha[i] : (real)0;
         u64 X = 0, Y = 0, Z = 0, D = 0, FZ = 0;
         for (int s = sub; s < cnt; s += AWSEM_ROW) {
-            const unsigned ent = rows[(size_t)i * B.stride + s];
+            const unsigned ent = rows[(size_t)k * B.stride + s];
             if (!(ent >> 31)) continue;
             const int j = ent & 0xffffffu;
             const Rec<real> rj = rec[j];
@@ -590,11 +598,11 @@ template <class real> __global__ void cell_chain_kernel(DevSys<real> S, CellSys<
         const bool vi = k < B.n;
         const int i = vi ? sorted[k] : 0;
         const Rec<real> ri = rec[i];
-        const int cnt = vi ? B.row_count[(size_t)rep * B.n + i] : 0;
+        const int cnt = vi ? B.row_count[(size_t)rep * B.n + k] : 0;
         const u64 di = L.drho[i];
         u64 X = 0, Y = 0, Z = 0;
         for (int s = sub; s < cnt; s += AWSEM_ROW) {
-            const unsigned ent = rows[(size_t)i * B.stride + s];
+            const unsigned ent = rows[(size_t)k * B.stride + s];
             if (!(ent & 0x40000000u)) continue;
             const int j = ent & 0xffffffu;
             const Rec<real> rj = rec[j];
@@ -696,6 +704,8 @@ template <class real> __global__ void cell_hb_rows_kernel(HbTerms<real> T, CellS
 //     cell_sort_kernel, where there is no window kernel) and leave at once unless the replica's flag is set.  (All workgroups of one
 //     launch doing all four phases was measured first: with 768 workgroups per group a barrier costs ~280 us -- same-address arrivals
 //     serialise at ~0.1 us each and the pollers crowd them out; with 32 it is a few us.)
+//     (Measured and rejected: the sort riding in the PREVIOUS step's integrator launch, its workgroups waiting for an arrival counter --
+//     235 same-address arrivals that all come at once plus the pollers made that launch 53 us instead of 14.)
 //   * ROWS are per owner and need nothing but the sorted arrays: the 16 lanes that are about to walk row i in the density pass (the
 //     excluded-volume pass, the hydrogen-bond pass) build it first when the flag is set -- full occupancy, no launch.
 // Invariant between rebuilds: cell_count[0 .. ncell) and tile_sum are zero (set at allocation, restored by whoever builds the rows).
@@ -1015,13 +1025,14 @@ __global__ void cell_integrate_kernel(DevSys<real> S, CellSys<real> C, real* __r
             mom[2] += (u64)__double2ll_rn(m * (double)vz * AWSEM_FIXED_SCALE);
         }
         if (pre) {   // list members are massive particles (checked at finalize): every member passes through here
-            const int m0 = C.member_of[0][i], m1 = C.member_of[1][i];
+            const Int4 pi = C.pre_items[k];   // one coalesced record instead of three dependent gathers
+            const int m0 = pi.x, m1 = pi.y;
             if (m0 >= 0 || m1 >= 0) {
                 moved = moved || (float)dist2(x - qref[i], y - qref[n + i], z - qref[2 * (size_t)n + i]) > (float)C.skin_half2;
                 blo[0] = fminf(blo[0], (float)x); bhi[0] = fmaxf(bhi[0], (float)x);
                 blo[1] = fminf(blo[1], (float)y); bhi[1] = fmaxf(bhi[1], (float)y);
                 blo[2] = fminf(blo[2], (float)z); bhi[2] = fmaxf(bhi[2], (float)z);
-                if (m0 >= 0) ((Rec<real>*)C.bin[0].rec + (size_t)rep * C.bin[0].n)[m0] = Rec<real>{x, y, z, make_tag(S.contact[0].info[m0], (real)0)};
+                if (m0 >= 0) ((Rec<real>*)C.bin[0].rec + (size_t)rep * C.bin[0].n)[m0] = Rec<real>{x, y, z, make_tag(pi.z, (real)0)};
                 if (m1 >= 0) ((Rec<real>*)C.bin[1].rec + (size_t)rep * C.bin[1].n)[m1] = Rec<real>{x, y, z, make_tag(i, (real)0)};
             }
         }

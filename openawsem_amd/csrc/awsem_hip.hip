@@ -1801,7 +1801,11 @@ template <class real> void Engine<real>::cell_setup(DevSys<real>& S, const HostS
         for (int i = 0; i < B0.n; i++) m0[H.contact[0].atom[i]] = i;
         for (int i = 0; i < B1.n; i++) m1[excl_sorted_atom_[i]] = i;
         for (size_t t = 0; t < vs_dev_site_.size(); t++) vso[vs_dev_site_[t]] = (int)t;   // index into DevSys::vs (its own order)
-        C.member_of[0] = upload(m0); C.member_of[1] = upload(m1); C.vs_of = upload(vso);
+        C.vs_of = upload(vso);
+        std::vector<Int4> pre;
+        for (int i = 0; i < natoms_; i++) if (H.mass[i] > 0)   // DevSys::massive's order
+            pre.push_back(Int4{m0[i], m1[i], m0[i] >= 0 ? (H.contact[0].resid[m0[i]] | (H.contact[0].chain[m0[i]] << 16) | (H.contact[0].restype[m0[i]] << 27)) : 0, 0});
+        C.pre_items = upload(pre);
         C.bar = dalloc<unsigned>(R * 2 * 4);
         HIP_TRY(hipMemset(C.bar, 0, R * 2 * 4 * sizeof(unsigned)));
         for (int b = 0; b < 2; b++) {   // the rebuild kernel's invariant: counts are zero between rebuilds
@@ -1958,7 +1962,8 @@ template <class real> void Engine<real>::cell_forces_pass(bool energy, unsigned 
     const bool contact_on = S.n_contact && ((mask >> S.contact[0].group) & 1u);
     const bool excl_on = S.n_excl && ((mask >> S.excl[0].group) & 1u);
     if (contact_on || excl_on) {
-        const int nbc = contact_on ? row_blocks(C.bin[0].n) : 0, nbx = excl_on ? row_blocks(C.bin[1].n) : 0;
+        const int nbc = contact_on ? row_blocks(C.bin[0].n) : 0;
+        const int nbx = excl_on ? (int)std::max(1LL, std::min(((long long)C.bin[1].n * AWSEM_ROW_X + 255) / 256, 16384LL)) : 0;   // four lanes per excluded-volume row
         const bool win = rows_cur >= 0 && cell_nslots_ > 0;   // dynamics: the bonded windows ride in this launch (cell_one_step)
         if (energy) hipLaunchKernelGGL((cell_density_excl_kernel<true, false, real>), dim3(nbc + nbx, nrep_), b, 0, stream_, S, C, pos_, nbc, nbx, mask, rows_cur, rows_force, (const int*)nullptr, 0);
         else if (win) hipLaunchKernelGGL((cell_density_excl_kernel<false, true, real>), dim3(nbc + nbx + cell_nwin_, nrep_), b, 0, stream_, S, C, pos_, nbc, nbx, mask, rows_cur, rows_force, cell_wstart_dev_, cell_nwin_);
@@ -2017,10 +2022,11 @@ template <class real> void Engine<real>::cell_one_step(double dt, double frictio
                            (unsigned long long)seed, (const long long*)cell_step_base_, offset, -1, (u64*)nullptr);
         return;
     }
-    // Round 3: window kernel (bonded terms; places the virtual sites) -> ONE rebuild launch (leaves at once unless a member moved
-    // skin/2) -> density + excluded volume -> pair pass -> chain rule [-> hydrogen bonds] -> integrator, which also leaves the member
-    // records, the displacement flag and the bounding boxes of the NEXT step and clears that step's virtual-site accumulators (the
-    // force arrays alternate with the flag parity).  The launch-start cell_pre(true) of cell_step stands in for a preceding integrator.
+    // Round 3, five launches: sort (64 small workgroups; leaves at once unless a member moved skin/2) -> density + excluded volume, which
+    // build the rows they walk when the flag is set, with the bonded windows (which place the virtual sites) in the same launch -> pair
+    // pass -> chain rule [-> hydrogen bonds, rows built likewise] -> integrator, which also leaves the member records, the displacement
+    // flag and the bounding boxes of the NEXT step and clears that step's virtual-site accumulators (the force arrays alternate with
+    // the flag parity).  The launch-start cell_pre(true) of cell_step stands in for a preceding integrator.
     const size_t fstride = (size_t)nrep_ * 3 * natoms_;
     const int cur = cell_cur_;
     CellSys<real> C = cell_;
@@ -2275,15 +2281,17 @@ template <class real> int Engine<real>::cell_neighbors(int rep, int kind, int in
             for (int s = 0; s < cnt[i]; s++) out.push_back({i, (int)rows[(size_t)i * Hb.stride + s]});   // (acceptor index, donor index)
     } else {
         const CellBin<real>& B = cell_.bin[b];
-        std::vector<int> cnt(B.n);
+        std::vector<int> cnt(B.n), sorted(B.n);
         std::vector<unsigned> rows((size_t)B.n * B.stride);
         if (B.n) {
             HIP_TRY(hipMemcpy(cnt.data(), B.row_count + (size_t)rep * B.n, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(sorted.data(), B.sorted + (size_t)rep * B.n, sorted.size() * sizeof(int), hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(rows.data(), B.rows + (size_t)rep * B.n * B.stride, rows.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
         }
-        for (int i = 0; i < B.n; i++)
-            for (int s = 0; s < cnt[i]; s++) {
-                const int j = (int)(rows[(size_t)i * B.stride + s] & 0xffffffu);
+        for (int k = 0; k < B.n; k++)   // row k belongs to member sorted[k]
+            for (int s = 0; s < cnt[k]; s++) {
+                const int i = sorted[k];
+                const int j = (int)(rows[(size_t)k * B.stride + s] & 0xffffffu);
                 if (b == 0) { if (i < j) out.push_back({i, j}); }   // every pair sits in both rows: keep the one of the lower site
                 else { const int a = excl_sorted_atom_[i], c = excl_sorted_atom_[j]; if (a < c) out.push_back({a, c}); }
             }
