@@ -20,8 +20,8 @@
 #define AWSEM_CELL_MAXCELLS (AWSEM_CELL_MAXDIM * AWSEM_CELL_MAXDIM * AWSEM_CELL_MAXDIM)
 #define AWSEM_ROW 16   // lanes that share one list row
 #define AWSEM_ROW_X 4   // ... of the excluded-volume bin: an atom has about ten partners inside 0.35 nm + skin, sixteen lanes idled on them (round 3)
-#define AWSEM_WIN 512        // atoms per window of the bonded-term kernel
-#define AWSEM_WIN_SPAN 768   // atoms a window's LDS holds: its own and the next half window (items reach forward along the chain)
+#define AWSEM_WIN 256        // atoms per window of the bonded-term kernel
+#define AWSEM_WIN_SPAN 384   // atoms a window's LDS holds: its own and the next half window (items reach forward along the chain)
 
 // One binning = the members of one listed term (bin 0: contact sites, bin 1: excluded-volume atoms) sorted into a
 // uniform grid whose cell edge is at least that term's cutoff + skin.
@@ -994,6 +994,11 @@ __global__ void cell_integrate_kernel(DevSys<real> S, CellSys<real> C, real* __r
         vcx = (real)((double)(long long)s[0] * f); vcy = (real)((double)(long long)s[1] * f); vcz = (real)((double)(long long)s[2] * f);
     }
     const bool pre = next_cur >= 0;   // uniform
+    if (pre) {   // first, so that these stores and the loads behind them are under way while the particles are integrated
+        u64* fo = f_other + (size_t)rep * 3 * n;
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < S.nvs; t += gridDim.x * blockDim.x) { const int a = S.vs[t].x; fo[a] = 0; fo[n + a] = 0; fo[2 * (size_t)n + a] = 0; }
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < S.nfixed; t += gridDim.x * blockDim.x) { const int a = S.fixed[t]; fo[a] = 0; fo[n + a] = 0; fo[2 * (size_t)n + a] = 0; }
+    }
     bool moved = false;
     float blo[3] = {3e38f, 3e38f, 3e38f}, bhi[3] = {-3e38f, -3e38f, -3e38f};
     const real* qref = C.ref + (size_t)rep * 3 * n;
@@ -1051,9 +1056,6 @@ __global__ void cell_integrate_kernel(DevSys<real> S, CellSys<real> C, real* __r
         if (threadIdx.x < 3) { bb[threadIdx.x] = slo[threadIdx.x]; bb[4 + threadIdx.x] = shi[threadIdx.x]; }
         if (blockIdx.x == 0 && threadIdx.x == 0) C.flag[2 * rep + (next_cur ^ 1)] = 0;
         if (blockIdx.x == 0 && (int)threadIdx.x < C.n_cv) C.cv[(size_t)rep * C.n_cv + threadIdx.x] = 0;
-        u64* fo = f_other + (size_t)rep * 3 * n;
-        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < S.nvs; t += gridDim.x * blockDim.x) { const int a = S.vs[t].x; fo[a] = 0; fo[n + a] = 0; fo[2 * (size_t)n + a] = 0; }
-        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < S.nfixed; t += gridDim.x * blockDim.x) { const int a = S.fixed[t]; fo[a] = 0; fo[n + a] = 0; fo[2 * (size_t)n + a] = 0; }
     }
     if (cmr) {   // this workgroup's share of the new momentum, for the next step (the other parity: nobody reads it during this kernel)
         cell_block_sum(mom, sh);
