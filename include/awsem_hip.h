@@ -354,7 +354,12 @@ int awsem_remd_state(awsem_handle h, int32_t* ladder_index, int64_t* attempted, 
  * Limits: replica-resident handles only (AWSEM_ESTATE on a cell-list handle); 256 + n_replicas x (pair-list entries
  * reserved per replica) x 4 bytes must fit the array, else AWSEM_ELIMIT with the numbers in awsem_last_error().
  * All calls on one GPU share the one array (it keeps the previous call's lists): calls that overlap in time on the same
- * GPU -- two streams, two handles, two host threads -- race; serialise them. */
+ * GPU -- two streams, two handles, two host threads -- race; serialise them.
+ * Errors: argument and size errors are returned before anything is queued.  DEVICE-side conditions are NOT reported on this path:
+ * the status word the kernel writes lives in the static array, is cleared by the call's memset node and is read by nobody (reading
+ * it would be a copy and a synchronisation); the only condition it can hold for an energy evaluation is a pair-list overflow, which
+ * the list capacities (= the number of candidate pairs) rule out.  The caller's current device is left as it was found.
+ * Safe under stream capture (hipStreamBeginCapture ... EndCapture, replayed with hipGraphLaunch): tests/test_zz_no_alloc.py. */
 #define AWSEM_NOALLOC_SCRATCH_BYTES (32u << 20)
 int awsem_energy_by_group_noalloc(awsem_handle h, int n_replicas, const double* d_xyz, double* d_energy,
                                   void* hip_stream);

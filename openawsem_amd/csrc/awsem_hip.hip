@@ -16,6 +16,7 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <atomic>
 #include <limits>
 #include <map>
 
@@ -30,7 +31,7 @@
 // g_noalloc_ptr[device], and only that pointer is ever handed to a kernel or a memset.
 static __device__ __align__(256) unsigned char scratch[AWSEM_NOALLOC_SCRATCH_BYTES];
 #define AWSEM_MAX_DEVICES 64
-static void* g_noalloc_ptr[AWSEM_MAX_DEVICES] = {};
+static std::atomic<void*> g_noalloc_ptr[AWSEM_MAX_DEVICES] = {};   // two threads finalizing handles on one GPU look up the same address: either store is right
 
 namespace {
 
@@ -242,7 +243,7 @@ public:
         if (cell_mode_) { cell_evaluate(true, mask, 0, e, nullptr); return; }
         const bool reuse = query_reuse();
         HIP_TRY(hipEventRecord(ev0_, stream_));
-        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, 0);
+        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, 0, (double*)nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1_, stream_));
         HIP_TRY(hipMemcpyAsync(e, dE_, sizeof(double) * nrep_ * AWSEM_NGROUPS, hipMemcpyDeviceToHost, stream_));
@@ -255,7 +256,7 @@ public:
         if (cell_mode_) { cell_evaluate(false, mask, redistribute, nullptr, f); return; }
         const bool reuse = query_reuse();
         HIP_TRY(hipEventRecord(ev0_, stream_));
-        hipLaunchKernelGGL((awsem_eval_kernel<false, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, redistribute, (double*)nullptr, dF_, (const double*)nullptr, (int)reuse, 0);
+        hipLaunchKernelGGL((awsem_eval_kernel<false, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, redistribute, (double*)nullptr, dF_, (const double*)nullptr, (int)reuse, 0, (double*)nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1_, stream_));
         HIP_TRY(hipMemcpyAsync(f, dF_, sizeof(double) * 3 * natoms_ * nrep_, hipMemcpyDeviceToHost, stream_));
@@ -310,8 +311,8 @@ public:
             return;
         }
         const bool reuse = query_reuse();
-        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, 0);
-        hipLaunchKernelGGL(awsem_group_sum_kernel, dim3((nrep_ + 255) / 256), dim3(256), 0, stream_, (const double*)dE_, mask, out, nrep_);
+        // the sum over the masked groups comes out of the energy kernel itself (one launch fewer per exchange)
+        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, 0, out);
         HIP_TRY(hipGetLastError());
     }
     void remd_sweep(const double* d_all, int64_t iteration) override {
@@ -462,7 +463,7 @@ public:
             const bool reuse = query_reuse();
             // one replica's energies (what StateDataReporter prints) are one workgroup; the other rows of the slot are left as NaN
             const int first = energy_replica >= 0 ? energy_replica : 0, count = energy_replica >= 0 ? 1 : nrep_;
-            hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(count), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, first);
+            hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(count), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, first, (double*)nullptr);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(sn.e + (size_t)first * AWSEM_NGROUPS, dE_ + (size_t)first * AWSEM_NGROUPS, sizeof(double) * count * AWSEM_NGROUPS, hipMemcpyDeviceToHost, stream_));
         }
@@ -518,7 +519,7 @@ public:
     // No hipMalloc / hipFree / host copy / synchronisation in here: one memset node and one kernel on the caller's stream.
     void energy_noalloc(int nrep, const double* d_xyz, double* d_energy, hipStream_t stream) override {
         if (cell_mode_) throw StateError{"energy_by_group_noalloc: this handle runs on the cell-list path (the system does not fit the LDS of one CU); use awsem_energy_by_group"};
-        unsigned char* base = device_ < AWSEM_MAX_DEVICES ? (unsigned char*)g_noalloc_ptr[device_] : nullptr;
+        unsigned char* base = device_ < AWSEM_MAX_DEVICES ? (unsigned char*)g_noalloc_ptr[device_].load(std::memory_order_acquire) : nullptr;
         if (!base) throw StateError{"energy_by_group_noalloc: no scratch address for this device (finalize did not run here)"};
         const unsigned long long need = 256ull + (unsigned long long)nrep * (unsigned long long)dsys_.list_stride * 4ull;
         if (need > AWSEM_NOALLOC_SCRATCH_BYTES) {
@@ -528,14 +529,18 @@ public:
                      (unsigned)AWSEM_NOALLOC_SCRATCH_BYTES, (unsigned long long)((AWSEM_NOALLOC_SCRATCH_BYTES - 256ull) / ((unsigned long long)dsys_.list_stride * 4ull)));
             throw std::string(msg);
         }
-        HIP_TRY(hipSetDevice(device_));
+        int caller_device = device_;                 // the caller's current device is left as it was found (no allocation in either call)
+        HIP_TRY(hipGetDevice(&caller_device));
+        if (caller_device != device_) HIP_TRY(hipSetDevice(device_));
         DevSys<real> S = dsys_;                      // the handle's descriptors, with the lists and the status word moved into the static array
         S.status = (int*)base;
         S.lists = (unsigned*)(base + 256);
         HIP_TRY(hipMemsetAsync(base, 0, 256, stream));   // the status word must start at zero; the lists are written before they are read
         hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep), dim3(block_), lds_eval_, stream, S, (const real*)nullptr, 0xffffffffu, 0,
-                           d_energy, (double*)nullptr, d_xyz, 0, 0);
-        HIP_TRY(hipGetLastError());
+                           d_energy, (double*)nullptr, d_xyz, 0, 0, (double*)nullptr);
+        const hipError_t launched = hipGetLastError();
+        if (caller_device != device_) (void)hipSetDevice(caller_device);
+        HIP_TRY(launched);
     }
 
 private:
@@ -929,10 +934,10 @@ static HostSystem renumbered(const HostSystem& H, const std::vector<int>& to) {
 
 template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     HIP_TRY(hipSetDevice(device_));
-    if (device_ < AWSEM_MAX_DEVICES && !g_noalloc_ptr[device_]) {   // set-up: this device's copy of the static scratch array
+    if (device_ < AWSEM_MAX_DEVICES && !g_noalloc_ptr[device_].load(std::memory_order_acquire)) {   // set-up: this device's copy of the static scratch array
         void* p = nullptr;
         HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
-        g_noalloc_ptr[device_] = p;
+        g_noalloc_ptr[device_].store(p, std::memory_order_release);
     }
     host_ = &H0;
     DevSys<real> S;

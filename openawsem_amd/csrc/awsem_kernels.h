@@ -1493,7 +1493,8 @@ __global__ AWSEM_BOUNDS(real) void awsem_eval_kernel(const DevSys<real> S, const
                                   double* __restrict__ e_out /* [R][32] or null */, double* __restrict__ f_out /* [R][natoms][3] or null */,
                                   const double* __restrict__ xyz_aos /* null, or [R][natoms][3] in the caller's atom order instead of `pos` */,
                                   int reuse /* S.lists are the lists the last step launch left for these very positions: walk them instead of building */,
-                                  int rep0 /* first replica of the launch (a grid of one workgroup evaluates one replica of the ensemble) */) {
+                                  int rep0 /* first replica of the launch (a grid of one workgroup evaluates one replica of the ensemble) */,
+                                  double* __restrict__ e_sum /* null, or [R]: the sum over the masked groups (what awsem_group_sum_kernel makes of e_out) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = (int)blockIdx.x + rep0;
     Lds<real> L = carve_lds((real)0, smem, lds_shape(S), false);
@@ -1552,6 +1553,11 @@ __global__ AWSEM_BOUNDS(real) void awsem_eval_kernel(const DevSys<real> S, const
         }
     }
     if (ENERGY && e_out && threadIdx.x < AWSEM_NGROUPS) e_out[(size_t)rep * AWSEM_NGROUPS + threadIdx.x] = fixed_to_double(L.eg[threadIdx.x]);
+    if (ENERGY && e_sum && threadIdx.x == 0) {   // groups in ascending order, as awsem_group_sum_kernel and the host sum them: the same double
+        double s = 0;
+        for (int g = 0; g < AWSEM_NGROUPS; g++) if ((mask >> g) & 1u) s += fixed_to_double(L.eg[g]);
+        e_sum[rep] = s;
+    }
 }
 
 // Pair-list dump for awsem_neighbors: builds the lists of the terms in `mask` and writes the per-list counts.

@@ -26,6 +26,12 @@ class _Hip:
         self.lib.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
         self.lib.hipStreamSynchronize.argtypes = [C.c_void_p]
         self.lib.hipStreamDestroy.argtypes = [C.c_void_p]
+        self.lib.hipStreamBeginCapture.argtypes = [C.c_void_p, C.c_int]
+        self.lib.hipStreamEndCapture.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        self.lib.hipGraphInstantiate.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        self.lib.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.hipGraphExecDestroy.argtypes = [C.c_void_p]
+        self.lib.hipGraphDestroy.argtypes = [C.c_void_p]
         self.bufs = []
 
     def ok(self, rc):
@@ -94,6 +100,23 @@ def test_noalloc_entry_point_equals_energy_by_group(precision, monkeypatch):
     hip.ok(hip.lib.hipStreamSynchronize(None))
     got3 = hip.to_host(e3, (n3, 32))
     assert np.array_equal(got3[:n1], want1) and np.isfinite(got3).all()
+
+    # under stream capture (what the entry point is for): captured once, replayed twice, the output poisoned in between
+    x4, e4 = hip.to_device(traj[:n1]), nan(n1)
+    graph, exe = C.c_void_p(), C.c_void_p()
+    hip.ok(hip.lib.hipStreamBeginCapture(stream, 1))                     # hipStreamCaptureModeThreadLocal
+    gpu.energy_by_group_noalloc(n1, x4.value, e4.value, stream.value)
+    hip.ok(hip.lib.hipStreamEndCapture(stream, C.byref(graph)))
+    hip.ok(hip.lib.hipGraphInstantiate(C.byref(exe), graph, None, None, 0))
+    assert np.isnan(hip.to_host(e4, (n1, 32))).all()                     # capturing ran nothing
+    for _ in range(2):
+        hip.ok(hip.lib.hipGraphLaunch(exe, stream))
+        hip.ok(hip.lib.hipStreamSynchronize(stream))
+        assert np.array_equal(hip.to_host(e4, (n1, 32)), want1)
+        poison = np.full((n1, 32), np.nan)
+        hip.ok(hip.lib.hipMemcpy(e4, poison.ctypes.data_as(C.c_void_p), poison.nbytes, 1))
+    hip.ok(hip.lib.hipGraphExecDestroy(exe))
+    hip.ok(hip.lib.hipGraphDestroy(graph))
 
     # beyond the static array: a clear error, nothing launched
     with pytest.raises(_capi.AwsemError) as err:
