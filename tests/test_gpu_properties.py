@@ -169,3 +169,55 @@ def test_exploding_forces_are_reported_not_wrapped(monkeypatch):
     with pytest.raises(_capi.AwsemError, match="fixed-point accumulators"):
         ctx.step(1, [300.0], 0.002, 1.0, 1)
         ctx.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cell", [False, True])
+def test_snapshot_returns_what_the_synchronous_queries_return(cell, monkeypatch):
+    """awsem_snapshot_begin / _end (include/awsem_hip.h): the asynchronous reads behind the reporters of scripts/mm_run.py:157-164.  A
+    snapshot is taken BEHIND the launches already queued and is not disturbed by launches queued after it: energies (all replicas, or
+    one replica alone with the others NaN), kinetic energies, one replica's positions and the ensemble state must equal, bit for bit,
+    what awsem_energy / awsem_kinetic_energy / awsem_get_positions / awsem_get_state return at the same point -- on both kernel paths,
+    with both slots in flight, and a slot cannot be begun twice."""
+    if cell:
+        monkeypatch.setenv("AWSEM_FORCE_CELL", "1")
+    else:
+        monkeypatch.delenv("AWSEM_FORCE_CELL", raising=False)
+    oa, traj, _ = golden_system("1ubq")
+    R = 4
+    T = np.linspace(300.0, 600.0, R)
+
+    def fresh():
+        ctx = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=R, precision=0)
+        oa.system.upload(ctx)
+        for r in range(R):
+            ctx.set_positions(traj[r], replica=r)
+        ctx.set_velocities_to_temperature(T, 3)
+        ctx.step(25, T, 0.002, 1.0, 9)
+        return ctx
+
+    # reference: synchronous queries after 25 and after 50 steps
+    ctx = fresh()
+    want = []
+    for _ in range(2):
+        want.append(dict(e=ctx.energy(), e22=ctx.energy(1 << 22), ke=ctx.kinetic_energy(), x2=ctx.get_positions(2), state=ctx.get_state()))
+        ctx.step(25, T, 0.002, 1.0, 9)
+    ctx.close()
+
+    ctx = fresh()
+    ctx.snapshot_begin(0, 0xFFFFFFFF, -1, 2, True)           # after 25 steps: all replicas' energies, replica 2, the state
+    with pytest.raises(_capi.AwsemError):
+        ctx.snapshot_begin(0)                                 # the slot is taken
+    ctx.step(25, T, 0.002, 1.0, 9)                            # queued behind the snapshot
+    ctx.snapshot_begin(1, 1 << 22, 1, 2, False)               # after 50 steps: the contact energy of replica 1 alone
+    ctx.step(25, T, 0.002, 1.0, 9)
+    a = ctx.snapshot_end(0, energy=True, replica_positions=True, state=True)
+    b = ctx.snapshot_end(1, energy=True, replica_positions=True, state=False)
+    with pytest.raises(_capi.AwsemError):
+        ctx.snapshot_end(1)                                   # nothing pending there any more
+    assert np.array_equal(a["energy"], want[0]["e"]) and np.array_equal(a["kinetic"], want[0]["ke"])
+    assert np.array_equal(a["positions"], want[0]["x2"])
+    assert np.array_equal(a["state"][0], want[0]["state"][0]) and np.array_equal(a["state"][1], want[0]["state"][1])
+    assert b["energy"][1] == want[1]["e22"][1] and np.isnan(np.delete(b["energy"], 1)).all() if not cell else np.array_equal(b["energy"], want[1]["e22"])
+    assert np.array_equal(b["kinetic"], want[1]["ke"]) and np.array_equal(b["positions"], want[1]["x2"])
+    ctx.close()
