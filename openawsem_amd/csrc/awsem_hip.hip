@@ -362,7 +362,9 @@ public:
         if ((dsys_.prio & 0xff) == 3 && place_every_ > 0 && launch_ > 0 && launch_ % place_every_ == 0 && nrep_ <= 8192)   // deal the replicas to the CUs anew
             hipLaunchKernelGGL(awsem_place_kernel, dim3(1), dim3(1024), (size_t)nrep_ * sizeof(int), stream_, dsys_.prof, nrep_, dsys_.pace_group);
         const bool reuse = list_reuse_ && lists_valid_ && skin_ <= lists_skin_;
-        hipLaunchKernelGGL(awsem_step_kernel<real>, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, step_T_, nsteps, dt, friction,
+        if (step_lean_) hipLaunchKernelGGL((awsem_step_kernel<real, true>), dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, step_T_, nsteps, dt, friction,
+                                           (unsigned long long)seed, (long long)step0, launch_++, (int)reuse);
+        else hipLaunchKernelGGL((awsem_step_kernel<real, false>), dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, step_T_, nsteps, dt, friction,
                            (unsigned long long)seed, (long long)step0, launch_++, (int)reuse);
         // the skin the lists counted after this launch were built under: lists carried in from the previous launch carry ITS skin
         const double built_skin = reuse ? std::max(skin_, lists_skin_) : skin_;
@@ -761,7 +763,7 @@ private:
     // positions since (every place that sets cell_stale_), or the skin has grown: lists built with a larger skin stay valid under a
     // smaller one (the rebuild test only gets stricter), not the other way round.  Energy / force / neighbour queries build their lists
     // in a buffer of their own (lists_eval_), so a reporter between two launches costs the dynamics nothing.  AWSEM_LIST_REUSE=0: off.
-    bool lists_valid_ = false, list_reuse_ = true, query_reuse_ = true;
+    bool lists_valid_ = false, list_reuse_ = true, query_reuse_ = true, step_lean_ = false;
     double lists_skin_ = 0;
     unsigned* lists_eval_ = nullptr;
     // Energy / force queries walk the pair lists the last step launch left in device memory when those are still the lists of the stored
@@ -1615,7 +1617,14 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     step_ok_ = lds_step_ <= lds_max;   // energies/forces need less LDS than dynamics (no velocities, no list reference positions)
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<true, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<false, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
-    if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
+    if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
+    if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
+    {   // the lean instantiation of the step kernel (evaluate_terms<LEAN>): none of the rarer term shapes present
+        bool lean = S.n_gauss == 0 && S.n_cv == 0 && S.n_helical == 0 && S.n_memb == 0 && S.n_contact <= 1 && (S.n_rama == 0 || S.ramam.n > 0);
+        for (int t = 0; t < S.n_fm; t++) lean = lean && S.fm[t].nbundles > 0;
+        step_lean_ = lean && !(getenv("AWSEM_STEP_LEAN") && atoi(getenv("AWSEM_STEP_LEAN")) == 0);
+        if (getenv("AWSEM_INFO")) fprintf(stderr, "[awsem] step kernel: %s instantiation\n", step_lean_ ? "lean" : "full");
+    }
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_minimize_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_list_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     // Workgroup size: the waves a CU can hold at this kernel's register budget (16) divided among the replicas whose LDS

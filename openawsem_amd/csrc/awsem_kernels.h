@@ -1315,29 +1315,33 @@ template <class V> __device__ __forceinline__ void build_lists(const DevSys<type
 // STEP (the Langevin kernel): the Ramachandran and chirality terms move from the first phase to the second, and with
 // `fused_vs` the first phase also places the virtual sites -- its other work (density, fragment memory) reads massive
 // particles only (DevSys::fuse_vs), so the sites need no phase and no barrier of their own.
-template <bool ENERGY, bool STEP = false, class V> __device__ __forceinline__ void evaluate_terms(const DevSys<typename V::real_t>& S, const V& L, unsigned mask, bool fused_vs AWSEM_STAMP_ARG) {
+// LEAN: the step kernel's second instantiation for systems that hold none of the rarer term shapes -- Gaussian bonds and collective
+// variables, helical, membrane / external fields, a second contact term, unbundled fragment memory, unmerged Ramachandran lists (the
+// default forces_setup.py list qualifies; Engine::finalize checks).  The code for them is not compiled in, which the register
+// allocator of the one big step kernel feels.
+template <bool ENERGY, bool STEP = false, bool LEAN = false, class V> __device__ __forceinline__ void evaluate_terms(const DevSys<typename V::real_t>& S, const V& L, unsigned mask, bool fused_vs AWSEM_STAMP_ARG) {
     typedef typename V::real_t real;
     int first = -1;   // the contact term whose passes define the phases
     for (int t = S.n_contact - 1; t >= 0; t--) if (AWSEM_ON(S.contact[t])) first = t;
     const ContactD<real>* c0 = first >= 0 ? &S.contact[first] : nullptr;
     const int* satom0 = L.satom + (first >= 0 ? first : 0) * S.max_contact_sites;
-    const bool multi = S.n_contact > 1;
-    const bool bar = c0 || S.n_cv > 0;   // the phases need barriers: contact passes, or a collective variable's sum before its forces
+    const bool multi = !LEAN && S.n_contact > 1;
+    const bool bar = c0 || (!LEAN && S.n_cv > 0);   // the phases need barriers: contact passes, or a collective variable's sum before its forces
     if (c0 && multi) { stage_contact_gamma(*c0, L); __syncthreads(); }
     Rotor rotor(L.nthr);
     // phase A
     if (STEP && fused_vs) update_virtual_sites(S, L);
     if (c0) contact_density(*c0, L, satom0);
     for (int u = 0; u < S.n_fm; u++) if (AWSEM_ON(S.fm[u])) {
-        if (S.fm[u].nbundles) term_fm_bundled<ENERGY>(S.fm[u], L, rotor.next(S.fm[u].nbundles));
+        if (LEAN || S.fm[u].nbundles) term_fm_bundled<ENERGY>(S.fm[u], L, rotor.next(S.fm[u].nbundles));
         else term_fm<ENERGY>(S.fm[u], L, rotor.next(S.fm[u].n));
     }
     if (!STEP) {
-        if (S.ramam.n) { if (AWSEM_ON(S.ramam)) term_rama_merged<ENERGY>(S.ramam, L, rotor.next(S.ramam.n)); }
+        if (LEAN || S.ramam.n) { if (AWSEM_ON(S.ramam)) term_rama_merged<ENERGY>(S.ramam, L, rotor.next(S.ramam.n)); }
         else for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
         for (int u = 0; u < S.n_chi; u++) if (AWSEM_ON(S.chi[u])) term_chi<ENERGY>(S.chi[u], L, rotor.next(S.chi[u].n));
     }
-    for (int u = 0; u < S.n_gauss; u++) { const GaussD<real> d = S.gauss[u]; if (d.cv && AWSEM_ON(d)) cv_sum(d, L, rotor.next(d.n)); }
+    if (!LEAN) for (int u = 0; u < S.n_gauss; u++) { const GaussD<real> d = S.gauss[u]; if (d.cv && AWSEM_ON(d)) cv_sum(d, L, rotor.next(d.n)); }
     AWSEM_ARRIVE(4);
     if (bar || STEP) __syncthreads();
     AWSEM_STAMP(S, 4);
@@ -1346,16 +1350,16 @@ template <bool ENERGY, bool STEP = false, class V> __device__ __forceinline__ vo
     if (c0) contact_single<ENERGY>(*c0, L, satom0, rotor.next(c0->nsites));
     for (int u = 0; u < S.n_harm; u++) if (AWSEM_ON(S.harm[u])) term_harmonic<ENERGY>(S.harm[u], L, rotor.next(S.harm[u].n));
     for (int u = 0; u < S.n_dh; u++) if (AWSEM_ON(S.dh[u])) term_dh<ENERGY>(S.dh[u], L, rotor.next(S.dh[u].n));
-    for (int u = 0; u < S.n_gauss; u++) {
+    if (!LEAN) for (int u = 0; u < S.n_gauss; u++) {
         const GaussD<real> d = S.gauss[u];   // uniform: scalar loads
         if (!AWSEM_ON(d)) continue;
         if (d.cv) cv_apply<ENERGY>(d, L, rotor.next(d.n));
         else term_gauss<ENERGY>(d, L, rotor.next(d.n));
     }
-    for (int u = 0; u < S.n_helical; u++) if (AWSEM_ON(S.helical[u])) term_helical<ENERGY>(S.helical[u], L, rotor.next(S.helical[u].n));
-    for (int u = 0; u < S.n_memb; u++) if (AWSEM_ON(S.memb[u])) term_memb<ENERGY>(S.memb[u], L, rotor.next(S.memb[u].n));
+    if (!LEAN) for (int u = 0; u < S.n_helical; u++) if (AWSEM_ON(S.helical[u])) term_helical<ENERGY>(S.helical[u], L, rotor.next(S.helical[u].n));
+    if (!LEAN) for (int u = 0; u < S.n_memb; u++) if (AWSEM_ON(S.memb[u])) term_memb<ENERGY>(S.memb[u], L, rotor.next(S.memb[u].n));
     if (STEP) {
-        if (S.ramam.n) { if (AWSEM_ON(S.ramam)) term_rama_merged<ENERGY>(S.ramam, L, rotor.next(S.ramam.n)); }
+        if (LEAN || S.ramam.n) { if (AWSEM_ON(S.ramam)) term_rama_merged<ENERGY>(S.ramam, L, rotor.next(S.ramam.n)); }
         else for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
         for (int u = 0; u < S.n_chi; u++) if (AWSEM_ON(S.chi[u])) term_chi<ENERGY>(S.chi[u], L, rotor.next(S.chi[u].n));
     }
@@ -1363,7 +1367,7 @@ template <bool ENERGY, bool STEP = false, class V> __device__ __forceinline__ vo
     if (bar) __syncthreads();
     AWSEM_STAMP(S, 5);
     // phase C
-    if (threadIdx.x < S.n_cv) L.cv[threadIdx.x] = 0;   // read for the last time in phase B; the next evaluation starts from zero
+    if (!LEAN && threadIdx.x < S.n_cv) L.cv[threadIdx.x] = 0;   // read for the last time in phase B; the next evaluation starts from zero
     if (c0 && !(c0->flags & 2)) contact_pairs<ENERGY>(*c0, L, satom0);
     for (int u = 0; u < S.n_beta; u++) if (AWSEM_ON(S.beta[u]) && S.beta[u].list_owner) eval_beta<ENERGY>(S.beta[u], L);   // one walk per shared list
     AWSEM_ARRIVE(6);
@@ -1374,7 +1378,7 @@ template <bool ENERGY, bool STEP = false, class V> __device__ __forceinline__ vo
     for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) eval_excl<ENERGY>(S.excl[t], L);
     for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t]) && S.pap[t].list_owner) eval_pap<ENERGY>(S.pap[t], L);
     // further contact terms (e.g. a standalone burial term next to the contact term) reuse the density scratch
-    for (int t = first + 1; first >= 0 && t < S.n_contact; t++) {
+    if (!LEAN) for (int t = first + 1; first >= 0 && t < S.n_contact; t++) {
         const ContactD<real>& d = S.contact[t];
         if (!AWSEM_ON(d)) continue;   // uniform: S and mask are
         const int* satom = L.satom + t * S.max_contact_sites;
@@ -1889,7 +1893,7 @@ __device__ __forceinline__ void set_wave_priority(int p) {
 #ifndef AWSEM_STEP_ATTR
 #define AWSEM_STEP_ATTR
 #endif
-template <class real>
+template <class real, bool LEAN = false>
 __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, real* __restrict__ vel,
                                   const double* __restrict__ T, int nsteps, double dt, double friction, unsigned long long seed,
                                   long long step0, int launch, int reuse) {
@@ -2001,7 +2005,7 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
                 }
             }
         }
-        evaluate_terms<false, true>(S, L, 0xffffffffu, fuse && !rebuild AWSEM_STAMP_PASS);
+        evaluate_terms<false, true, LEAN>(S, L, 0xffffffffu, fuse && !rebuild AWSEM_STAMP_PASS);
         if (threadIdx.x == 0) L.flag[cur] = 0;   // read by everyone before the barriers of the evaluation; written again next step
         {
             float m = 0;
