@@ -1619,12 +1619,6 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<false, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
-    {   // the lean instantiation of the step kernel (evaluate_terms<LEAN>): none of the rarer term shapes present
-        bool lean = S.n_gauss == 0 && S.n_cv == 0 && S.n_helical == 0 && S.n_memb == 0 && S.n_contact <= 1 && (S.n_rama == 0 || S.ramam.n > 0);
-        for (int t = 0; t < S.n_fm; t++) lean = lean && S.fm[t].nbundles > 0;
-        step_lean_ = lean && !(getenv("AWSEM_STEP_LEAN") && atoi(getenv("AWSEM_STEP_LEAN")) == 0);
-        if (getenv("AWSEM_INFO")) fprintf(stderr, "[awsem] step kernel: %s instantiation\n", step_lean_ ? "lean" : "full");
-    }
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_minimize_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_list_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     // Workgroup size: the waves a CU can hold at this kernel's register budget (16) divided among the replicas whose LDS
@@ -1675,6 +1669,31 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         group_scan(dsys_.pap, dsys_.n_pap, H.pap, 2);
         if (dsys_.n_beta) dsys_.beta_dev = upload(std::vector<BetaD<real>>(dsys_.beta, dsys_.beta + dsys_.n_beta));
         if (dsys_.n_pap) dsys_.pap_dev = upload(std::vector<PapD<real>>(dsys_.pap, dsys_.pap + dsys_.n_pap));
+    }
+    {   // the lean instantiation of the step kernel (evaluate_terms<LEAN>): none of the rarer term shapes present
+        bool lean = dsys_.n_gauss == 0 && dsys_.n_cv == 0 && dsys_.n_helical == 0 && dsys_.n_memb == 0 && dsys_.n_contact <= 1 && (dsys_.n_rama == 0 || dsys_.ramam.n > 0);
+        for (int t = 0; t < dsys_.n_fm; t++) lean = lean && dsys_.fm[t].nbundles > 0;
+        for (int t = 0; t < dsys_.n_contact; t++) lean = lean && dsys_.contact[t].flags == 0;                       // the plain contact_term
+        for (int t = 0; t < dsys_.n_beta; t++) lean = lean && dsys_.beta[t].scan_mode == 0 && !dsys_.beta[t].fn;         // every term scans for itself, dense tables
+        for (int t = 0; t < dsys_.n_pap; t++) lean = lean && dsys_.pap[t].scan_mode == 0 && !dsys_.pap[t].fn;
+        lean = lean && dsys_.fuse_vs == 1 && dsys_.nmassive <= 2 * block_ && (dsys_.prio & 0xff) != 2;
+        step_lean_ = lean && !(getenv("AWSEM_STEP_LEAN") && atoi(getenv("AWSEM_STEP_LEAN")) == 0);
+        if (getenv("AWSEM_INFO")) {
+            fprintf(stderr, "[awsem] step kernel: %s instantiation", step_lean_ ? "lean" : "full");
+            if (!step_lean_) {
+                fprintf(stderr, " (gauss %d cv %d helical %d memb %d contact %d rama %d/%d fuse_vs %d massive %d block %d prio %d; contact flags", dsys_.n_gauss, dsys_.n_cv, dsys_.n_helical,
+                        dsys_.n_memb, dsys_.n_contact, dsys_.n_rama, dsys_.ramam.n, dsys_.fuse_vs, dsys_.nmassive, block_, dsys_.prio & 0xff);
+                for (int t = 0; t < dsys_.n_contact; t++) fprintf(stderr, " %d", dsys_.contact[t].flags);
+                fprintf(stderr, "; beta scan/fn");
+                for (int t = 0; t < dsys_.n_beta; t++) fprintf(stderr, " %d/%d", dsys_.beta[t].scan_mode, dsys_.beta[t].fn != nullptr);
+                fprintf(stderr, "; pap scan/fn");
+                for (int t = 0; t < dsys_.n_pap; t++) fprintf(stderr, " %d/%d", dsys_.pap[t].scan_mode, dsys_.pap[t].fn != nullptr);
+                fprintf(stderr, "; fm bundles");
+                for (int t = 0; t < dsys_.n_fm; t++) fprintf(stderr, " %d", dsys_.fm[t].nbundles);
+                fprintf(stderr, ")");
+            }
+            fprintf(stderr, "\n");
+        }
     }
 }
 

@@ -19,6 +19,7 @@
 // of wave order; a pair term adds +F to one atom and -F to the other bit for bit (Newton's third law is exact).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "awsem_device.h"
 
 typedef unsigned long long u64;
@@ -109,6 +110,7 @@ template <class real> __device__ __forceinline__ real dist2(const R3<real>& d) {
 // ------------------------------------------------------------------ views of one replica
 // Members every view carries besides coordinates and forces (the contact passes' scratch, energies, pair lists).
 template <class real> struct ViewCommon {
+    static constexpr bool lean = false;   // LdsLean: the view of the step kernel's lean instantiation (contact variants fold away: cflags)
     int nthr;                // threads of the workgroup.  blockDim.x is a 16-bit field of the implicit kernel arguments: every place the compiler
                              // rematerialises it costs a VECTOR load and a wait on it (there is no scalar 16-bit load); the LDS views read it once and
                              // pin it in a scalar register
@@ -224,6 +226,14 @@ template <> struct Lds<double> : ViewCommon<double>, SoaOps<double> {
     __device__ __forceinline__ R3<double> refpos(int a) const { return R3<double>{rx[a], ry[a], rz[a]}; }
     __device__ __forceinline__ void set_ref(int a, const R3<double>& r) const { rx[a] = r.x; ry[a] = r.y; rz[a] = r.z; }
 };
+
+// The view of the step kernel's lean instantiation: the same LDS image; `lean` tells the term bodies that the system holds only the plain
+// contact_term (flags 0), so the variants' branches are not compiled in (cflags).
+template <class real> struct LdsLean : Lds<real> {
+    static constexpr bool lean = true;
+    __device__ __forceinline__ explicit LdsLean(const Lds<real>& b) : Lds<real>(b) {}
+};
+template <class V> __device__ __forceinline__ int cflags(const ContactD<typename V::real_t>& d, const V&) { return V::lean ? 0 : d.flags; }
 
 // Energies are summed as 2^-32 fixed point from the first addition on (integer adds commute, so a sum does not
 // depend on the order in which a pair list happens to hold its entries): `Energy` is a per-lane accumulator.
@@ -801,7 +811,7 @@ template <class V> __device__ __forceinline__ void build_contact(const ContactD<
                 // the density counts |resid_i - resid_j| >= 2 whatever the chains (contactTerms.py:255); the pair energy
                 // counts different chains or |resid_i - resid_j| >= min_seq_sep (res_table, contactTerms.py:200-210)
                 const bool in_rho = dres >= 2 || dres <= -2;
-                const bool pair_e = !(d.flags & 2) && ((((info_i[u] ^ info_j[u]) >> 16) & 0x7ff) != 0 || dres >= d.min_seq_sep || -dres >= d.min_seq_sep);
+                const bool pair_e = !(cflags(d, L) & 2) && ((((info_i[u] ^ info_j[u]) >> 16) & 0x7ff) != 0 || dres >= d.min_seq_sep || -dres >= d.min_seq_sep);
                 const bool pass = v[u] && (in_rho || pair_e) && r2[u] < d.list_rc2;
                 const unsigned ty = (unsigned)(((info_i[u] >> 27) & 31) * 20 + ((info_j[u] >> 27) & 31));
                 list_append(e, cnt, d.ls.list_cap, status, pass,
@@ -843,7 +853,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void single_body(cons
     real rho = fixed_to_real(L.rho[i], (real)0);
     L.rhov[i] = sigmoid(-d.eta_s2 * (rho - d.rho0));
     real dE = 0, al = 0, dal = 0;
-    if (d.flags & 1) {
+    if (cflags(d, L) & 1) {
         real z = L.pos(atom).z - d.zc;
         real su = sigmoid(d.eta_sw2 * (z + d.z_m)), sv = sigmoid(d.eta_sw2 * (d.z_m - z));
         al = su + sv - (real)1;
@@ -852,14 +862,14 @@ template <bool ENERGY, class V> __device__ __forceinline__ void single_body(cons
         L.dalpha[i] = dal;
     }
     if (d.has_burial) {
-        int t = (d.flags & 16) ? i : (d.info[i] >> 27) & 31;   // index based: wells per site
+        int t = (cflags(d, L) & 16) ? i : (d.info[i] >> 27) & 31;   // index based: wells per site
         real dz = 0;
 #pragma unroll
         for (int m = 0; m < 3; m++) {
             real gb = d.bgamma[t * 3 + m];
             // tanh(a) + tanh(b) = 2 (sig(2a) + sig(2b) - 1)
             real sa = sigmoid(d.kappa2 * (rho - d.rho_lo[m])), sb = sigmoid(d.kappa2 * (d.rho_hi[m] - rho));
-            if (d.flags & 8) {   // hybrid contact: the wells blend water and membrane depths with the site's own alpha(z)
+            if (cflags(d, L) & 8) {   // hybrid contact: the wells blend water and membrane depths with the site's own alpha(z)
                 const real gm = d.bgamma[60 + t * 3 + m];
                 dz += -d.kb * (gm - gb) * (sa + sb - (real)1);
                 gb = ((real)1 - al) * gb + al * gm;
@@ -867,7 +877,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void single_body(cons
             if (ENERGY) e += (double)(-d.kb * gb * (sa + sb - (real)1));
             dE += -d.kb * gb * d.kappa2 * (sa * ((real)1 - sa) - sb * ((real)1 - sb));
         }
-        if (d.flags & 8) L.add_fz(atom, -dz * dal);
+        if (cflags(d, L) & 8) L.add_fz(atom, -dz * dal);
     }
     L.drho[i] = to_fixed(dE);
 }
@@ -881,7 +891,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void contact_single(c
 // E, dE/dr, dE/d(sigma_water) and, for the z-dependent variant, M - W (membrane minus water energy).
 template <class real> struct PairTerms { real E, dEdr, dEdsw, MW; };
 // INDEXED (index_based_contact_term): g0 is the global [3][nsites][nsites] table and ty = site_i * nsites + site_j.
-template <bool INDEXED = false, class real> __device__ __forceinline__ PairTerms<real> contact_pair_math(const ContactD<real>& d, const real* g0, int ty, real r, real sw, real aa) {
+template <bool INDEXED = false, bool PLAIN = false, class real> __device__ __forceinline__ PairTerms<real> contact_pair_math(const ContactD<real>& d, const real* g0, int ty, real r, real sw, real aa) {
     // one environment is three planes (direct, protein, water) of 400 type pairs, or of nsites^2 site pairs (INDEXED); the membrane
     // environment of a z-dependent term lies behind the water one
     const int plane = INDEXED ? d.nsites * d.nsites : 400;
@@ -892,7 +902,7 @@ template <bool INDEXED = false, class real> __device__ __forceinline__ PairTerms
     const real th1 = s1 * s2, dth1 = d.eta2 * th1 * (s2 - s1);
     const real th2 = s3 * s4, dth2 = d.eta2 * th2 * (s4 - s3);
     PairTerms<real> o;
-    if (!(d.flags & 1)) {
+    if (PLAIN || !(d.flags & 1)) {   // PLAIN: the caller knows the term is not z-dependent (lean step kernel)
         const real gd = g0[ty], gp = g0[plane + ty], gw = g0[2 * plane + ty];
         const real med = sw * gw + (one - sw) * gp;
         o.E = -d.k * (gd * th1 + th2 * med);
@@ -913,7 +923,7 @@ template <bool INDEXED = false, class real> __device__ __forceinline__ PairTerms
 }
 template <bool ENERGY, class V> __device__ __forceinline__ void pairs_body(const ContactD<typename V::real_t>& d, const V& L, int i, int j, int ty, int a, int b, bool v, Energy& e) {
     typedef typename V::real_t real;
-    const bool zdep = d.flags & 1;
+    const bool zdep = cflags(d, L) & 1;
     const real one = (real)1;
     const R3<real> dd = L.pos(a) - L.pos(b);
     const real r2 = dist2(dd);
@@ -923,8 +933,8 @@ template <bool ENERGY, class V> __device__ __forceinline__ void pairs_body(const
     const real si = L.rhov[i], sj = L.rhov[j];
     real ai = 0, aj = 0;
     if (zdep) { ai = L.alpha[i]; aj = L.alpha[j]; }
-    const PairTerms<real> t = (d.flags & 16) ? contact_pair_math<true>(d, d.gamma, pass ? i * d.nsites + j : 0, r, si * sj, ai * aj)
-                                             : contact_pair_math(d, L.gamma, ty, r, si * sj, ai * aj);
+    const PairTerms<real> t = (cflags(d, L) & 16) ? contact_pair_math<true>(d, d.gamma, pass ? i * d.nsites + j : 0, r, si * sj, ai * aj)
+                                             : contact_pair_math<false, V::lean>(d, L.gamma, ty, r, si * sj, ai * aj);
     if (pass) {
         if (ENERGY) e += (double)t.E;
         L.pair_force(a, b, dd.x, dd.y, dd.z, -t.dEdr * ir);
@@ -1007,7 +1017,7 @@ template <class real> __host__ __device__ __forceinline__ real hb_fn_value(const
     return (d >= 9 || other) ? s * f.g[2] : (real)0;
 }
 
-template <class V, class Desc> __device__ __forceinline__ void build_hbond(const Desc& d, const V& L, int* status) {
+template <bool LEAN = false, class V, class Desc> __device__ __forceinline__ void build_hbond(const Desc& d, const V& L, int* status) {
     typedef typename V::real_t real;
     AWSEM_WAVE_VARS;
     HbEntry<real>* e = (HbEntry<real>*)(L.lists + d.ls.list_off);
@@ -1020,7 +1030,7 @@ template <class V, class Desc> __device__ __forceinline__ void build_hbond(const
     for (int i = threadIdx.x; i < d.ndon; i += L.nthr) { const Int4 D = d.don[i]; sd[i] = (unsigned)D.x | ((unsigned)(resw == 3 ? D.w : D.z) << 16); }
     // which (donor residue, acceptor residue) pairs have a non-zero table entry: one bit each, staged as well when it fits
     const unsigned* nz = d.nzmask;
-    if (d.nz_lds && !d.fn) {
+    if (d.nz_lds && (LEAN || !d.fn)) {
         unsigned* sm = sd + d.ndon;
         const int words = (d.nres * d.nres + 31) >> 5;
         for (int i = threadIdx.x; i < words; i += L.nthr) sm[i] = d.nzmask[i];
@@ -1055,7 +1065,7 @@ template <class V, class Desc> __device__ __forceinline__ void build_hbond(const
                 HbEntry<real> ent;
                 ent.w0 = ent.w1 = ent.w2 = 0u; ent.c = (real)0;
                 if (pass[u]) {   // a surviving pair's record: the atoms of both sides and the coefficient, exactly as the pair bodies used to look them up
-                    if (d.fn) { const real v = hb_fn_value(*d.fn, dres, ares); pass[u] = v != (real)0; ent.c = d.fn->scale * v; }   // uniform branch
+                    if (!LEAN && d.fn) { const real v = hb_fn_value(*d.fn, dres, ares); pass[u] = v != (real)0; ent.c = d.fn->scale * v; }   // uniform branch
                     else {
                         const unsigned bit = (unsigned)(dres * d.nres + ares);
                         pass[u] = (nz[bit >> 5] >> (bit & 31)) & 1u;
@@ -1276,9 +1286,9 @@ template <class V> __device__ __forceinline__ void redistribute_forces(const Dev
 // Once per launch: contact site -> atom tables and (when the system has a single contact term) its gamma tables.
 template <class V> __device__ __forceinline__ void stage_contact_gamma(const ContactD<typename V::real_t>& d, const V& L) {
     typedef typename V::real_t real;
-    if (d.flags & (2 | 16)) return;   // burial only: no pair tables; index based: read from global memory
-    const int ng = (d.flags & 1) ? 2400 : 1200;
-    const real* src = d.gamma + ((d.flags & 1) ? 0 : d.env * 1200);
+    if (cflags(d, L) & (2 | 16)) return;   // burial only: no pair tables; index based: read from global memory
+    const int ng = (cflags(d, L) & 1) ? 2400 : 1200;
+    const real* src = d.gamma + ((cflags(d, L) & 1) ? 0 : d.env * 1200);
     for (int i = threadIdx.x; i < ng; i += L.nthr) L.gamma[i] = src[i];
 }
 template <class V> __device__ __forceinline__ void stage_tables(const DevSys<typename V::real_t>& S, const V& L) {
@@ -1291,15 +1301,15 @@ template <class V> __device__ __forceinline__ void stage_tables(const DevSys<typ
 #define AWSEM_ON(d) ((mask >> (d).group) & 1u)
 // (Re)build the pair list of every pair term in `mask` from the current positions.  The caller zeroes L.lcount
 // before (and synchronises), and synchronises after.
-template <class V> __device__ __forceinline__ void build_lists(const DevSys<typename V::real_t>& S, const V& L, unsigned mask) {
+template <bool LEAN = false, class V> __device__ __forceinline__ void build_lists(const DevSys<typename V::real_t>& S, const V& L, unsigned mask) {
     for (int t = 0; t < S.n_contact; t++) if (AWSEM_ON(S.contact[t])) build_contact(S.contact[t], L, L.satom + t * S.max_contact_sites, S.status);
     for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) build_excl(S.excl[t], L, S.status);
     for (int t = 0; t < S.n_beta; t++) if (AWSEM_ON(S.beta[t])) {
-        if (!S.beta[t].scan_mode) build_hbond(S.beta[t], L, S.status);
+        if (LEAN || !S.beta[t].scan_mode) build_hbond<LEAN>(S.beta[t], L, S.status);   // (LEAN: chosen only for systems whose terms scan for themselves, dense tables)
         else if (S.beta[t].list_owner) build_hbond_group(S.beta[t], S.beta_dev, t, S.n_beta, L, S.status);
     }
     for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) {
-        if (!S.pap[t].scan_mode) build_hbond(S.pap[t], L, S.status);
+        if (LEAN || !S.pap[t].scan_mode) build_hbond<LEAN>(S.pap[t], L, S.status);
         else if (S.pap[t].list_owner) build_hbond_group(S.pap[t], S.pap_dev, t, S.n_pap, L, S.status);
     }
     for (int i = threadIdx.x; i < S.natoms; i += L.nthr) L.zero_force(i);   // the builders staged their tables in the accumulators
@@ -1368,7 +1378,7 @@ template <bool ENERGY, bool STEP = false, bool LEAN = false, class V> __device__
     AWSEM_STAMP(S, 5);
     // phase C
     if (!LEAN && threadIdx.x < S.n_cv) L.cv[threadIdx.x] = 0;   // read for the last time in phase B; the next evaluation starts from zero
-    if (c0 && !(c0->flags & 2)) contact_pairs<ENERGY>(*c0, L, satom0);
+    if (c0 && !(cflags(*c0, L) & 2)) contact_pairs<ENERGY>(*c0, L, satom0);
     for (int u = 0; u < S.n_beta; u++) if (AWSEM_ON(S.beta[u]) && S.beta[u].list_owner) eval_beta<ENERGY>(S.beta[u], L);   // one walk per shared list
     AWSEM_ARRIVE(6);
     if (bar) __syncthreads();
@@ -1901,7 +1911,8 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
     AWSEM_STAMP_WALL(S, 0);
     const long long pace_t0 = (S.prio & 0xff) == 3 ? (long long)wall_clock64() : 0;
     const int natoms = S.natoms, rep = (S.prio & 0xff) == 3 ? uniform(pace_perm(S, (int)gridDim.x)[blockIdx.x]) : (int)blockIdx.x;
-    Lds<real> L = carve_lds((real)0, smem, lds_shape(S), true);
+    typedef typename std::conditional<LEAN, LdsLean<real>, Lds<real>>::type View;
+    View L(carve_lds((real)0, smem, lds_shape(S), true));
     L.lists = S.lists + (size_t)rep * S.list_stride;
     real* gp = pos + (size_t)rep * 3 * natoms;
     real* gv = vel + (size_t)rep * 3 * natoms;
@@ -1948,7 +1959,7 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
     AWSEM_STAMP_INIT;
     // The lists are rebuilt when a MASSIVE particle has moved further than skin/2 since the last build; lists screened on a
     // virtual site carry a correspondingly larger margin (host: list_margin), so the sites need no displacement test.
-    const bool fuse = S.fuse_vs != 0;
+    const bool fuse = LEAN || S.fuse_vs != 0;   // (the lean instantiation is only chosen for systems that fuse, and whose random numbers are drawn ahead: `pre` below)
     int boost_left = 0;
     for (int s = 0; s < nsteps; s++) {
         const int cur = s & 1;
@@ -1963,7 +1974,7 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
             if (boost_left > 0) { boost_left--; set_wave_priority(3); }
             else set_wave_priority(p < 0 ? 0 : p > 3 ? 3 : p);
         }
-        else if (S.prio == 2) set_wave_priority(prio_slot + (int)(wall_clock64() >> 11));   // by the clock instead (100 MHz: turns of 20 us); measured equal
+        else if (!LEAN && S.prio == 2) set_wave_priority(prio_slot + (int)(wall_clock64() >> 11));   // by the clock instead (100 MHz: turns of 20 us); measured equal
         if (cmr && threadIdx.x < 3) {
             L.cm[(cur ^ 1) * 3 + threadIdx.x] = 0;   // read for the last time in the previous step's integrator; this step's adds to it
             // the mean velocity this step removes, as reals, for every lane to pick up in the integrator (several barriers from here)
@@ -1978,7 +1989,7 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
             if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
             for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) { const int i = S.massive[k].atom; L.set_ref(i, L.pos(i)); }
             __syncthreads();
-            build_lists(S, L, 0xffffffffu);
+            build_lists<LEAN>(S, L, 0xffffffffu);
             AWSEM_ARRIVE(2);
             __syncthreads();
             AWSEM_STAMP(S, 2);
@@ -1990,7 +2001,7 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
         // (for up to two particles per lane; larger systems draw them in the integrator as before)
         real g_pre[2][3] = {{0, 0, 0}, {0, 0, 0}}, im_pre[2] = {0, 0}, ms_pre[2] = {0, 0};
         int at_pre[2] = {0, 0};
-        const bool pre = S.nmassive <= 2 * L.nthr;
+        const bool pre = LEAN || S.nmassive <= 2 * L.nthr;
         if (pre) {
 #pragma unroll
             for (int q = 0; q < 2; q++) {
