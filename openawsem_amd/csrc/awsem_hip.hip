@@ -1676,7 +1676,11 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         for (int t = 0; t < dsys_.n_contact; t++) lean = lean && dsys_.contact[t].flags == 0;                       // the plain contact_term
         for (int t = 0; t < dsys_.n_beta; t++) lean = lean && dsys_.beta[t].scan_mode == 0 && !dsys_.beta[t].fn;         // every term scans for itself, dense tables
         for (int t = 0; t < dsys_.n_pap; t++) lean = lean && dsys_.pap[t].scan_mode == 0 && !dsys_.pap[t].fn;
-        lean = lean && dsys_.fuse_vs == 1 && dsys_.nmassive <= 2 * block_ && (dsys_.prio & 0xff) != 2;
+        lean = lean && dsys_.fuse_vs == 1 && dsys_.nmassive <= 2 * block_ && (dsys_.prio & 0xff) != 2 && dsys_.remove_cm != 0;
+        // one term of a kind (the harmonic terms merged into one list), the beta / P-AP terms behind one shared list each, owned by the first
+        lean = lean && dsys_.n_harm <= 1 && dsys_.n_chi <= 1 && dsys_.n_fm <= 1 && dsys_.n_dh <= 1 && dsys_.n_excl <= 1 && dsys_.n_beta <= 3 && dsys_.n_pap <= 2;
+        for (int t = 1; t < dsys_.n_beta; t++) lean = lean && !dsys_.beta[t].list_owner;
+        for (int t = 1; t < dsys_.n_pap; t++) lean = lean && !dsys_.pap[t].list_owner;
         step_lean_ = lean && !(getenv("AWSEM_STEP_LEAN") && atoi(getenv("AWSEM_STEP_LEAN")) == 0);
         if (getenv("AWSEM_INFO")) {
             fprintf(stderr, "[awsem] step kernel: %s instantiation", step_lean_ ? "lean" : "full");

@@ -1302,13 +1302,13 @@ template <class V> __device__ __forceinline__ void stage_tables(const DevSys<typ
 // (Re)build the pair list of every pair term in `mask` from the current positions.  The caller zeroes L.lcount
 // before (and synchronises), and synchronises after.
 template <bool LEAN = false, class V> __device__ __forceinline__ void build_lists(const DevSys<typename V::real_t>& S, const V& L, unsigned mask) {
-    for (int t = 0; t < S.n_contact; t++) if (AWSEM_ON(S.contact[t])) build_contact(S.contact[t], L, L.satom + t * S.max_contact_sites, S.status);
-    for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) build_excl(S.excl[t], L, S.status);
-    for (int t = 0; t < S.n_beta; t++) if (AWSEM_ON(S.beta[t])) {
+    for (int t = 0; t < (LEAN ? (S.n_contact < 1 ? S.n_contact : 1) : S.n_contact); t++) if (AWSEM_ON(S.contact[t])) build_contact(S.contact[t], L, L.satom + t * S.max_contact_sites, S.status);
+    for (int t = 0; t < (LEAN ? (S.n_excl < 1 ? S.n_excl : 1) : S.n_excl); t++) if (AWSEM_ON(S.excl[t])) build_excl(S.excl[t], L, S.status);
+    for (int t = 0; t < (LEAN ? (S.n_beta < 3 ? S.n_beta : 3) : S.n_beta); t++) if (AWSEM_ON(S.beta[t])) {
         if (LEAN || !S.beta[t].scan_mode) build_hbond<LEAN>(S.beta[t], L, S.status);   // (LEAN: chosen only for systems whose terms scan for themselves, dense tables)
         else if (S.beta[t].list_owner) build_hbond_group(S.beta[t], S.beta_dev, t, S.n_beta, L, S.status);
     }
-    for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) {
+    for (int t = 0; t < (LEAN ? (S.n_pap < 2 ? S.n_pap : 2) : S.n_pap); t++) if (AWSEM_ON(S.pap[t])) {
         if (LEAN || !S.pap[t].scan_mode) build_hbond<LEAN>(S.pap[t], L, S.status);
         else if (S.pap[t].list_owner) build_hbond_group(S.pap[t], S.pap_dev, t, S.n_pap, L, S.status);
     }
@@ -1342,14 +1342,14 @@ template <bool ENERGY, bool STEP = false, bool LEAN = false, class V> __device__
     // phase A
     if (STEP && fused_vs) update_virtual_sites(S, L);
     if (c0) contact_density(*c0, L, satom0);
-    for (int u = 0; u < S.n_fm; u++) if (AWSEM_ON(S.fm[u])) {
+    for (int u = 0; u < (LEAN ? (S.n_fm < 1 ? S.n_fm : 1) : S.n_fm); u++) if (AWSEM_ON(S.fm[u])) {
         if (LEAN || S.fm[u].nbundles) term_fm_bundled<ENERGY>(S.fm[u], L, rotor.next(S.fm[u].nbundles));
         else term_fm<ENERGY>(S.fm[u], L, rotor.next(S.fm[u].n));
     }
     if (!STEP) {
         if (LEAN || S.ramam.n) { if (AWSEM_ON(S.ramam)) term_rama_merged<ENERGY>(S.ramam, L, rotor.next(S.ramam.n)); }
         else for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
-        for (int u = 0; u < S.n_chi; u++) if (AWSEM_ON(S.chi[u])) term_chi<ENERGY>(S.chi[u], L, rotor.next(S.chi[u].n));
+        for (int u = 0; u < (LEAN ? (S.n_chi < 1 ? S.n_chi : 1) : S.n_chi); u++) if (AWSEM_ON(S.chi[u])) term_chi<ENERGY>(S.chi[u], L, rotor.next(S.chi[u].n));
     }
     if (!LEAN) for (int u = 0; u < S.n_gauss; u++) { const GaussD<real> d = S.gauss[u]; if (d.cv && AWSEM_ON(d)) cv_sum(d, L, rotor.next(d.n)); }
     AWSEM_ARRIVE(4);
@@ -1358,8 +1358,8 @@ template <bool ENERGY, bool STEP = false, bool LEAN = false, class V> __device__
     // phase B
     rotor.acc = 0;
     if (c0) contact_single<ENERGY>(*c0, L, satom0, rotor.next(c0->nsites));
-    for (int u = 0; u < S.n_harm; u++) if (AWSEM_ON(S.harm[u])) term_harmonic<ENERGY>(S.harm[u], L, rotor.next(S.harm[u].n));
-    for (int u = 0; u < S.n_dh; u++) if (AWSEM_ON(S.dh[u])) term_dh<ENERGY>(S.dh[u], L, rotor.next(S.dh[u].n));
+    for (int u = 0; u < (LEAN ? (S.n_harm < 1 ? S.n_harm : 1) : S.n_harm); u++) if (AWSEM_ON(S.harm[u])) term_harmonic<ENERGY>(S.harm[u], L, rotor.next(S.harm[u].n));
+    for (int u = 0; u < (LEAN ? (S.n_dh < 1 ? S.n_dh : 1) : S.n_dh); u++) if (AWSEM_ON(S.dh[u])) term_dh<ENERGY>(S.dh[u], L, rotor.next(S.dh[u].n));
     if (!LEAN) for (int u = 0; u < S.n_gauss; u++) {
         const GaussD<real> d = S.gauss[u];   // uniform: scalar loads
         if (!AWSEM_ON(d)) continue;
@@ -1371,7 +1371,7 @@ template <bool ENERGY, bool STEP = false, bool LEAN = false, class V> __device__
     if (STEP) {
         if (LEAN || S.ramam.n) { if (AWSEM_ON(S.ramam)) term_rama_merged<ENERGY>(S.ramam, L, rotor.next(S.ramam.n)); }
         else for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
-        for (int u = 0; u < S.n_chi; u++) if (AWSEM_ON(S.chi[u])) term_chi<ENERGY>(S.chi[u], L, rotor.next(S.chi[u].n));
+        for (int u = 0; u < (LEAN ? (S.n_chi < 1 ? S.n_chi : 1) : S.n_chi); u++) if (AWSEM_ON(S.chi[u])) term_chi<ENERGY>(S.chi[u], L, rotor.next(S.chi[u].n));
     }
     AWSEM_ARRIVE(5);
     if (bar) __syncthreads();
@@ -1379,14 +1379,14 @@ template <bool ENERGY, bool STEP = false, bool LEAN = false, class V> __device__
     // phase C
     if (!LEAN && threadIdx.x < S.n_cv) L.cv[threadIdx.x] = 0;   // read for the last time in phase B; the next evaluation starts from zero
     if (c0 && !(cflags(*c0, L) & 2)) contact_pairs<ENERGY>(*c0, L, satom0);
-    for (int u = 0; u < S.n_beta; u++) if (AWSEM_ON(S.beta[u]) && S.beta[u].list_owner) eval_beta<ENERGY>(S.beta[u], L);   // one walk per shared list
+    for (int u = 0; u < (LEAN ? (S.n_beta < 1 ? S.n_beta : 1) : S.n_beta); u++) if (AWSEM_ON(S.beta[u]) && S.beta[u].list_owner) eval_beta<ENERGY>(S.beta[u], L);   // one walk per shared list
     AWSEM_ARRIVE(6);
     if (bar) __syncthreads();
     AWSEM_STAMP(S, 6);
     // phase D
     if (c0) contact_chain_rule(*c0, L, satom0);
-    for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) eval_excl<ENERGY>(S.excl[t], L);
-    for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t]) && S.pap[t].list_owner) eval_pap<ENERGY>(S.pap[t], L);
+    for (int t = 0; t < (LEAN ? (S.n_excl < 1 ? S.n_excl : 1) : S.n_excl); t++) if (AWSEM_ON(S.excl[t])) eval_excl<ENERGY>(S.excl[t], L);
+    for (int t = 0; t < (LEAN ? (S.n_pap < 1 ? S.n_pap : 1) : S.n_pap); t++) if (AWSEM_ON(S.pap[t]) && S.pap[t].list_owner) eval_pap<ENERGY>(S.pap[t], L);
     // further contact terms (e.g. a standalone burial term next to the contact term) reuse the density scratch
     if (!LEAN) for (int t = first + 1; first >= 0 && t < S.n_contact; t++) {
         const ContactD<real>& d = S.contact[t];
@@ -1949,7 +1949,7 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
         }
         book_displacement(&L.flag[0], m);
     }
-    const bool cmr = S.remove_cm != 0;
+    const bool cmr = LEAN || S.remove_cm != 0;   // (lean: chosen only with the centre-of-mass motion remover on, forces_setup.py's default)
     if (cmr) {   // momentum of the incoming velocities: what the first step removes (L.cm[0..2]; zeroed at the carve-up, a barrier ago)
         CmAcc<real> acc;
         for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) acc.add(M<real>::rcp(S.massive[k].inv_mass), L.vel(k));
