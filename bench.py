@@ -114,13 +114,13 @@ def _valu_view(args, folded, kernel_ms):
         return None
     valu = rows["SQ_INSTS_VALU"]
     per_cu = args.replicas / 256.0
-    cu_cycles_per_step = kernel_ms * 1e-3 / args.md_steps * 2.4e9
+    cu_cycles_per_step = kernel_ms * 1e-3 / (args.md_steps * args.stages) * 2.4e9
     out = {"insts_per_replica_step": valu, "busy_frac": per_cu * valu * 4.0 / 4.0 / cu_cycles_per_step,
            "source": src + " (rocprofv3 --pmc SQ_INSTS_VALU)", "clock_ghz_assumed": 2.4}
     ghz = rows.get("DERIVED_CLOCK_GHZ")
     if ghz:   # the clock the chip actually held under this kernel (GRBM_GUI_ACTIVE of the same counter pass): the 2.4 GHz figure is the boost ceiling
         out["clock_ghz_measured"] = ghz
-        out["busy_frac_at_measured_clock"] = per_cu * valu * 4.0 / 4.0 / (kernel_ms * 1e-3 / args.md_steps * ghz * 1e9)
+        out["busy_frac_at_measured_clock"] = per_cu * valu * 4.0 / 4.0 / (kernel_ms * 1e-3 / (args.md_steps * args.stages) * ghz * 1e9)
     return out
 
 
@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU (default: 1024 for 1r69, see WORKLOADS)")
     ap.add_argument("--md-steps", type=int, default=None, help="Langevin steps per launch (default 50; 200 for 2xov-remd)")
+    ap.add_argument("--stages", type=int, default=1, help="temperature stages of --md-steps steps per launch (awsem_step_stages; default 1 = one awsem_step per stage)")
     ap.add_argument("--precision", choices=["fp32", "fp64"], default="fp32")
     ap.add_argument("--workload", choices=list(WORKLOADS), default="1r69",
                     help="1r69: BASELINE.json configs[1], the configuration the metric is quoted on (default); 1r69-fraglib / t0958: "
@@ -267,6 +268,8 @@ def main():
             # when the ladder spans ranks) -> sweep kernel -> temperatures and velocity factors, nothing through the host
             ctx.step_remd(args.md_steps, 0.002, 1.0, seed)
             remd.exchange_on_device()
+        elif args.stages > 1:   # the same stages, several to a launch
+            ctx.step_stages(args.md_steps, np.stack([stage_T(it * args.stages + g) for g in range(args.stages)]), 0.002, 1.0, seed)
         else:
             ctx.step(args.md_steps, stage_T(it), 0.002, 1.0, seed)   # asynchronous: the launches queue up back to back
 
@@ -352,6 +355,18 @@ def main():
         t_full = all_ranks_max(time.perf_counter() - t0)
         legs["full_schedule"] = {"value": world * R * args.md_steps * stages / t_full, "seconds": t_full, "kernel_ms": ctx.last_kernel_ms(),
                                  "what": f"{stages} stages x {args.md_steps} steps, {Tstart:.0f} -> {Tend:.0f} K, fresh extended start: the default awsem_run schedule"}
+        # the same schedule the way awsem_run sends it (engine.Context._step): four stages to a launch, same trajectories bit for bit
+        STAGED = 4
+        ctx.set_positions(oa.pdb.positions, replica=-1)
+        ctx.set_velocities_to_temperature(np.full(R, Tstart), seed)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(0, stages, STAGED):
+            ctx.step_stages(args.md_steps, np.stack([np.full(R, Tstart + (Tend - Tstart) / stages * (i + g)) for g in range(STAGED)]), 0.002, 1.0, seed)
+        barrier()
+        t_fs = all_ranks_max(time.perf_counter() - t0)
+        legs["full_schedule_staged"] = {"value": world * R * args.md_steps * stages / t_fs, "seconds": t_fs, "kernel_ms": ctx.last_kernel_ms(),
+                                        "what": f"the same {stages} stages, {STAGED} to a launch (awsem_step_stages): what awsem_run sends"}
         ctx.set_positions(oa.pdb.positions, replica=-1)
         ctx.set_velocities_to_temperature(np.full(R, Tstart), seed)
         anneal_to_300K()
@@ -365,27 +380,35 @@ def main():
         t_c = all_ranks_max(time.perf_counter() - t0)
         legs["compact_300K"] = {"value": world * R * args.md_steps * args.steps / t_c, "seconds": t_c, "kernel_ms": ctx.last_kernel_ms(),
                                 "what": f"{args.steps} launches x {args.md_steps} steps at 300 K after an untimed 400 x 250-step anneal 800 -> 300 K (compact chains)"}
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(max(1, args.steps // STAGED)):
+            ctx.step_stages(args.md_steps, np.full((STAGED, R), 300.0), 0.002, 1.0, seed)
+        barrier()
+        t_cs = all_ranks_max(time.perf_counter() - t0)
+        legs["compact_300K_staged"] = {"value": world * R * args.md_steps * STAGED * max(1, args.steps // STAGED) / t_cs, "seconds": t_cs, "kernel_ms": ctx.last_kernel_ms(),
+                                       "what": f"{max(1, args.steps // STAGED)} launches x {STAGED} stages x {args.md_steps} steps at 300 K, continuing the leg above"}
         if not np.all(np.isfinite(ctx.energy())):
             sys.exit("non-finite potential energy after the schedule legs")
         force_eval["compact_300K"] = force_eval_leg(ctx, R)
 
     if rank == 0:
-        total_steps = world * R * args.md_steps * args.steps
+        total_steps = world * R * args.md_steps * args.steps * args.stages
         b_alg, n_real, n_fm = workloads.algorithmic_bytes_per_replica_step(oa)
         if synthetic:   # ~110 B per site and step on the neighbour-list path
             b_alg = 110 * oa.nres
         k_ms = float(np.mean(kernel_ms))
-        achieved = b_alg * R * args.md_steps / (k_ms * 1e-3) / 1e9
+        achieved = b_alg * R * args.md_steps * args.stages / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "MD steps/sec (all replicas)", "value": total_steps / elapsed, "unit": "replica-MD-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f64",
             "data": (f"synthetic ({kwargs.get('n_chains', 122)} rigidly rotated copies of the reference's 2lzm test structure on a jittered lattice, seed {kwargs.get('seed', 2026)})" if synthetic else
                      f"synthetic ({args.workload.split('-')[0]} start structure from the reference's examples/, Maxwell-Boltzmann velocities, Philox seed 2026)"),
-            "config": {"workload": description + (" -- timed at 300 K after an untimed anneal (compact chains)" if args.folded else ""), "replicas_per_gpu": R, "md_steps_per_launch": args.md_steps,
+            "config": {"workload": description + (" -- timed at 300 K after an untimed anneal (compact chains)" if args.folded else ""), "replicas_per_gpu": R, "md_steps_per_launch": args.md_steps * args.stages, "stages_per_launch": args.stages,
                        "residues": oa.nres, "atoms": oa.natoms, "parallelism": f"replica-sharded x{world}" + (" (REHEARSAL: ranks share GPUs, gloo collectives)" if args.share_gpu and world > 1 else "")},
             # the whole MD step (forces + virtual sites + list upkeep + Langevin update) per replica, from the step kernel's own time
-            "md_step_us_per_replica_step": k_ms * 1e3 / (R * args.md_steps),
+            "md_step_us_per_replica_step": k_ms * 1e3 / (R * args.md_steps * args.stages),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": _measured_traffic(args, oa), "kernel": "cell-list step (kernel sequence)" if synthetic else "awsem_step_kernel<float>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_replica_step": b_alg,
@@ -409,6 +432,8 @@ def main():
             # the whole-schedule truth next to the headline: the driver-parsed line carries all three rates
             out["value_full_schedule"] = legs["full_schedule"]["value"]
             out["value_compact_300K"] = legs["compact_300K"]["value"]
+            out["value_full_schedule_staged"] = legs["full_schedule_staged"]["value"]
+            out["value_compact_300K_staged"] = legs["compact_300K_staged"]["value"]
             out["legs"] = legs
             vc = _valu_view(args, True, legs["compact_300K"]["kernel_ms"])
             if vc is not None:

@@ -287,6 +287,14 @@ int awsem_neighbors(awsem_handle h, int replica, int kind, int index, double ski
  * T_kelvin is per replica (integrator.setTemperature); all terms (every group) drive the dynamics. */
 int awsem_step(awsem_handle h, int nsteps, const double* T_kelvin, double dt_ps, double friction_per_ps,
                uint64_t seed);
+/* The annealing loop of scripts/mm_run.py:171-175 -- `for i in range(n): integrator.setTemperature(T_i); simulation.step(k)` -- as ONE
+ * call: n_stages stages of steps_per_stage steps, T_kelvin[stage][replica].  The trajectory is bit for bit the one the same sequence of
+ * awsem_step calls gives (the random numbers are a function of the step counter, the noise amplitude is set at each stage's first step);
+ * what goes is the launch boundary between the stages: state write-back and reload, the staging of the tables, and the wait for the
+ * slowest replica (1r69, 1024 replicas, stages of 50 steps: +4 % at four stages a launch).  At most 16 stages ride in one launch, longer
+ * schedules are split; the cell-list path runs the stages as awsem_step calls. */
+int awsem_step_stages(awsem_handle h, int n_stages, int steps_per_stage, const double* T_kelvin, double dt_ps,
+                      double friction_per_ps, uint64_t seed);
 int64_t awsem_step_count(awsem_handle h);
 int awsem_set_step_count(awsem_handle h, int64_t step);
 

@@ -83,6 +83,8 @@ _HIP_ONLY = {
     "remd_sweep": (C.c_int, ["H", C.c_void_p, C.c_int64]),
     "remd_state": (C.c_int, ["H", c_int_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_dbl_p]),
     "remd_set_mixing": (C.c_int, ["H", C.c_int]),
+    # several temperature stages in one launch: for the oracle the same thing IS the sequence of step calls (Context.step_stages)
+    "step_stages": (C.c_int, ["H", C.c_int, C.c_int, c_dbl_p, C.c_double, C.c_double, C.c_uint64]),
     # asynchronous snapshots for reporters: pinned host memory and stream events, nothing for the CPU oracle to mirror
     "snapshot_begin": (C.c_int, ["H", C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int]),
     "snapshot_end": (C.c_int, ["H", C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p]),
@@ -383,6 +385,19 @@ class Context:
     def step(self, nsteps, T, dt_ps, friction_per_ps, seed):
         T = np.broadcast_to(_f64(T), (self.n_replicas,)).copy()
         self._call("step", int(nsteps), _dp(T), float(dt_ps), float(friction_per_ps), C.c_uint64(int(seed)))
+
+    def step_stages(self, steps_per_stage, T_stages, dt_ps, friction_per_ps, seed):
+        """T_stages[stage][replica] (or [stage]): the stages of an annealing loop in one launch (awsem_step_stages); same trajectory as
+        one step() per stage, which is what the oracle library runs."""
+        T = _f64(T_stages)
+        if T.ndim == 1:
+            T = T[:, None]
+        T = np.ascontiguousarray(np.broadcast_to(T, (T.shape[0], self.n_replicas)))
+        if "step_stages" not in self.api.fn:
+            for row in T:
+                self.step(steps_per_stage, row, dt_ps, friction_per_ps, seed)
+            return
+        self._call("step_stages", int(T.shape[0]), int(steps_per_stage), _dp(T), float(dt_ps), float(friction_per_ps), C.c_uint64(int(seed)))
 
     def minimize(self, tolerance=10.0, max_iterations=0):
         """FIRE on the device for every replica at once (awsem_minimize); returns (iterations, rms_force) per replica."""

@@ -26,6 +26,7 @@
 #define AWSEM_MAX_GAUSS 16
 #define AWSEM_FIXED_SCALE 4294967296.0   // 2^32: forces, energies and densities are accumulated as int64 fixed point
 #define AWSEM_MAX_LISTS (AWSEM_MAX_EXCL + AWSEM_MAX_CONTACT + AWSEM_MAX_BETA + AWSEM_MAX_PAP)
+#define AWSEM_MAX_STAGES 16   // temperature stages in one step launch (awsem_step_stages splits longer schedules)
 
 // Every pair term (excl, contact, beta, pap) owns one Verlet pair list per replica: 32-bit entries in a per-replica
 // global buffer (`DevSys::lists + replica * list_stride + list_off`), at most `list_cap` of them (= the number of

@@ -100,6 +100,7 @@ struct EngineBase {
     virtual void energy_by_group(unsigned mask, double* e) = 0;
     virtual void forces(unsigned mask, int redistribute, double* f) = 0;
     virtual void step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) = 0;
+    virtual void step_stages(int nstages, int steps_per_stage, const double* T, double dt, double friction, uint64_t seed, int64_t step0) = 0;
     virtual void synchronize() = 0;
     virtual void kinetic_energy(double* ke) = 0;
     virtual void set_state_all(const double* xyz, const double* v) = 0;
@@ -195,7 +196,7 @@ public:
         for (void* p : allocs_) (void)hipFree(p);
         if (h_lmean_) (void)hipHostFree(h_lmean_);
         if (lmean_ev_) (void)hipEventDestroy(lmean_ev_);
-        for (int k = 0; k < NRING; k++) { if (ring0_[k]) (void)hipEventDestroy(ring0_[k]); if (ring1_[k]) (void)hipEventDestroy(ring1_[k]); if (ringT_[k]) (void)hipHostFree(ringT_[k]); }
+        for (int k = 0; k < NRING; k++) { if (ring0_[k]) (void)hipEventDestroy(ring0_[k]); if (ring1_[k]) (void)hipEventDestroy(ring1_[k]); if (ringT_[k]) (void)hipHostFree(ringT_[k]); if (ringS_[k]) (void)hipHostFree(ringS_[k]); }
         if (ev0_) (void)hipEventDestroy(ev0_);
         for (auto& sn : snap_) {
             if (sn.ev) (void)hipEventDestroy(sn.ev);
@@ -347,8 +348,20 @@ public:
         if (T_local) HIP_TRY(hipMemcpy(T_local, remd_T_, sizeof(double) * nrep_, hipMemcpyDeviceToHost));
     }
     void step(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) override { step_impl(nsteps, T, dt, friction, seed, step0); }
+    // nstages temperature stages of steps_per_stage steps in ONE launch (T: [stage][replica]): the trajectory of nstages step() calls,
+    // without the launch boundaries between them (state write-back and reload, table staging, and the wait for the slowest replica)
+    void step_stages(int nstages, int steps_per_stage, const double* T, double dt, double friction, uint64_t seed, int64_t step0) override {
+        if (cell_mode_ || !step_ok_ || nstages == 1) {   // the cell-list path (and the error path) stage by stage
+            for (int g = 0; g < nstages; g++) step_impl(steps_per_stage, T + (size_t)g * nrep_, dt, friction, seed, step0 + (int64_t)g * steps_per_stage);
+            return;
+        }
+        for (int g = 0; g < nstages; g += AWSEM_MAX_STAGES) {
+            const int n = std::min(AWSEM_MAX_STAGES, nstages - g);
+            step_impl(n * steps_per_stage, T + (size_t)g * nrep_, dt, friction, seed, step0 + (int64_t)g * steps_per_stage, n);
+        }
+    }
     // T == nullptr: the temperatures already on the device (replica exchange) drive the launch
-    void step_impl(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0) {
+    void step_impl(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0, int nstages = 1) {
         if (cell_mode_) { cell_step(nsteps, T, dt, friction, seed, step0); return; }
         if (!step_ok_) {
             char msg[256];
@@ -357,15 +370,19 @@ public:
             throw std::string(msg);
         }
         HIP_TRY(hipSetDevice(device_));
-        apply_skin(T);
-        begin_async(T);
+        if (nstages > 1) {   // the skin follows the hottest stage
+            std::vector<double> hot(T, T + nrep_);
+            for (int g = 1; g < nstages; g++) for (int r = 0; r < nrep_; r++) hot[r] = std::max(hot[r], T[(size_t)g * nrep_ + r]);
+            apply_skin(hot.data());
+        } else apply_skin(T);
+        begin_async(T, nstages);
         if ((dsys_.prio & 0xff) == 3 && place_every_ > 0 && launch_ > 0 && launch_ % place_every_ == 0 && nrep_ <= 8192)   // deal the replicas to the CUs anew
             hipLaunchKernelGGL(awsem_place_kernel, dim3(1), dim3(1024), (size_t)nrep_ * sizeof(int), stream_, dsys_.prof, nrep_, dsys_.pace_group);
         const bool reuse = list_reuse_ && lists_valid_ && skin_ <= lists_skin_;
         if (step_lean_) hipLaunchKernelGGL((awsem_step_kernel<real, true>), dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, step_T_, nsteps, dt, friction,
-                                           (unsigned long long)seed, (long long)step0, launch_++, (int)reuse);
+                                           (unsigned long long)seed, (long long)step0, launch_++, (int)reuse, nsteps / nstages);
         else hipLaunchKernelGGL((awsem_step_kernel<real, false>), dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, step_T_, nsteps, dt, friction,
-                           (unsigned long long)seed, (long long)step0, launch_++, (int)reuse);
+                           (unsigned long long)seed, (long long)step0, launch_++, (int)reuse, nsteps / nstages);
         // the skin the lists counted after this launch were built under: lists carried in from the previous launch carry ITS skin
         const double built_skin = reuse ? std::max(skin_, lists_skin_) : skin_;
         lists_valid_ = nsteps > 0;
@@ -588,10 +605,20 @@ private:
         return upload(t);
     }
     // start / end of an asynchronous launch: temperatures through a pinned ring buffer, events from the ring
-    void begin_async(const double* T) {
+    void begin_async(const double* T, int nstages = 1) {
         if (npend_ == NRING) synchronize();
         const int k = npend_;
         if (!ring0_[k]) { HIP_TRY(hipEventCreate(&ring0_[k])); HIP_TRY(hipEventCreate(&ring1_[k])); HIP_TRY(hipHostMalloc((void**)&ringT_[k], sizeof(double) * nrep_, hipHostMallocDefault)); }
+        if (nstages > 1) {   // (replica-resident path only.)  Several stages: the kernel reads a stage's temperature in the middle of its run, so
+            // the block goes to device memory -- a read of host memory there would stall the workgroup for microseconds, stage after stage
+            if (!ringS_[k]) HIP_TRY(hipHostMalloc((void**)&ringS_[k], sizeof(double) * nrep_ * AWSEM_MAX_STAGES, hipHostMallocDefault));
+            if (!dT_stages_) dT_stages_ = dalloc<double>((size_t)nrep_ * AWSEM_MAX_STAGES);
+            memcpy(ringS_[k], T, sizeof(double) * nrep_ * nstages);
+            HIP_TRY(hipMemcpyAsync(dT_stages_, ringS_[k], sizeof(double) * nrep_ * nstages, hipMemcpyHostToDevice, stream_));
+            step_T_ = dT_stages_;
+            HIP_TRY(hipEventRecord(ring0_[k], stream_));
+            return;
+        }
         // null: the temperatures are on the device already (replica exchange).  Otherwise the kernel reads them from this launch's
         // slot of pinned host memory itself (one double per workgroup): no copy between two launches on the stream
         step_T_ = dT_;
@@ -690,6 +717,8 @@ private:
     static constexpr int NRING = 32;
     hipEvent_t ring0_[NRING] = {}, ring1_[NRING] = {};
     double* ringT_[NRING] = {};
+    double* ringS_[NRING] = {};     // staged launches: [stage][replica] blocks (allocated at the first such launch)
+    double* dT_stages_ = nullptr;
     int npend_ = 0;
     std::vector<void*> allocs_;
     DevSys<real> dsys_;
@@ -2723,6 +2752,15 @@ int awsem_step(awsem_handle h, int nsteps, const double* T, double dt, double fr
     GUARD_BEGIN
     if (nsteps > 0) h->eng->step(nsteps, T, dt, friction, seed, h->step);
     h->step += nsteps;
+    return AWSEM_OK;
+    GUARD_END
+}
+int awsem_step_stages(awsem_handle h, int nstages, int steps_per_stage, const double* T, double dt, double friction, uint64_t seed) {
+    NEED_RUN(h);
+    if (nstages < 0 || steps_per_stage < 0 || !T || !(dt > 0) || friction < 0) return fail(AWSEM_EINVAL, "step_stages: bad arguments");
+    GUARD_BEGIN
+    if (nstages > 0 && steps_per_stage > 0) h->eng->step_stages(nstages, steps_per_stage, T, dt, friction, seed, h->step);
+    h->step += (int64_t)nstages * steps_per_stage;
     return AWSEM_OK;
     GUARD_END
 }

@@ -1906,7 +1906,7 @@ __device__ __forceinline__ void set_wave_priority(int p) {
 template <class real, bool LEAN = false>
 __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, real* __restrict__ vel,
                                   const double* __restrict__ T, int nsteps, double dt, double friction, unsigned long long seed,
-                                  long long step0, int launch, int reuse) {
+                                  long long step0, int launch, int reuse, int stage_len) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     AWSEM_STAMP_WALL(S, 0);
     const long long pace_t0 = (S.prio & 0xff) == 3 ? (long long)wall_clock64() : 0;
@@ -1924,7 +1924,11 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
     for (int i = threadIdx.x; i < S.max_contact_sites; i += L.nthr) L.rho[i] = 0;
     const double a_d = ::exp(-friction * dt);
     const real a = (real)a_d, fs = (real)(friction == 0.0 ? dt : (1.0 - a_d) / friction);
-    const real ns = (real)::sqrt(AWSEM_KB * T[rep] * (1.0 - a_d * a_d)), dtr = (real)dt;
+    // The launch runs nsteps / stage_len temperature stages back to back (awsem_step_stages: T is [stage][replica]); the noise
+    // amplitude is set at the first step of each, from the same expression a launch of that stage alone evaluates.
+    const real dtr = (real)dt;
+    real ns = 0;
+    int stage_next = 0;
     stage_tables(S, L);
     if (threadIdx.x < 2) L.flag[threadIdx.x] = 0;
     if (threadIdx.x == 0) L.flag[2] = __builtin_amdgcn_s_getreg((3 << 11) | 4);   // HW_ID[3:0]: wave 0's slot on its SIMD -- distinct among the replicas that share the CU (measured: 0..3 in dispatch order)
@@ -1964,6 +1968,10 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
     for (int s = 0; s < nsteps; s++) {
         const int cur = s & 1;
         const bool rebuild = (s == 0 && !reuse) || __uint_as_float(L.flag[cur]) > (float)S.skin_half2;   // uniform across the workgroup
+        if (s == stage_next) {
+            ns = (real)::sqrt(AWSEM_KB * T[rep] * (1.0 - a_d * a_d));
+            T += gridDim.x; stage_next += stage_len;
+        }
         if (S.prio == 1) set_wave_priority(prio_slot + s);   // this replica's turn at each of the four levels comes round every four steps
         else if (paced) {   // the same rotation, shifted by the replica's bias (dithered step by step, so a fractional bias acts as such)
             const int shift = (int)floorf(prio_bias + (float)(((unsigned)s * 2654435769u) >> 8) * (1.f / 16777216.f));

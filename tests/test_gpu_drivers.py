@@ -180,6 +180,34 @@ def test_reports_written_behind_the_launches_are_byte_identical(tmp_path, monkey
         assert np.array_equal(za["positions"], zb["positions"]) and np.array_equal(za["energies"], zb["energies"])
 
 
+def test_annealing_stages_sent_as_one_launch_write_the_same_files(tmp_path, monkeypatch):
+    """The annealing loop of scripts/mm_run.py:171-175 (set the temperature, step 50 times, 400 times over) reaches the library as
+    launches of up to AWSEM_STAGES_PER_LAUNCH stages (engine.Context._step / awsem_step_stages); report points, checkpoints and the end of
+    the run cut the blocks wherever they fall.  Every file must equal, byte for byte, the run that sends one launch per stage."""
+    from openawsem_amd.scripts import mm_run
+    d = tmp_path / "1r69"
+    shutil.copytree(data_path.data / "1r69", d, ignore=shutil.ignore_patterns("fraglib", "frags.mem"))
+    shutil.copy(d / "1r69.fasta", d / "crystal_structure.fasta")
+    seq = "".join(ln.strip() for ln in open(d / "1r69.fasta") if not ln.startswith(">"))
+    (d / "charge.txt").write_text("".join(f"{i} {1.0 if a in 'RK' else (-1.0 if a in 'DE' else 0.0)}\n" for i, a in enumerate(seq)))
+    outs = []
+    for stages in ("1", "4", "16"):
+        monkeypatch.setenv("AWSEM_STAGES_PER_LAUNCH", stages)
+        monkeypatch.chdir(d)
+        out = tmp_path / f"run_stages{stages}"
+        sim = mm_run.main(["1r69", "--to", str(out), "-s", "3000", "--tempStart", "700", "--tempEnd", "300", "--replicas", "8", "--seed", "13",
+                           "-f", os.path.join(os.path.dirname(mm_run.__file__), "forces_setup.py")])
+        assert sim.context._max_stages == int(stages) and not sim.context._pending
+        outs.append(out)
+    monkeypatch.delenv("AWSEM_STAGES_PER_LAUNCH", raising=False)
+    for other in outs[1:]:
+        for f in ("native.pdb", "movie.dcd", "output.log", "checkpnt.chk"):
+            a, b = (outs[0] / f).read_bytes(), (other / f).read_bytes()
+            assert len(a) > 100 and a == b, (f, other)
+        with np.load(outs[0] / "ensemble_final.npz") as za, np.load(other / "ensemble_final.npz") as zb:
+            assert np.array_equal(za["positions"], zb["positions"]) and np.array_equal(za["energies"], zb["energies"])
+
+
 def test_awsem_remd_runs_a_ladder_and_restarts(tmp_path, monkeypatch):
     """mm_remd.py of the reference delegates to openmmtools (absent here; its output.nc is not reproduced): outputs are
     checked for shape, label bookkeeping and restart ("parity unpinned"; the Metropolis rule itself is tested in test_ensemble.py)."""

@@ -55,6 +55,35 @@ def test_asynchronous_launches_equal_synchronised_ones():
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("lean", ["1", "0"])
+def test_stages_in_one_launch_equal_one_launch_per_stage(lean, monkeypatch):
+    """awsem_step_stages -- the annealing loop's stages in one launch, 16 at most -- gives bit for bit the trajectory of one awsem_step
+    per stage: 19 stages (a launch of 16 and one of 3) of 7 steps with per-replica temperatures, on both instantiations of the step
+    kernel; the step counter advances alike, and the caller's temperature block is free for reuse on return."""
+    monkeypatch.setenv("AWSEM_STEP_LEAN", lean)
+    oa, traj, _ = golden_system("1ubq")
+    T = np.stack([np.array([800.0 - 20.0 * g, 300.0 + 11.0 * g, 450.0]) for g in range(19)])
+    out = []
+    for staged in (False, True):
+        gpu = _ctx(oa.system, oa.natoms, R=3)
+        gpu.set_positions(traj[0])
+        gpu.compute_virtual_sites()
+        gpu.set_velocities_to_temperature([800.0, 300.0, 450.0], 11)
+        gpu.step(5, T[0], 0.002, 1.0, 11)           # lists in place, a step counter that is not zero
+        if staged:
+            block = T.copy()
+            gpu.step_stages(7, block, 0.002, 1.0, 11)
+            block[:] = -1.0
+        else:
+            for row in T:
+                gpu.step(7, row, 0.002, 1.0, 11)
+        assert gpu.step_count == 5 + 19 * 7
+        out.append([gpu.get_positions(r) for r in range(3)] + [gpu.get_velocities(r) for r in range(3)])
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(out[0][0], out[0][1])   # the replicas did run at their own temperatures
+
+
 def test_empty_and_tiny_systems():
     """Two bonded particles and a spectator, an empty bond list next to it: energies, forces and dynamics behave."""
     system = System(np.array([12.0, 12.0, 12.0]))
