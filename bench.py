@@ -355,7 +355,9 @@ def main():
         t_full = all_ranks_max(time.perf_counter() - t0)
         legs["full_schedule"] = {"value": world * R * args.md_steps * stages / t_full, "seconds": t_full, "kernel_ms": ctx.last_kernel_ms(),
                                  "what": f"{stages} stages x {args.md_steps} steps, {Tstart:.0f} -> {Tend:.0f} K, fresh extended start: the default awsem_run schedule"}
-        # the same schedule the way awsem_run sends it (engine.Context._step): four stages to a launch, same trajectories bit for bit
+        # the same schedule four stages to a launch (awsem_step_stages; same trajectories bit for bit): what engine.Context sends when the
+        # run reports less often than it changes the temperature (awsem_run --reportFrequency 200 and up; at the default, a report after
+        # every stage, each stage stays a launch of its own and the leg above is the one that applies)
         STAGED = 4
         ctx.set_positions(oa.pdb.positions, replica=-1)
         ctx.set_velocities_to_temperature(np.full(R, Tstart), seed)
@@ -366,7 +368,7 @@ def main():
         barrier()
         t_fs = all_ranks_max(time.perf_counter() - t0)
         legs["full_schedule_staged"] = {"value": world * R * args.md_steps * stages / t_fs, "seconds": t_fs, "kernel_ms": ctx.last_kernel_ms(),
-                                        "what": f"the same {stages} stages, {STAGED} to a launch (awsem_step_stages): what awsem_run sends"}
+                                        "what": f"the same {stages} stages, {STAGED} to a launch (awsem_step_stages): runs that report every {STAGED} stages or less often"}
         ctx.set_positions(oa.pdb.positions, replica=-1)
         ctx.set_velocities_to_temperature(np.full(R, Tstart), seed)
         anneal_to_300K()

@@ -176,6 +176,8 @@ class Context:
     # used to be a launch; now up to AWSEM_STAGES_PER_LAUNCH (default 4, at most 16) consecutive stages of equal length go out as ONE
     # (awsem_step_stages: same trajectory bit for bit, +4 % throughput).  The stages wait here until the block is full or anything else
     # wants the library handle: every access to `_ctx` sends them off first, so no query can see a state the queued steps have not reached.
+    # (A report point is such an access: a run that reports after every stage -- awsem_run's default, reportFrequency = steps / 400 --
+    # keeps one launch per stage; the blocks form when --reportFrequency spans several stages.)
     @property
     def _ctx(self):
         self._flush()
