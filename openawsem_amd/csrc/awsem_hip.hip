@@ -379,10 +379,13 @@ public:
         if ((dsys_.prio & 0xff) == 3 && place_every_ > 0 && launch_ > 0 && launch_ % place_every_ == 0 && nrep_ <= 8192)   // deal the replicas to the CUs anew
             hipLaunchKernelGGL(awsem_place_kernel, dim3(1), dim3(1024), (size_t)nrep_ * sizeof(int), stream_, dsys_.prof, nrep_, dsys_.pace_group);
         const bool reuse = list_reuse_ && lists_valid_ && skin_ <= lists_skin_;
-        if (step_lean_) hipLaunchKernelGGL((awsem_step_kernel<real, true>), dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, step_T_, nsteps, dt, friction,
-                                           (unsigned long long)seed, (long long)step0, launch_++, (int)reuse, nsteps / nstages);
-        else hipLaunchKernelGGL((awsem_step_kernel<real, false>), dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, step_T_, nsteps, dt, friction,
-                           (unsigned long long)seed, (long long)step0, launch_++, (int)reuse, nsteps / nstages);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, step_T_, nsteps, dt, friction,
+                               (unsigned long long)seed, (long long)step0, launch_++, (int)reuse, nsteps / nstages);
+        };
+        if (step_lean_ == 1) launch(awsem_step_kernel<real, 1>);
+        else if (step_lean_ == 2) launch(awsem_step_kernel<real, 2>);
+        else launch(awsem_step_kernel<real, 0>);
         // the skin the lists counted after this launch were built under: lists carried in from the previous launch carry ITS skin
         const double built_skin = reuse ? std::max(skin_, lists_skin_) : skin_;
         lists_valid_ = nsteps > 0;
@@ -792,7 +795,8 @@ private:
     // positions since (every place that sets cell_stale_), or the skin has grown: lists built with a larger skin stay valid under a
     // smaller one (the rebuild test only gets stricter), not the other way round.  Energy / force / neighbour queries build their lists
     // in a buffer of their own (lists_eval_), so a reporter between two launches costs the dynamics nothing.  AWSEM_LIST_REUSE=0: off.
-    bool lists_valid_ = false, list_reuse_ = true, query_reuse_ = true, step_lean_ = false;
+    bool lists_valid_ = false, list_reuse_ = true, query_reuse_ = true;
+    int step_lean_ = 0;   // which instantiation of the step kernel runs (evaluate_terms: LEAN)
     double lists_skin_ = 0;
     unsigned* lists_eval_ = nullptr;
     // Energy / force queries walk the pair lists the last step launch left in device memory when those are still the lists of the stored
@@ -1646,8 +1650,9 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     step_ok_ = lds_step_ <= lds_max;   // energies/forces need less LDS than dynamics (no velocities, no list reference positions)
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<true, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<false, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
-    if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
-    if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
+    if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
+    if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
+    if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_minimize_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_list_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     // Workgroup size: the waves a CU can hold at this kernel's register budget (16) divided among the replicas whose LDS
@@ -1700,7 +1705,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         if (dsys_.n_pap) dsys_.pap_dev = upload(std::vector<PapD<real>>(dsys_.pap, dsys_.pap + dsys_.n_pap));
     }
     {   // the lean instantiation of the step kernel (evaluate_terms<LEAN>): none of the rarer term shapes present
-        bool lean = dsys_.n_gauss == 0 && dsys_.n_cv == 0 && dsys_.n_helical == 0 && dsys_.n_memb == 0 && dsys_.n_contact <= 1 && (dsys_.n_rama == 0 || dsys_.ramam.n > 0);
+        bool lean = dsys_.n_gauss == 0 && dsys_.n_cv == 0 && dsys_.n_helical <= 1 && dsys_.n_memb == 0 && dsys_.n_contact <= 1 && (dsys_.n_rama == 0 || dsys_.ramam.n > 0);
         for (int t = 0; t < dsys_.n_fm; t++) lean = lean && dsys_.fm[t].nbundles > 0;
         for (int t = 0; t < dsys_.n_contact; t++) lean = lean && dsys_.contact[t].flags == 0;                       // the plain contact_term
         for (int t = 0; t < dsys_.n_beta; t++) lean = lean && dsys_.beta[t].scan_mode == 0 && !dsys_.beta[t].fn;         // every term scans for itself, dense tables
@@ -1710,9 +1715,9 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         lean = lean && dsys_.n_harm <= 1 && dsys_.n_chi <= 1 && dsys_.n_fm <= 1 && dsys_.n_dh <= 1 && dsys_.n_excl <= 1 && dsys_.n_beta <= 3 && dsys_.n_pap <= 2;
         for (int t = 1; t < dsys_.n_beta; t++) lean = lean && !dsys_.beta[t].list_owner;
         for (int t = 1; t < dsys_.n_pap; t++) lean = lean && !dsys_.pap[t].list_owner;
-        step_lean_ = lean && !(getenv("AWSEM_STEP_LEAN") && atoi(getenv("AWSEM_STEP_LEAN")) == 0);
+        step_lean_ = lean && !(getenv("AWSEM_STEP_LEAN") && atoi(getenv("AWSEM_STEP_LEAN")) == 0) ? (dsys_.n_helical ? 2 : 1) : 0;
         if (getenv("AWSEM_INFO")) {
-            fprintf(stderr, "[awsem] step kernel: %s instantiation", step_lean_ ? "lean" : "full");
+            fprintf(stderr, "[awsem] step kernel: %s instantiation", step_lean_ == 2 ? "lean + helical" : step_lean_ ? "lean" : "full");
             if (!step_lean_) {
                 fprintf(stderr, " (gauss %d cv %d helical %d memb %d contact %d rama %d/%d fuse_vs %d massive %d block %d prio %d; contact flags", dsys_.n_gauss, dsys_.n_cv, dsys_.n_helical,
                         dsys_.n_memb, dsys_.n_contact, dsys_.n_rama, dsys_.ramam.n, dsys_.fuse_vs, dsys_.nmassive, block_, dsys_.prio & 0xff);

@@ -1328,8 +1328,9 @@ template <bool LEAN = false, class V> __device__ __forceinline__ void build_list
 // LEAN: the step kernel's second instantiation for systems that hold none of the rarer term shapes -- Gaussian bonds and collective
 // variables, helical, membrane / external fields, a second contact term, unbundled fragment memory, unmerged Ramachandran lists (the
 // default forces_setup.py list qualifies; Engine::finalize checks).  The code for them is not compiled in, which the register
-// allocator of the one big step kernel feels.
-template <bool ENERGY, bool STEP = false, bool LEAN = false, class V> __device__ __forceinline__ void evaluate_terms(const DevSys<typename V::real_t>& S, const V& L, unsigned mask, bool fused_vs AWSEM_STAMP_ARG) {
+// allocator of the one big step kernel feels.  LEAN == 2: the same plus one helical term (forces_setup.py with the helical term
+// switched on, as the many-memory configurations run it).
+template <bool ENERGY, bool STEP = false, int LEAN = 0, class V> __device__ __forceinline__ void evaluate_terms(const DevSys<typename V::real_t>& S, const V& L, unsigned mask, bool fused_vs AWSEM_STAMP_ARG) {
     typedef typename V::real_t real;
     int first = -1;   // the contact term whose passes define the phases
     for (int t = S.n_contact - 1; t >= 0; t--) if (AWSEM_ON(S.contact[t])) first = t;
@@ -1366,7 +1367,7 @@ template <bool ENERGY, bool STEP = false, bool LEAN = false, class V> __device__
         if (d.cv) cv_apply<ENERGY>(d, L, rotor.next(d.n));
         else term_gauss<ENERGY>(d, L, rotor.next(d.n));
     }
-    if (!LEAN) for (int u = 0; u < S.n_helical; u++) if (AWSEM_ON(S.helical[u])) term_helical<ENERGY>(S.helical[u], L, rotor.next(S.helical[u].n));
+    if (LEAN != 1) for (int u = 0; u < (LEAN ? (S.n_helical < 1 ? S.n_helical : 1) : S.n_helical); u++) if (AWSEM_ON(S.helical[u])) term_helical<ENERGY>(S.helical[u], L, rotor.next(S.helical[u].n));
     if (!LEAN) for (int u = 0; u < S.n_memb; u++) if (AWSEM_ON(S.memb[u])) term_memb<ENERGY>(S.memb[u], L, rotor.next(S.memb[u].n));
     if (STEP) {
         if (LEAN || S.ramam.n) { if (AWSEM_ON(S.ramam)) term_rama_merged<ENERGY>(S.ramam, L, rotor.next(S.ramam.n)); }
@@ -1903,7 +1904,7 @@ __device__ __forceinline__ void set_wave_priority(int p) {
 #ifndef AWSEM_STEP_ATTR
 #define AWSEM_STEP_ATTR
 #endif
-template <class real, bool LEAN = false>
+template <class real, int LEAN = 0>
 __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSys<real> S, real* __restrict__ pos, real* __restrict__ vel,
                                   const double* __restrict__ T, int nsteps, double dt, double friction, unsigned long long seed,
                                   long long step0, int launch, int reuse, int stage_len) {
@@ -1911,7 +1912,7 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
     AWSEM_STAMP_WALL(S, 0);
     const long long pace_t0 = (S.prio & 0xff) == 3 ? (long long)wall_clock64() : 0;
     const int natoms = S.natoms, rep = (S.prio & 0xff) == 3 ? uniform(pace_perm(S, (int)gridDim.x)[blockIdx.x]) : (int)blockIdx.x;
-    typedef typename std::conditional<LEAN, LdsLean<real>, Lds<real>>::type View;
+    typedef typename std::conditional<LEAN != 0, LdsLean<real>, Lds<real>>::type View;
     View L(carve_lds((real)0, smem, lds_shape(S), true));
     L.lists = S.lists + (size_t)rep * S.list_stride;
     real* gp = pos + (size_t)rep * 3 * natoms;
@@ -1997,7 +1998,7 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
             if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
             for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) { const int i = S.massive[k].atom; L.set_ref(i, L.pos(i)); }
             __syncthreads();
-            build_lists<LEAN>(S, L, 0xffffffffu);
+            build_lists<LEAN != 0>(S, L, 0xffffffffu);
             AWSEM_ARRIVE(2);
             __syncthreads();
             AWSEM_STAMP(S, 2);
