@@ -385,6 +385,7 @@ public:
         };
         if (step_lean_ == 1) launch(awsem_step_kernel<real, 1>);
         else if (step_lean_ == 2) launch(awsem_step_kernel<real, 2>);
+        else if (step_lean_ == 3) launch(awsem_step_kernel<real, 3>);
         else launch(awsem_step_kernel<real, 0>);
         // the skin the lists counted after this launch were built under: lists carried in from the previous launch carry ITS skin
         const double built_skin = reuse ? std::max(skin_, lists_skin_) : skin_;
@@ -1653,6 +1654,7 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
+    if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_minimize_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     HIP_TRY(hipFuncSetAttribute((const void*)awsem_list_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     // Workgroup size: the waves a CU can hold at this kernel's register budget (16) divided among the replicas whose LDS
@@ -1705,9 +1707,13 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         if (dsys_.n_pap) dsys_.pap_dev = upload(std::vector<PapD<real>>(dsys_.pap, dsys_.pap + dsys_.n_pap));
     }
     {   // the lean instantiation of the step kernel (evaluate_terms<LEAN>): none of the rarer term shapes present
-        bool lean = dsys_.n_gauss == 0 && dsys_.n_cv == 0 && dsys_.n_helical <= 1 && dsys_.n_memb == 0 && dsys_.n_contact <= 1 && (dsys_.n_rama == 0 || dsys_.ramam.n > 0);
+        bool lean = dsys_.n_gauss == 0 && dsys_.n_cv == 0 && dsys_.n_helical <= 1 && dsys_.n_memb <= 1 && dsys_.n_contact <= 1 && (dsys_.n_rama == 0 || dsys_.ramam.n > 0);
         for (int t = 0; t < dsys_.n_fm; t++) lean = lean && dsys_.fm[t].nbundles > 0;
-        for (int t = 0; t < dsys_.n_contact; t++) lean = lean && dsys_.contact[t].flags == 0;                       // the plain contact_term
+        // flavours: 1 plain contact_term; 2 the same with one helical term; 3 the z-dependent contact term with one membrane term
+        const bool zdep = dsys_.n_contact == 1 && dsys_.contact[0].flags == 1;
+        const int flavour = dsys_.n_memb || zdep ? 3 : dsys_.n_helical ? 2 : 1;
+        if (flavour == 3) lean = lean && zdep && dsys_.n_memb == 1 && dsys_.n_helical == 0;
+        else for (int t = 0; t < dsys_.n_contact; t++) lean = lean && dsys_.contact[t].flags == 0;
         for (int t = 0; t < dsys_.n_beta; t++) lean = lean && dsys_.beta[t].scan_mode == 0 && !dsys_.beta[t].fn;         // every term scans for itself, dense tables
         for (int t = 0; t < dsys_.n_pap; t++) lean = lean && dsys_.pap[t].scan_mode == 0 && !dsys_.pap[t].fn;
         lean = lean && dsys_.fuse_vs == 1 && dsys_.nmassive <= 2 * block_ && (dsys_.prio & 0xff) != 2 && dsys_.remove_cm != 0;
@@ -1715,9 +1721,9 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         lean = lean && dsys_.n_harm <= 1 && dsys_.n_chi <= 1 && dsys_.n_fm <= 1 && dsys_.n_dh <= 1 && dsys_.n_excl <= 1 && dsys_.n_beta <= 3 && dsys_.n_pap <= 2;
         for (int t = 1; t < dsys_.n_beta; t++) lean = lean && !dsys_.beta[t].list_owner;
         for (int t = 1; t < dsys_.n_pap; t++) lean = lean && !dsys_.pap[t].list_owner;
-        step_lean_ = lean && !(getenv("AWSEM_STEP_LEAN") && atoi(getenv("AWSEM_STEP_LEAN")) == 0) ? (dsys_.n_helical ? 2 : 1) : 0;
+        step_lean_ = lean && !(getenv("AWSEM_STEP_LEAN") && atoi(getenv("AWSEM_STEP_LEAN")) == 0) ? flavour : 0;
         if (getenv("AWSEM_INFO")) {
-            fprintf(stderr, "[awsem] step kernel: %s instantiation", step_lean_ == 2 ? "lean + helical" : step_lean_ ? "lean" : "full");
+            fprintf(stderr, "[awsem] step kernel: %s instantiation", step_lean_ == 3 ? "lean + membrane" : step_lean_ == 2 ? "lean + helical" : step_lean_ ? "lean" : "full");
             if (!step_lean_) {
                 fprintf(stderr, " (gauss %d cv %d helical %d memb %d contact %d rama %d/%d fuse_vs %d massive %d block %d prio %d; contact flags", dsys_.n_gauss, dsys_.n_cv, dsys_.n_helical,
                         dsys_.n_memb, dsys_.n_contact, dsys_.n_rama, dsys_.ramam.n, dsys_.fuse_vs, dsys_.nmassive, block_, dsys_.prio & 0xff);

@@ -110,6 +110,7 @@ template <class real> __device__ __forceinline__ real dist2(const R3<real>& d) {
 // ------------------------------------------------------------------ views of one replica
 // Members every view carries besides coordinates and forces (the contact passes' scratch, energies, pair lists).
 template <class real> struct ViewCommon {
+    static constexpr int cflag = 0;       // (lean views: the contact term's flags, known at compile time)
     static constexpr bool lean = false;   // LdsLean: the view of the step kernel's lean instantiation (contact variants fold away: cflags)
     int nthr;                // threads of the workgroup.  blockDim.x is a 16-bit field of the implicit kernel arguments: every place the compiler
                              // rematerialises it costs a VECTOR load and a wait on it (there is no scalar 16-bit load); the LDS views read it once and
@@ -233,7 +234,13 @@ template <class real> struct LdsLean : Lds<real> {
     static constexpr bool lean = true;
     __device__ __forceinline__ explicit LdsLean(const Lds<real>& b) : Lds<real>(b) {}
 };
-template <class V> __device__ __forceinline__ int cflags(const ContactD<typename V::real_t>& d, const V&) { return V::lean ? 0 : d.flags; }
+// ... and of the membrane flavour: the one contact term is the z-dependent one (flags 1)
+template <class real> struct LdsLeanZ : Lds<real> {
+    static constexpr bool lean = true;
+    static constexpr int cflag = 1;
+    __device__ __forceinline__ explicit LdsLeanZ(const Lds<real>& b) : Lds<real>(b) {}
+};
+template <class V> __device__ __forceinline__ int cflags(const ContactD<typename V::real_t>& d, const V&) { return V::lean ? V::cflag : d.flags; }
 
 // Energies are summed as 2^-32 fixed point from the first addition on (integer adds commute, so a sum does not
 // depend on the order in which a pair list happens to hold its entries): `Energy` is a per-lane accumulator.
@@ -891,7 +898,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void contact_single(c
 // E, dE/dr, dE/d(sigma_water) and, for the z-dependent variant, M - W (membrane minus water energy).
 template <class real> struct PairTerms { real E, dEdr, dEdsw, MW; };
 // INDEXED (index_based_contact_term): g0 is the global [3][nsites][nsites] table and ty = site_i * nsites + site_j.
-template <bool INDEXED = false, bool PLAIN = false, class real> __device__ __forceinline__ PairTerms<real> contact_pair_math(const ContactD<real>& d, const real* g0, int ty, real r, real sw, real aa) {
+template <bool INDEXED = false, int PLAIN = 0, class real> __device__ __forceinline__ PairTerms<real> contact_pair_math(const ContactD<real>& d, const real* g0, int ty, real r, real sw, real aa) {
     // one environment is three planes (direct, protein, water) of 400 type pairs, or of nsites^2 site pairs (INDEXED); the membrane
     // environment of a z-dependent term lies behind the water one
     const int plane = INDEXED ? d.nsites * d.nsites : 400;
@@ -902,7 +909,7 @@ template <bool INDEXED = false, bool PLAIN = false, class real> __device__ __for
     const real th1 = s1 * s2, dth1 = d.eta2 * th1 * (s2 - s1);
     const real th2 = s3 * s4, dth2 = d.eta2 * th2 * (s4 - s3);
     PairTerms<real> o;
-    if (PLAIN || !(d.flags & 1)) {   // PLAIN: the caller knows the term is not z-dependent (lean step kernel)
+    if (PLAIN == 1 || (PLAIN == 0 && !(d.flags & 1))) {   // PLAIN 1 / 2: the caller knows the term is not / is z-dependent (lean step kernels)
         const real gd = g0[ty], gp = g0[plane + ty], gw = g0[2 * plane + ty];
         const real med = sw * gw + (one - sw) * gp;
         o.E = -d.k * (gd * th1 + th2 * med);
@@ -934,7 +941,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void pairs_body(const
     real ai = 0, aj = 0;
     if (zdep) { ai = L.alpha[i]; aj = L.alpha[j]; }
     const PairTerms<real> t = (cflags(d, L) & 16) ? contact_pair_math<true>(d, d.gamma, pass ? i * d.nsites + j : 0, r, si * sj, ai * aj)
-                                             : contact_pair_math<false, V::lean>(d, L.gamma, ty, r, si * sj, ai * aj);
+                                             : contact_pair_math<false, V::lean ? 1 + (V::cflag & 1) : 0>(d, L.gamma, ty, r, si * sj, ai * aj);
     if (pass) {
         if (ENERGY) e += (double)t.E;
         L.pair_force(a, b, dd.x, dd.y, dd.z, -t.dEdr * ir);
@@ -1329,7 +1336,8 @@ template <bool LEAN = false, class V> __device__ __forceinline__ void build_list
 // variables, helical, membrane / external fields, a second contact term, unbundled fragment memory, unmerged Ramachandran lists (the
 // default forces_setup.py list qualifies; Engine::finalize checks).  The code for them is not compiled in, which the register
 // allocator of the one big step kernel feels.  LEAN == 2: the same plus one helical term (forces_setup.py with the helical term
-// switched on, as the many-memory configurations run it).
+// switched on, as the many-memory configurations run it).  LEAN == 3: lean plus one membrane term, the contact term being the
+// z-dependent one (the membrane-protein set-up, configs[3]).
 template <bool ENERGY, bool STEP = false, int LEAN = 0, class V> __device__ __forceinline__ void evaluate_terms(const DevSys<typename V::real_t>& S, const V& L, unsigned mask, bool fused_vs AWSEM_STAMP_ARG) {
     typedef typename V::real_t real;
     int first = -1;   // the contact term whose passes define the phases
@@ -1368,7 +1376,7 @@ template <bool ENERGY, bool STEP = false, int LEAN = 0, class V> __device__ __fo
         else term_gauss<ENERGY>(d, L, rotor.next(d.n));
     }
     if (LEAN != 1) for (int u = 0; u < (LEAN ? (S.n_helical < 1 ? S.n_helical : 1) : S.n_helical); u++) if (AWSEM_ON(S.helical[u])) term_helical<ENERGY>(S.helical[u], L, rotor.next(S.helical[u].n));
-    if (!LEAN) for (int u = 0; u < S.n_memb; u++) if (AWSEM_ON(S.memb[u])) term_memb<ENERGY>(S.memb[u], L, rotor.next(S.memb[u].n));
+    if (!LEAN || LEAN == 3) for (int u = 0; u < (LEAN ? (S.n_memb < 1 ? S.n_memb : 1) : S.n_memb); u++) if (AWSEM_ON(S.memb[u])) term_memb<ENERGY>(S.memb[u], L, rotor.next(S.memb[u].n));
     if (STEP) {
         if (LEAN || S.ramam.n) { if (AWSEM_ON(S.ramam)) term_rama_merged<ENERGY>(S.ramam, L, rotor.next(S.ramam.n)); }
         else for (int u = 0; u < S.n_rama; u++) if (AWSEM_ON(S.rama[u])) term_rama<ENERGY>(S.rama[u], L, rotor.next(S.rama[u].n));
@@ -1912,7 +1920,7 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
     AWSEM_STAMP_WALL(S, 0);
     const long long pace_t0 = (S.prio & 0xff) == 3 ? (long long)wall_clock64() : 0;
     const int natoms = S.natoms, rep = (S.prio & 0xff) == 3 ? uniform(pace_perm(S, (int)gridDim.x)[blockIdx.x]) : (int)blockIdx.x;
-    typedef typename std::conditional<LEAN != 0, LdsLean<real>, Lds<real>>::type View;
+    typedef typename std::conditional<LEAN == 3, LdsLeanZ<real>, typename std::conditional<LEAN != 0, LdsLean<real>, Lds<real>>::type>::type View;
     View L(carve_lds((real)0, smem, lds_shape(S), true));
     L.lists = S.lists + (size_t)rep * S.list_stride;
     real* gp = pos + (size_t)rep * 3 * natoms;
