@@ -49,10 +49,11 @@ def cpu_baseline(oa, md_steps, budget_s=15.0):
     ctx.set_positions(oa.pdb.positions, replica=-1)
     T = np.full(threads, 800.0)
     ctx.set_velocities_to_temperature(T, 2026)
+    ctx.step(10, T, 0.002, 1.0, 2026)      # first touch (thread pool, lists)
     t0 = time.perf_counter()
-    ctx.step(10, T, 0.002, 1.0, 2026)
+    ctx.step(200, T, 0.002, 1.0, 2026)
     probe = time.perf_counter() - t0
-    n = int(max(20, min(200000, budget_s / max(probe / 10, 1e-6))))
+    n = int(max(20, min(400000, budget_s / max(probe / 200, 1e-6))))
     t0 = time.perf_counter()
     ctx.step(n, T, 0.002, 1.0, 2026)
     dt = time.perf_counter() - t0
