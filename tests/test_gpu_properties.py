@@ -84,6 +84,39 @@ def test_stages_in_one_launch_equal_one_launch_per_stage(lean, monkeypatch):
     assert not np.array_equal(out[0][0], out[0][1])   # the replicas did run at their own temperatures
 
 
+@pytest.mark.parametrize("mode", ["fp64", "cell"])
+def test_stages_on_the_other_paths_and_their_edge_cases(mode, monkeypatch):
+    """awsem_step_stages in the fp64 check mode (its own step kernel) and on the cell-list path (which runs the stages one by one): the
+    trajectory of one awsem_step per stage; zero stages and zero steps per stage advance nothing; bad arguments are refused."""
+    if mode == "cell":
+        monkeypatch.setenv("AWSEM_FORCE_CELL", "1")
+    oa, traj, _ = golden_system("1ubq")
+    T = np.stack([np.array([600.0 - 30.0 * g, 320.0]) for g in range(5)])
+    out = []
+    for staged in (False, True):
+        gpu = _ctx(oa.system, oa.natoms, R=2, precision=FP64 if mode == "fp64" else FP32)
+        gpu.set_positions(traj[0])
+        gpu.compute_virtual_sites()
+        gpu.set_velocities_to_temperature([600.0, 320.0], 3)
+        if staged:
+            gpu.step_stages(6, T, 0.002, 1.0, 4)
+            before = gpu.step_count
+            gpu.step_stages(6, T[:0], 0.002, 1.0, 4)      # no stage
+            gpu.step_stages(0, T, 0.002, 1.0, 4)          # stages of no steps
+            assert gpu.step_count == before
+            with pytest.raises(_capi.AwsemError, match="bad arguments"):
+                gpu.step_stages(6, T, -0.002, 1.0, 4)
+            with pytest.raises(_capi.AwsemError, match="bad arguments"):
+                gpu.step_stages(-1, T, 0.002, 1.0, 4)
+        else:
+            for row in T:
+                gpu.step(6, row, 0.002, 1.0, 4)
+        assert gpu.step_count == 30
+        out.append((gpu.get_positions(0), gpu.get_positions(1), gpu.get_velocities(0), gpu.get_velocities(1)))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+
+
 def test_empty_and_tiny_systems():
     """Two bonded particles and a spectator, an empty bond list next to it: energies, forces and dynamics behave."""
     system = System(np.array([12.0, 12.0, 12.0]))
