@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 #include <atomic>
+#include <mutex>
 #include <limits>
 #include <map>
 
@@ -508,8 +509,12 @@ public:
         if (!sn.busy) throw StateError{"snapshot_end: no snapshot was begun in this slot"};
         if ((xyz_all || v_all) && !sn.with_state) throw StateError{"snapshot_end: the snapshot was begun without the ensemble state"};
         if (xyz_replica && sn.replica < 0) throw StateError{"snapshot_end: the snapshot was begun without a replica's positions"};
-        HIP_TRY(hipSetDevice(device_));
-        HIP_TRY(hipEventSynchronize(sn.ev));
+        {   // not while another thread captures a graph on this handle's stream (cell_step): hipEventSynchronize on an event of a stream
+            // that is being captured invalidates the capture, whichever thread calls it and although the event was recorded before
+            std::lock_guard<std::mutex> hold(capture_mu_);
+            HIP_TRY(hipSetDevice(device_));
+            HIP_TRY(hipEventSynchronize(sn.ev));
+        }
         sn.busy = false;
         const size_t n3 = (size_t)3 * natoms_;
         if (e) for (int r = 0; r < nrep_; r++) {
@@ -798,6 +803,7 @@ private:
     // in a buffer of their own (lists_eval_), so a reporter between two launches costs the dynamics nothing.  AWSEM_LIST_REUSE=0: off.
     bool lists_valid_ = false, list_reuse_ = true, query_reuse_ = true;
     int step_lean_ = 0;   // which instantiation of the step kernel runs (evaluate_terms: LEAN)
+    std::mutex capture_mu_;   // graph capture on stream_ (cell_step) against event waits from another thread (snapshot_end)
     double lists_skin_ = 0;
     unsigned* lists_eval_ = nullptr;
     // Energy / force queries walk the pair lists the last step launch left in device memory when those are still the lists of the stored
@@ -2231,9 +2237,13 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
                 if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
                 const int cur0 = cell_cur_;
                 hipGraph_t graph = nullptr;
-                HIP_TRY(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-                for (int k = 0; k < AWSEM_CELL_CHUNK; k++) cell_one_step(dt, friction, seed, k);
-                HIP_TRY(hipStreamEndCapture(stream_, &graph));
+                {
+                    std::lock_guard<std::mutex> hold(capture_mu_);   // keeps the reporters' thread (snapshot_end) off the stream's events meanwhile
+                    HIP_TRY(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+                    try { for (int k = 0; k < AWSEM_CELL_CHUNK; k++) cell_one_step(dt, friction, seed, k); }
+                    catch (...) { (void)hipStreamEndCapture(stream_, &graph); if (graph) (void)hipGraphDestroy(graph); cell_cur_ = cur0; throw; }
+                    HIP_TRY(hipStreamEndCapture(stream_, &graph));
+                }
                 HIP_TRY(hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0));
                 HIP_TRY(hipGraphDestroy(graph));
                 cell_cur_ = cur0;   // capturing ran nothing; AWSEM_CELL_CHUNK is even, so a replay ends on the parity it started on

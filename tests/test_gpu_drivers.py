@@ -152,12 +152,17 @@ def test_awsem_run_anneals_an_ensemble_and_writes_the_reference_files(tmp_path, 
     assert sim2.currentStep == 2000 + 400
 
 
-def test_reports_written_behind_the_launches_are_byte_identical(tmp_path, monkeypatch):
+@pytest.mark.parametrize("cell", [False, True])
+def test_reports_written_behind_the_launches_are_byte_identical(cell, tmp_path, monkeypatch):
     """engine.Simulation.step serves the built-in reporters in two halves -- values fetched asynchronously behind the launch
     (awsem_snapshot_begin, pinned host memory), files written by a worker thread after the next launches have been queued -- where the
     reference's OpenMM reporters run synchronously inside simulation.step (scripts/mm_run.py:157-175).  Same values, same order: every
-    file of a run must equal, byte for byte, what AWSEM_ASYNC_REPORT=0 (synchronous reporting) writes."""
+    file of a run must equal, byte for byte, what AWSEM_ASYNC_REPORT=0 (synchronous reporting) writes.
+    cell: the same on the cell-list path, whose steps are captured HIP graphs -- the worker thread's wait on a snapshot event must not
+    fall into a capture on the same stream (it invalidated the capture until the two were serialised: Engine::capture_mu_)."""
     from openawsem_amd.scripts import mm_run
+    if cell:
+        monkeypatch.setenv("AWSEM_FORCE_CELL", "1")
     d = tmp_path / "1r69"
     shutil.copytree(data_path.data / "1r69", d, ignore=shutil.ignore_patterns("fraglib", "frags.mem"))
     shutil.copy(d / "1r69.fasta", d / "crystal_structure.fasta")

@@ -334,6 +334,7 @@ def test_lean_step_kernel_follows_the_full_one(workload, flavour, monkeypatch, c
     oa = getattr(workloads, workload)()
     R = 12
     T = np.linspace(250.0, 800.0, R)
+    monkeypatch.delenv("AWSEM_FORCE_CELL", raising=False)   # about the replica-resident path's kernel
     monkeypatch.setenv("AWSEM_INFO", "1")
     out = []
     for lean in ("1", "0", "1"):

@@ -160,6 +160,8 @@ def test_gpu_reproduces_the_legacy_1r69_table(precision, cell, monkeypatch):
     oa, frames, table = _legacy_1r69(split)
     if cell:
         monkeypatch.setenv("AWSEM_FORCE_CELL", "1")
+    else:   # the split system holds two contact-shaped terms, which only the replica-resident path takes
+        monkeypatch.delenv("AWSEM_FORCE_CELL", raising=False)
     gpu = _capi.Context(_capi.load_hip_library(), oa.natoms, n_replicas=len(frames), precision=precision)
     oa.system.upload(gpu)
     for r, x in enumerate(frames):
