@@ -630,7 +630,10 @@ template <class real> __global__ void cell_chain_kernel(DevSys<real> S, CellSys<
 // moved further than skin/2 an O-N or CA-N distance has changed by less than 1.19 skin: the rows are cut at the
 // screening distance + 1.2 skin.  Evaluation: 16 lanes walk a row, same per-pair code as the resident path
 // (beta_pair / pap_pair), forces through global fixed-point atomics (a pair touches up to five atoms).
-struct HbRows { unsigned* rows; int* row_count; int stride; };   // [R][nacc][stride] donor indices, [R][nacc]
+#define AWSEM_HB_BLOCK 16   // donors per bounding sphere: one iteration of the row builder's fine test (= AWSEM_ROW)
+// [R][nacc][stride] donor indices, [R][nacc]; [R][nblocks][4] bounding spheres (centre, radius; fp32) of the donors' screening atoms in
+// blocks of AWSEM_HB_BLOCK consecutive donors, renewed at every rebuild (cell_hb_spheres_kernel)
+struct HbRows { unsigned* rows; int* row_count; int stride; float* spheres; int nblocks; };
 
 template <class real> __device__ inline CellView<real> cell_view_plain(const CellSys<real>& C, const real* pos, int rep) {
     CellView<real> L;
@@ -645,54 +648,164 @@ template <class real> __device__ inline CellView<real> cell_view_plain(const Cel
     L.lcount = nullptr; L.flag = nullptr; L.lists = nullptr;
     return L;
 }
+// The cell-list view with the coordinates read from packed {x, y, z, -} records (HbTerms::pos4)
+template <class real> struct CellViewP : CellView<real> {
+    const Rec<real>* p4;
+    __device__ __forceinline__ CellViewP(const CellView<real>& b, const Rec<real>* q) : CellView<real>(b), p4(q) {}
+    __device__ __forceinline__ R3<real> pos(int a) const { const Rec<real> q = p4[a]; return R3<real>{q.x, q.y, q.z}; }
+};
+// ... and with the forces on the ROW's acceptor atoms summed in registers.  The sixteen lanes of a row walk the partners of one
+// acceptor: every one of them adds to the same two or three atoms, and same-address atomics of one instruction are served one after
+// the other (measured: 39 of the hydrogen-bond kernel's 90 us at 20 008 residues).  The lanes keep those contributions as integers,
+// the row adds them up with shuffles and nine lanes issue one atomic each: the same sums bit for bit (fixed point), 16 times fewer
+// atomics on the contended addresses.  The donors' atoms differ from lane to lane and keep their atomics.
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m, int width) {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, m, width), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), m, width);
+    return ((u64)hi << 32) | lo;
+}
+template <class real> struct CellViewHb : CellViewP<real> {
+    int a0, a1, a2;
+    mutable u64 x0, y0, z0, x1, y1, z1, x2, y2, z2;
+    __device__ __forceinline__ CellViewHb(const CellView<real>& b, const Rec<real>* q) : CellViewP<real>(b, q), a0(-1), a1(-1), a2(-1), x0(0), y0(0), z0(0), x1(0), y1(0), z1(0), x2(0), y2(0), z2(0) {}
+    __device__ __forceinline__ void begin_row(int b0, int b1, int b2) { a0 = b0; a1 = b1; a2 = b2; x0 = y0 = z0 = x1 = y1 = z1 = x2 = y2 = z2 = 0; }
+    __device__ __forceinline__ void book(int i, u64 X, u64 Y, u64 Z) const {   // += on atom i
+        if (i == a0) { x0 += X; y0 += Y; z0 += Z; }
+        else if (i == a1) { x1 += X; y1 += Y; z1 += Z; }
+        else if (i == a2) { x2 += X; y2 += Y; z2 += Z; }
+        else { fixed_add(&this->fx[i], X); fixed_add(&this->fy[i], Y); fixed_add(&this->fz[i], Z); }
+    }
+    __device__ __forceinline__ void pair_force(int i, int j, real dx, real dy, real dz, real s) const {
+        const real t = s * (real)AWSEM_FIXED_SCALE;
+        const u64 X = to_fixed_scaled(t * dx), Y = to_fixed_scaled(t * dy), Z = to_fixed_scaled(t * dz);
+        book(i, X, Y, Z);
+        book(j, (u64)0 - X, (u64)0 - Y, (u64)0 - Z);
+    }
+    static __device__ __forceinline__ u64 row_sum(u64 v) {
+#pragma unroll
+        for (int m = AWSEM_ROW / 2; m > 0; m >>= 1) v += shfl_xor_u64(v, m, AWSEM_ROW);
+        return v;
+    }
+    // all sixteen lanes of the row (whether or not they had a partner)
+    __device__ __forceinline__ void end_row(int sub) const {
+        const u64 r0 = row_sum(x0), r1 = row_sum(y0), r2 = row_sum(z0), r3 = row_sum(x1), r4 = row_sum(y1), r5 = row_sum(z1), r6 = row_sum(x2), r7 = row_sum(y2), r8 = row_sum(z2);
+        const u64 mine = sub == 0 ? r0 : sub == 1 ? r1 : sub == 2 ? r2 : sub == 3 ? r3 : sub == 4 ? r4 : sub == 5 ? r5 : sub == 6 ? r6 : sub == 7 ? r7 : r8;
+        // (No select among the members a0..a2 or fx..fz themselves: the compiler turns a select of adjacent struct fields into an indexed
+        // load from the struct, which then lives in scratch -- 272 B per lane here.  The atoms pass through a shuffle, the component
+        // plane is reached by its distance from fx: the three planes are one array, cell_view.)
+        const int q = sub / 3, comp = sub - 3 * q;
+        const int b0 = __shfl(a0, 0, AWSEM_ROW), b1 = __shfl(a1, 0, AWSEM_ROW), b2 = __shfl(a2, 0, AWSEM_ROW);
+        const int atom = sub < 9 ? (q == 0 ? b0 : q == 1 ? b1 : b2) : -1;
+        if (atom >= 0 && mine != 0) fixed_add(this->fx + (size_t)comp * (size_t)(this->fy - this->fx) + atom, mine);
+    }
+};
 template <bool ENERGY, class V> __device__ __forceinline__ void hb_pair(const BetaD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e) { beta_pair<ENERGY>(d, L, A, D, e); }
 template <bool ENERGY, class V> __device__ __forceinline__ void hb_pair(const PapD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e) { pap_pair<ENERGY>(d, L, A, D, e); }
 
 // All hydrogen-bond terms of a system go through ONE launch of each kernel (grid (blocks, R, terms)): their descriptors,
 // rows and list radii sit in device memory and are fetched with scalar loads (blockIdx.z is uniform).
-template <class real> struct HbTerms { const BetaD<real>* beta; const PapD<real>* pap; const HbRows* rows; const real* rc2; int n_beta, n_pap; };
+// pos4: [R][natoms] the coordinates once more as packed {x, y, z, -} records, written by cell_hb_prepare_kernel before every walk.  The
+// hydrogen-bond kernels gather up to six atoms per pair from all over the system; from the SoA arrays that is three cache lines per atom
+// and lane, and the kernel was bound by exactly that (48 vector-memory instructions per wave, 80 % of its cycles waiting on them).
+template <class real> struct HbTerms { const BetaD<real>* beta; const PapD<real>* pap; const HbRows* rows; const real* rc2; int n_beta, n_pap; Rec<real>* pos4; };
 
-template <class real, class Desc> __device__ __forceinline__ void hb_rows_body(const Desc& d, const CellSys<real>& C, const HbRows& H, const real* __restrict__ pos, real rc2, int rep) {
+// Donor rows of one hydrogen-bond term: for every acceptor the donors whose screening atom lies inside the list radius (and whose table
+// entry is not zero), in ascending donor order.  Rounds 1 and 2 tested every acceptor against every donor -- 4 10^8 distance tests per
+// term for the 20 008-residue system, 4.3 ms per rebuild.  Now the donors come in blocks of 16 consecutive ones (neighbours along a
+// chain, so a block is a blob of ~1 nm) with a bounding sphere each (hb_spheres_body, renewed at every rebuild): a wave tests 64 spheres
+// per iteration against its four acceptors and runs the fine test only on the blocks that can hold a partner.  The rows are the same
+// rows (same donors, same order): |a - d| >= |a - c| - r_block, so a block further than list radius + r_block holds nothing.
+template <class real, class Desc> __device__ __forceinline__ void hb_spheres_body(const Desc& d, const CellSys<real>& C, const HbRows& H, const real* __restrict__ pos, int rep) {
     const size_t n = C.natoms;
     const real* p = pos + (size_t)rep * 3 * n;
-    const int sub = threadIdx.x & (AWSEM_ROW - 1), row_in_wave = (threadIdx.x & 63) / AWSEM_ROW;
+    float* sp = H.spheres + (size_t)rep * H.nblocks * 4;
+    const int sub = threadIdx.x & (AWSEM_HB_BLOCK - 1);
+    const int nb_pad = (H.nblocks + 3) & ~3;   // whole waves: the shuffles are wave collectives
+    for (int b = (blockIdx.x * blockDim.x + threadIdx.x) / AWSEM_HB_BLOCK; b < nb_pad; b += gridDim.x * blockDim.x / AWSEM_HB_BLOCK) {
+        const bool vb = b < H.nblocks;
+        const int q = b * AWSEM_HB_BLOCK + sub;
+        const Int4 D = d.don[vb ? (q < d.ndon ? q : b * AWSEM_HB_BLOCK) : 0];   // a short last block repeats its first donor
+        const float x = (float)p[D.x], y = (float)p[n + D.x], z = (float)p[2 * n + D.x];
+        float cx = x, cy = y, cz = z;
+        for (int m = AWSEM_HB_BLOCK / 2; m > 0; m >>= 1) { cx += __shfl_xor(cx, m, AWSEM_HB_BLOCK); cy += __shfl_xor(cy, m, AWSEM_HB_BLOCK); cz += __shfl_xor(cz, m, AWSEM_HB_BLOCK); }
+        cx *= 1.0f / AWSEM_HB_BLOCK; cy *= 1.0f / AWSEM_HB_BLOCK; cz *= 1.0f / AWSEM_HB_BLOCK;
+        float r2 = (x - cx) * (x - cx) + (y - cy) * (y - cy) + (z - cz) * (z - cz);
+        for (int m = AWSEM_HB_BLOCK / 2; m > 0; m >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, m, AWSEM_HB_BLOCK));
+        if (vb && sub == 0) { sp[4 * b] = cx; sp[4 * b + 1] = cy; sp[4 * b + 2] = cz; sp[4 * b + 3] = sqrtf(r2); }
+    }
+}
+template <class real, class Desc> __device__ __forceinline__ void hb_rows_body(const Desc& d, const CellSys<real>& C, const HbRows& H, const Rec<real>* __restrict__ pos4, real rc2, int rep) {
+    const Rec<real>* p4 = pos4 + (size_t)rep * C.natoms;
+    const float* sp = H.spheres + (size_t)rep * H.nblocks * 4;
+    const int lane = threadIdx.x & 63, sub = threadIdx.x & (AWSEM_ROW - 1), row_in_wave = lane / AWSEM_ROW;
     const int nrows_total = (d.nacc + 3) & ~3;   // whole waves: the ballots are wave collectives
+    const float reach = sqrtf((float)rc2) + 1e-3f;   // list radius plus a margin for the spheres' fp32 arithmetic
     unsigned* rows = H.rows + (size_t)rep * d.nacc * H.stride;
     for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows_total; k += gridDim.x * blockDim.x / AWSEM_ROW) {
         const bool vi = k < d.nacc;
         const Int4 A = d.acc[vi ? k : 0];
         const int ares = Desc::res_slot == 3 ? A.w : A.z;
-        const real ax = p[A.x], ay = p[n + A.x], az = p[2 * n + A.x];
+        const Rec<real> pa = p4[A.x];
+        const real ax = pa.x, ay = pa.y, az = pa.z;
+        float gx[4], gy[4], gz[4];   // the wave's four acceptors, for the sphere test (an invalid row repeats acceptor 0: harmless)
+        for (int g = 0; g < 4; g++) { gx[g] = __shfl((float)ax, g * AWSEM_ROW); gy[g] = __shfl((float)ay, g * AWSEM_ROW); gz[g] = __shfl((float)az, g * AWSEM_ROW); }
         int cnt = 0;
-        for (int q0 = 0; q0 < d.ndon; q0 += AWSEM_ROW) {   // the same trip count for every lane
-            const int q = q0 + sub;
-            const bool vq = vi && q < d.ndon;
-            const Int4 D = d.don[vq ? q : 0];
-            const int dres = Desc::res_slot == 3 ? D.w : D.z, dq = dres - ares;
-            const real r2 = dist2(ax - p[D.x], ay - p[n + D.x], az - p[2 * n + D.x]);
-            bool pass = vq && r2 < rc2 && (dq <= d.band_lo || dq >= d.band_hi);
-            if (pass) {
-                if (d.fn) pass = hb_fn_value(*d.fn, dres, ares) != (real)0;
-                else { const size_t bit = (size_t)dres * d.nres + ares; pass = (d.nzmask[bit >> 5] >> (bit & 31)) & 1u; }
+        for (int b0 = 0; b0 < H.nblocks; b0 += 64) {   // the same trip count for every lane
+            const int b = b0 + lane;
+            bool near = false;
+            if (b < H.nblocks) {
+                const float cx = sp[4 * b], cy = sp[4 * b + 1], cz = sp[4 * b + 2], lim = reach + sp[4 * b + 3];
+                for (int g = 0; g < 4; g++) near = near || (gx[g] - cx) * (gx[g] - cx) + (gy[g] - cy) * (gy[g] - cy) + (gz[g] - cz) * (gz[g] - cz) < lim * lim;
             }
-            const unsigned rowmask = (unsigned)(__ballot(pass) >> (row_in_wave * AWSEM_ROW)) & 0xffffu;
-            if (pass) {
-                const int slot = cnt + __popc(rowmask & ((1u << sub) - 1u));
-                if (slot < H.stride) rows[(size_t)k * H.stride + slot] = (unsigned)q;
-                else atomicOr(C.status, 2);
+            unsigned long long blocks = __ballot(near);
+            while (blocks) {   // uniform: every lane walks the same blocks, in ascending order
+                const int q0 = (b0 + __builtin_ctzll(blocks)) * AWSEM_HB_BLOCK;
+                blocks &= blocks - 1;
+                const int q = q0 + sub;
+                const bool vq = vi && q < d.ndon;
+                const Int4 D = d.don[vq ? q : 0];
+                const int dres = Desc::res_slot == 3 ? D.w : D.z, dq = dres - ares;
+                const Rec<real> pd = p4[D.x];
+                const real r2 = dist2(ax - pd.x, ay - pd.y, az - pd.z);
+                bool pass = vq && r2 < rc2 && (dq <= d.band_lo || dq >= d.band_hi);
+                if (pass) {
+                    if (d.fn) pass = hb_fn_value(*d.fn, dres, ares) != (real)0;
+                    else { const size_t bit = (size_t)dres * d.nres + ares; pass = (d.nzmask[bit >> 5] >> (bit & 31)) & 1u; }
+                }
+                const unsigned rowmask = (unsigned)(__ballot(pass) >> (row_in_wave * AWSEM_ROW)) & 0xffffu;
+                if (pass) {
+                    const int slot = cnt + __popc(rowmask & ((1u << sub) - 1u));
+                    if (slot < H.stride) rows[(size_t)k * H.stride + slot] = (unsigned)q;
+                    else atomicOr(C.status, 2);
+                }
+                cnt += __popc(rowmask);
             }
-            cnt += __popc(rowmask);
         }
         if (vi && sub == 0) H.row_count[(size_t)rep * d.nacc + k] = min(cnt, H.stride);
     }
+}
+// grid (blocks, R, terms + 1): slice `terms` packs the coordinates (every step), the others renew the spheres of their term's donors on
+// a rebuild step -- from the SoA coordinates, which are what this launch can rely on.  Launched before the rows are built / walked.
+template <class real> __global__ void cell_hb_prepare_kernel(HbTerms<real> T, CellSys<real> C, const real* __restrict__ pos, int cur, int force) {
+    const int rep = blockIdx.y, t = blockIdx.z;
+    if (t == T.n_beta + T.n_pap) {
+        const size_t n = C.natoms;
+        const real* p = pos + (size_t)rep * 3 * n;
+        Rec<real>* p4 = T.pos4 + (size_t)rep * n;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C.natoms; i += gridDim.x * blockDim.x) p4[i] = Rec<real>{p[i], p[n + i], p[2 * n + i], (real)0};
+        return;
+    }
+    if (!cell_rebuild(C, rep, cur, force)) return;
+    const HbRows H = T.rows[t];
+    if (t < T.n_beta) { const BetaD<real> d = T.beta[t]; hb_spheres_body(d, C, H, pos, rep); }
+    else { const PapD<real> d = T.pap[t - T.n_beta]; hb_spheres_body(d, C, H, pos, rep); }
 }
 template <class real> __global__ void cell_hb_rows_kernel(HbTerms<real> T, CellSys<real> C, const real* __restrict__ pos, int cur, int force) {
     const int rep = blockIdx.y, t = blockIdx.z;
     if (!cell_rebuild(C, rep, cur, force)) return;
     const HbRows H = T.rows[t];
     const real rc2 = T.rc2[t];
-    if (t < T.n_beta) { const BetaD<real> d = T.beta[t]; hb_rows_body(d, C, H, pos, rc2, rep); }
-    else { const PapD<real> d = T.pap[t - T.n_beta]; hb_rows_body(d, C, H, pos, rc2, rep); }
+    if (t < T.n_beta) { const BetaD<real> d = T.beta[t]; hb_rows_body(d, C, H, T.pos4, rc2, rep); }
+    else { const PapD<real> d = T.pap[t - T.n_beta]; hb_rows_body(d, C, H, T.pos4, rc2, rep); }
 }
 
 // ------------------------------------------------------------------ the rebuild without launches of its own (round 3)
@@ -844,8 +957,8 @@ template <class real> __device__ void cell_sort_body(const CellSys<real>& C, con
 template <class real> __global__ __launch_bounds__(256) void cell_sort_kernel(CellSys<real> C, const real* __restrict__ pos, int cur, int force) {
     cell_sort_body(C, pos, (int)blockIdx.y >> 1, (int)blockIdx.y & 1, (int)blockIdx.x, (int)gridDim.x, cur, force);
 }
-template <bool ENERGY, class real, class Desc> __device__ __forceinline__ void hb_eval_body(const Desc& d, const CellSys<real>& C, const HbRows& H, const real* __restrict__ pos, int rep) {
-    const CellView<real> L = cell_view_plain(C, pos, rep);
+template <bool ENERGY, class real, class Desc> __device__ __forceinline__ void hb_eval_body(const Desc& d, const CellSys<real>& C, const HbRows& H, const real* __restrict__ pos, const Rec<real>* __restrict__ pos4, int rep) {
+    CellViewHb<real> L(cell_view_plain(C, pos, rep), pos4 + (size_t)rep * C.natoms);
     const int sub = threadIdx.x & (AWSEM_ROW - 1);
     const unsigned* rows = H.rows + (size_t)rep * d.nacc * H.stride;
     const int* rc = H.row_count + (size_t)rep * d.nacc;
@@ -854,7 +967,9 @@ template <bool ENERGY, class real, class Desc> __device__ __forceinline__ void h
         const int cnt = rc[k];
         if (cnt == 0) continue;
         const Int4 A = d.acc[k];
+        L.begin_row(A.x, A.y, Desc::res_slot == 3 ? A.z : -1);   // (P-AP: two acceptor atoms, the third slot is the residue)
         for (int s = sub; s < cnt; s += AWSEM_ROW) hb_pair<ENERGY>(d, L, A, d.don[rows[(size_t)k * H.stride + s]], e);
+        L.end_row(sub);
     }
     flush_energy<ENERGY>(L, d.group, e);
 }
@@ -865,12 +980,12 @@ template <bool ENERGY, class real> __global__ void cell_hb_eval_kernel(HbTerms<r
     const bool build = rows_cur >= 0 && cell_rebuild(C, rep, rows_cur, rows_force);   // as in cell_density_excl_kernel
     if (t < T.n_beta) {
         const BetaD<real> d = T.beta[t];
-        if (build) { hb_rows_body(d, C, H, pos, T.rc2[t], rep); __syncthreads(); }
-        if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, rep);
+        if (build) { hb_rows_body(d, C, H, T.pos4, T.rc2[t], rep); __syncthreads(); }
+        if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, T.pos4, rep);
     } else {
         const PapD<real> d = T.pap[t - T.n_beta];
-        if (build) { hb_rows_body(d, C, H, pos, T.rc2[t], rep); __syncthreads(); }
-        if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, rep);
+        if (build) { hb_rows_body(d, C, H, T.pos4, T.rc2[t], rep); __syncthreads(); }
+        if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, T.pos4, rep);
     }
 }
 

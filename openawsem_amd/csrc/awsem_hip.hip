@@ -836,9 +836,17 @@ private:
     HbRows cell_hb_beta_[AWSEM_MAX_BETA] = {}, cell_hb_pap_[AWSEM_MAX_PAP] = {};   // donor rows of the hydrogen-bond terms
     real cell_hb_rc2_beta_[AWSEM_MAX_BETA] = {}, cell_hb_rc2_pap_[AWSEM_MAX_PAP] = {};
     HbTerms<real> cell_hb_ = {};           // device-resident descriptor / rows / radius tables of all hydrogen-bond terms
-    int cell_hb_maxacc_ = 0;
+    int cell_hb_maxacc_ = 0, cell_hb_maxblocks_ = 1;
+    // before the hydrogen-bond rows are built or walked: the coordinates as packed records (every time), the donors' bounding spheres
+    // (on a rebuild step) -- cell_hb_prepare_kernel
+    void cell_hb_prepare(const CellSys<real>& C, int cur, int force) {
+        const long long want = std::max((long long)cell_hb_maxblocks_ * AWSEM_HB_BLOCK, (long long)natoms_ / 4);
+        const dim3 g((unsigned)std::max(1LL, std::min((want + 255) / 256, 4096LL)), nrep_, cell_hb_.n_beta + cell_hb_.n_pap + 1);
+        hipLaunchKernelGGL(cell_hb_prepare_kernel<real>, g, dim3(256), 0, stream_, cell_hb_, C, pos_, cur, force);
+    }
     void cell_hb_sync();                   // re-uploads the rows and radius tables after a change on the host
-    int dsys_beta_n_ = 0, dsys_pap_n_ = 0, cell_nacc_beta_[AWSEM_MAX_BETA] = {}, cell_nacc_pap_[AWSEM_MAX_PAP] = {};   // known before dsys_ is set
+    int dsys_beta_n_ = 0, dsys_pap_n_ = 0, cell_nacc_beta_[AWSEM_MAX_BETA] = {}, cell_nacc_pap_[AWSEM_MAX_PAP] = {},   // known before dsys_ is set
+        cell_ndon_beta_[AWSEM_MAX_BETA] = {}, cell_ndon_pap_[AWSEM_MAX_PAP] = {};
     CellGraph cell_graph_[2];
     long long* cell_step_base_ = nullptr;
     int cell_neighbors(int rep, int kind, int index, double skin, int32_t* pairs, int capacity);
@@ -1822,11 +1830,12 @@ template <class real> void Engine<real>::cell_setup(DevSys<real>& S, const HostS
     cell_hb_.n_beta = S.n_beta; cell_hb_.n_pap = S.n_pap;
     if (S.n_beta) cell_hb_.beta = upload(std::vector<BetaD<real>>(S.beta, S.beta + S.n_beta));
     if (S.n_pap) cell_hb_.pap = upload(std::vector<PapD<real>>(S.pap, S.pap + S.n_pap));
+    if (S.n_beta + S.n_pap) cell_hb_.pos4 = dalloc<Rec<real>>((size_t)nrep_ * natoms_);
     cell_hb_maxacc_ = 0;
     for (int t = 0; t < S.n_beta; t++) cell_hb_maxacc_ = std::max(cell_hb_maxacc_, S.beta[t].nacc);
     for (int t = 0; t < S.n_pap; t++) cell_hb_maxacc_ = std::max(cell_hb_maxacc_, S.pap[t].nacc);
-    for (int t = 0; t < S.n_beta; t++) cell_nacc_beta_[t] = S.beta[t].nacc;
-    for (int t = 0; t < S.n_pap; t++) cell_nacc_pap_[t] = S.pap[t].nacc;
+    for (int t = 0; t < S.n_beta; t++) { cell_nacc_beta_[t] = S.beta[t].nacc; cell_ndon_beta_[t] = S.beta[t].ndon; }
+    for (int t = 0; t < S.n_pap; t++) { cell_nacc_pap_[t] = S.pap[t].nacc; cell_ndon_pap_[t] = S.pap[t].ndon; }
     if (S.n_contact > 1 || S.n_excl > 1) throw std::string("cell-list path: at most one contact and one excluded-volume term");
     if (S.n_contact && S.contact[0].nsites >= (1 << 24)) throw std::string("cell-list path: at most 2^24 contact sites");
     if (const char* env = getenv("AWSEM_CELL_NEIGHBORS")) { int v = atoi(env); if (v >= 16 && v <= 4096) cell_per_site_ = v; }
@@ -1960,16 +1969,22 @@ template <class real> void Engine<real>::cell_alloc_lists() {
         if (C.bin[b].rows) { HIP_TRY(hipStreamSynchronize(stream_)); dfree(C.bin[b].rows); }
         C.bin[b].rows = dalloc<unsigned>(n * nrep_);
     }
-    auto hb_alloc = [&](HbRows& Hb, int nacc) {
+    auto hb_alloc = [&](HbRows& Hb, int nacc, int ndon) {
         Hb.stride = C.bin[0].stride;
+        if (!Hb.spheres) {   // (a term without donors has no block: nothing is read or written for it)
+            if (ndon < 0 || ndon > (1 << 28)) throw std::string("cell-list path: donor count out of range");
+            Hb.nblocks = (ndon + AWSEM_HB_BLOCK - 1) / AWSEM_HB_BLOCK;
+            Hb.spheres = dalloc<float>((size_t)std::max(1, Hb.nblocks) * 4 * nrep_);
+        }
         const size_t n = (size_t)std::max(1, nacc) * Hb.stride;
         if (n > 0x7fffffffULL) throw std::string("cell-list path: hydrogen-bond rows exceed 2^31 entries per replica");
         if (Hb.rows) { HIP_TRY(hipStreamSynchronize(stream_)); dfree(Hb.rows); }
         Hb.rows = dalloc<unsigned>(n * nrep_);
         if (!Hb.row_count) { Hb.row_count = dalloc<int>((size_t)std::max(1, nacc) * nrep_); HIP_TRY(hipMemset(Hb.row_count, 0, (size_t)std::max(1, nacc) * nrep_ * sizeof(int))); }
     };
-    for (int t = 0; t < dsys_beta_n_; t++) hb_alloc(cell_hb_beta_[t], cell_nacc_beta_[t]);
-    for (int t = 0; t < dsys_pap_n_; t++) hb_alloc(cell_hb_pap_[t], cell_nacc_pap_[t]);
+    cell_hb_maxblocks_ = 1;
+    for (int t = 0; t < dsys_beta_n_; t++) { hb_alloc(cell_hb_beta_[t], cell_nacc_beta_[t], cell_ndon_beta_[t]); cell_hb_maxblocks_ = std::max(cell_hb_maxblocks_, cell_hb_beta_[t].nblocks); }
+    for (int t = 0; t < dsys_pap_n_; t++) { hb_alloc(cell_hb_pap_[t], cell_nacc_pap_[t], cell_ndon_pap_[t]); cell_hb_maxblocks_ = std::max(cell_hb_maxblocks_, cell_hb_pap_[t].nblocks); }
     cell_hb_sync();
     cell_rows_gen_++;
     cell_stale_ = true; lists_valid_ = false;
@@ -1996,6 +2011,7 @@ template <class real> void Engine<real>::cell_refresh(const CellSys<real>& C) {
         hipLaunchKernelGGL(cell_rows_kernel<real>, gr, b, 0, stream_, dsys_, C, cur, force);
         if (cell_hb_.n_beta + cell_hb_.n_pap) {
             const dim3 gh((unsigned)std::max(1LL, std::min(((long long)cell_hb_maxacc_ * AWSEM_ROW + 255) / 256, 16384LL)), nrep_, cell_hb_.n_beta + cell_hb_.n_pap);
+            cell_hb_prepare(C, cur, force);
             hipLaunchKernelGGL(cell_hb_rows_kernel<real>, gh, b, 0, stream_, cell_hb_, C, pos_, cur, force);
         }
         HIP_TRY(hipGetLastError());
@@ -2009,6 +2025,7 @@ template <class real> void Engine<real>::cell_refresh(const CellSys<real>& C) {
     hipLaunchKernelGGL(cell_rows_kernel<real>, gr, b, 0, stream_, dsys_, C, cur, force);
     if (cell_hb_.n_beta + cell_hb_.n_pap) {
         const dim3 gh((unsigned)std::max(1LL, std::min(((long long)cell_hb_maxacc_ * AWSEM_ROW + 255) / 256, 16384LL)), nrep_, cell_hb_.n_beta + cell_hb_.n_pap);
+        cell_hb_prepare(C, cur, force);
         hipLaunchKernelGGL(cell_hb_rows_kernel<real>, gh, b, 0, stream_, cell_hb_, C, pos_, cur, force);
     }
     HIP_TRY(hipGetLastError());
@@ -2063,6 +2080,7 @@ template <class real> void Engine<real>::cell_forces_pass(bool energy, unsigned 
     }
     if (cell_hb_.n_beta + cell_hb_.n_pap) {
         const dim3 g(row_blocks(cell_hb_maxacc_), nrep_, cell_hb_.n_beta + cell_hb_.n_pap);
+        if (rows_cur >= 0) cell_hb_prepare(C, rows_cur, rows_force);   // dynamics: the evaluation kernel builds the rows it walks on a rebuild step (otherwise cell_refresh has prepared)
         if (energy) hipLaunchKernelGGL((cell_hb_eval_kernel<true, real>), g, b, 0, stream_, cell_hb_, C, pos_, mask, rows_cur, rows_force);
         else hipLaunchKernelGGL((cell_hb_eval_kernel<false, real>), g, b, 0, stream_, cell_hb_, C, pos_, mask, rows_cur, rows_force);
     }
