@@ -415,8 +415,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": _measured_traffic(args, oa), "kernel": "cell-list step (kernel sequence)" if synthetic else "awsem_step_kernel<float>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_replica_step": b_alg,
-                         "note": ("cell-list path: a step is a sequence of 11 grid-wide kernels (graph replay), each a few us of launch + latency "
-                                  "at this size (see DESIGN.md section 8)") if synthetic else
+                         "note": ("cell-list path: a step is a sequence of five grid-wide kernels (seven with hydrogen-bond terms; graph replay), each "
+                                  "about one round of waves long at this size (see DESIGN.md sections 8 and 11.1)") if synthetic else
                                  ("state is LDS-resident across the launch, so the kernel is VALU/LDS-bound, not HBM-bound "
                                   "(see DESIGN.md); the HBM fraction is reported because the metric asks for it")},
         }
