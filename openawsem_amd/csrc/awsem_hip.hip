@@ -134,8 +134,9 @@ public:
             long long p[16] = {0};
             (void)hipDeviceSynchronize();
             if (hipMemcpy(p, dsys_.prof, sizeof p, hipMemcpyDeviceToHost) == hipSuccess) {
-                static const char* names[10] = {"vsites", "zero+displacement", "list rebuild", "rho zero", "density+fm", "single+harm+rama",
-                                                "pairs+beta", "chain+chi+dh+excl+pap", "redistribute", "integrate"};
+                // (the rebuild is split by builder: build_lists_prof in awsem_kernels.h)
+                static const char* names[10] = {"vsites", "rebuild: contact", "rebuild: pap + rest", "rebuild: excl", "density+fm", "single+harm+rama",
+                                                "pairs+beta", "chain+chi+dh+excl+pap", "rebuild: beta", "integrate"};
                 long long tot = 0;
                 for (int k = 0; k < 10; k++) tot += p[k];
                 if (tot > 0) for (int k = 0; k < 10; k++) fprintf(stderr, "[awsem prof] %-24s %14lld cycles  %5.1f %%\n", names[k], p[k], 100.0 * p[k] / tot);

@@ -1322,6 +1322,26 @@ template <bool LEAN = false, class V> __device__ __forceinline__ void build_list
     for (int i = threadIdx.x; i < S.natoms; i += L.nthr) L.zero_force(i);   // the builders staged their tables in the accumulators
 }
 
+#ifdef AWSEM_PROF
+// -DAWSEM_PROF experiment builds: the rebuild split by builder -- contact into slot 1, excluded volume into slot 3, beta into slot 8
+// (three slots no phase of the step kernel uses), P-AP and the clearing of the staging area stay in slot 2 with the caller's stamp
+template <bool LEAN = false, class V> __device__ __forceinline__ void build_lists_prof(const DevSys<typename V::real_t>& S, const V& L, unsigned mask, AwsemProf& awsem_prof) {
+    for (int t = 0; t < S.n_contact; t++) if (AWSEM_ON(S.contact[t])) build_contact(S.contact[t], L, L.satom + t * S.max_contact_sites, S.status);
+    AWSEM_ARRIVE(1);
+    for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) build_excl(S.excl[t], L, S.status);
+    AWSEM_ARRIVE(3);
+    for (int t = 0; t < S.n_beta; t++) if (AWSEM_ON(S.beta[t])) {
+        if (LEAN || !S.beta[t].scan_mode) build_hbond<LEAN>(S.beta[t], L, S.status);
+        else if (S.beta[t].list_owner) build_hbond_group(S.beta[t], S.beta_dev, t, S.n_beta, L, S.status);
+    }
+    AWSEM_ARRIVE(8);
+    for (int t = 0; t < S.n_pap; t++) if (AWSEM_ON(S.pap[t])) {
+        if (LEAN || !S.pap[t].scan_mode) build_hbond<LEAN>(S.pap[t], L, S.status);
+        else if (S.pap[t].list_owner) build_hbond_group(S.pap[t], S.pap_dev, t, S.n_pap, L, S.status);
+    }
+    for (int i = threadIdx.x; i < S.natoms; i += L.nthr) L.zero_force(i);
+}
+#endif
 // Evaluate every term whose group is in `mask` from the current pair lists.  Forces accumulate into the view and the
 // density of the first contact term into L.rho: both zeroed by the caller and visible (call after a __syncthreads());
 // ends with all contributions visible to the workgroup.
@@ -2006,7 +2026,12 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
             if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
             for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) { const int i = S.massive[k].atom; L.set_ref(i, L.pos(i)); }
             __syncthreads();
+#ifdef AWSEM_PROF
+            AWSEM_ARRIVE(2);
+            build_lists_prof<LEAN != 0>(S, L, 0xffffffffu, awsem_prof);
+#else
             build_lists<LEAN != 0>(S, L, 0xffffffffu);
+#endif
             AWSEM_ARRIVE(2);
             __syncthreads();
             AWSEM_STAMP(S, 2);
