@@ -654,25 +654,45 @@ template <class real> struct CellViewP : CellView<real> {
     __device__ __forceinline__ CellViewP(const CellView<real>& b, const Rec<real>* q) : CellView<real>(b), p4(q) {}
     __device__ __forceinline__ R3<real> pos(int a) const { const Rec<real> q = p4[a]; return R3<real>{q.x, q.y, q.z}; }
 };
-// ... and with the forces on the ROW's acceptor atoms summed in registers.  The sixteen lanes of a row walk the partners of one
-// acceptor: every one of them adds to the same two or three atoms, and same-address atomics of one instruction are served one after
-// the other (measured: 39 of the hydrogen-bond kernel's 90 us at 20 008 residues).  The lanes keep those contributions as integers,
-// the row adds them up with shuffles and nine lanes issue one atomic each: the same sums bit for bit (fixed point), 16 times fewer
-// atomics on the contended addresses.  The donors' atoms differ from lane to lane and keep their atomics.
-__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m, int width) {
-    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, m, width), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), m, width);
-    return ((u64)hi << 32) | lo;
-}
+// ... and with the forces collected per workgroup before they reach the force array.  The sixteen lanes of a row walk the partners of
+// ONE acceptor, and the sixteen acceptors of a workgroup are neighbours along a chain that see the same donors: most atomics of this
+// kernel hit an address that other lanes of the same instruction, or other rows of the same workgroup, hit at the same moment, and
+// same-address atomics are served one after the other (measured with the atomics compiled out: 62 of the kernel's 90 us at 20 008
+// residues were theirs, 39 of them the acceptor atoms').  The contributions go to a workgroup-local table in LDS instead -- open
+// addressing on the atom index, AWSEM_HB_SLOTS slots, a neighbourhood of AWSEM_HB_PROBES probes, beyond that the global atomic --
+// and every occupied slot is added to the force array once, when the workgroup's rows are done: the same fixed-point sums bit for
+// bit.  (Summing the acceptor atoms' share in registers and across the row with shuffles, the first form, was slower than the table.)
+#define AWSEM_HB_SLOTS 512
+#define AWSEM_HB_PROBES 8
 template <class real> struct CellViewHb : CellViewP<real> {
-    int a0, a1, a2;
-    mutable u64 x0, y0, z0, x1, y1, z1, x2, y2, z2;
-    __device__ __forceinline__ CellViewHb(const CellView<real>& b, const Rec<real>* q) : CellViewP<real>(b, q), a0(-1), a1(-1), a2(-1), x0(0), y0(0), z0(0), x1(0), y1(0), z1(0), x2(0), y2(0), z2(0) {}
-    __device__ __forceinline__ void begin_row(int b0, int b1, int b2) { a0 = b0; a1 = b1; a2 = b2; x0 = y0 = z0 = x1 = y1 = z1 = x2 = y2 = z2 = 0; }
+    int* tkey;    // LDS [AWSEM_HB_SLOTS] atom index, -1 = free
+    u64* tacc;    // LDS [AWSEM_HB_SLOTS][3]
+    __device__ __forceinline__ CellViewHb(const CellView<real>& b, const Rec<real>* q, int* key, u64* acc) : CellViewP<real>(b, q), tkey(key), tacc(acc) {}
+    // every thread of the workgroup, before the first and after the last row
+    __device__ __forceinline__ void table_clear() const {
+        for (int sl = threadIdx.x; sl < AWSEM_HB_SLOTS; sl += blockDim.x) { tkey[sl] = -1; tacc[3 * sl] = 0; tacc[3 * sl + 1] = 0; tacc[3 * sl + 2] = 0; }
+        __syncthreads();
+    }
+    __device__ __forceinline__ void table_flush() const {
+        __syncthreads();
+        for (int sl = threadIdx.x; sl < AWSEM_HB_SLOTS; sl += blockDim.x) {
+            const int atom = tkey[sl];
+            if (atom < 0) continue;
+            const u64 X = tacc[3 * sl], Y = tacc[3 * sl + 1], Z = tacc[3 * sl + 2];
+            if (X) fixed_add(&this->fx[atom], X);
+            if (Y) fixed_add(&this->fy[atom], Y);
+            if (Z) fixed_add(&this->fz[atom], Z);
+        }
+    }
     __device__ __forceinline__ void book(int i, u64 X, u64 Y, u64 Z) const {   // += on atom i
-        if (i == a0) { x0 += X; y0 += Y; z0 += Z; }
-        else if (i == a1) { x1 += X; y1 += Y; z1 += Z; }
-        else if (i == a2) { x2 += X; y2 += Y; z2 += Z; }
-        else { fixed_add(&this->fx[i], X); fixed_add(&this->fy[i], Y); fixed_add(&this->fz[i], Z); }
+        unsigned h = ((unsigned)i * 2654435761u) >> 23;   // 9 bits: AWSEM_HB_SLOTS
+#pragma unroll 1
+        for (int probe = 0; probe < AWSEM_HB_PROBES; probe++) {
+            const int old = atomicCAS(&tkey[h], -1, i);
+            if (old == -1 || old == i) { fixed_add(&tacc[3 * h], X); fixed_add(&tacc[3 * h + 1], Y); fixed_add(&tacc[3 * h + 2], Z); return; }
+            h = (h + 1) & (AWSEM_HB_SLOTS - 1);
+        }
+        fixed_add(&this->fx[i], X); fixed_add(&this->fy[i], Y); fixed_add(&this->fz[i], Z);
     }
     __device__ __forceinline__ void pair_force(int i, int j, real dx, real dy, real dz, real s) const {
         const real t = s * (real)AWSEM_FIXED_SCALE;
@@ -680,24 +700,8 @@ template <class real> struct CellViewHb : CellViewP<real> {
         book(i, X, Y, Z);
         book(j, (u64)0 - X, (u64)0 - Y, (u64)0 - Z);
     }
-    static __device__ __forceinline__ u64 row_sum(u64 v) {
-#pragma unroll
-        for (int m = AWSEM_ROW / 2; m > 0; m >>= 1) v += shfl_xor_u64(v, m, AWSEM_ROW);
-        return v;
-    }
-    // all sixteen lanes of the row (whether or not they had a partner)
-    __device__ __forceinline__ void end_row(int sub) const {
-        const u64 r0 = row_sum(x0), r1 = row_sum(y0), r2 = row_sum(z0), r3 = row_sum(x1), r4 = row_sum(y1), r5 = row_sum(z1), r6 = row_sum(x2), r7 = row_sum(y2), r8 = row_sum(z2);
-        const u64 mine = sub == 0 ? r0 : sub == 1 ? r1 : sub == 2 ? r2 : sub == 3 ? r3 : sub == 4 ? r4 : sub == 5 ? r5 : sub == 6 ? r6 : sub == 7 ? r7 : r8;
-        // (No select among the members a0..a2 or fx..fz themselves: the compiler turns a select of adjacent struct fields into an indexed
-        // load from the struct, which then lives in scratch -- 272 B per lane here.  The atoms pass through a shuffle, the component
-        // plane is reached by its distance from fx: the three planes are one array, cell_view.)
-        const int q = sub / 3, comp = sub - 3 * q;
-        const int b0 = __shfl(a0, 0, AWSEM_ROW), b1 = __shfl(a1, 0, AWSEM_ROW), b2 = __shfl(a2, 0, AWSEM_ROW);
-        const int atom = sub < 9 ? (q == 0 ? b0 : q == 1 ? b1 : b2) : -1;
-        if (atom >= 0 && mine != 0) fixed_add(this->fx + (size_t)comp * (size_t)(this->fy - this->fx) + atom, mine);
-    }
 };
+static_assert((AWSEM_HB_SLOTS & (AWSEM_HB_SLOTS - 1)) == 0 && AWSEM_HB_SLOTS == 512, "CellViewHb::book hashes to 9 bits");
 template <bool ENERGY, class V> __device__ __forceinline__ void hb_pair(const BetaD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e) { beta_pair<ENERGY>(d, L, A, D, e); }
 template <bool ENERGY, class V> __device__ __forceinline__ void hb_pair(const PapD<typename V::real_t>& d, const V& L, const Int4& A, const Int4& D, Energy& e) { pap_pair<ENERGY>(d, L, A, D, e); }
 
@@ -705,7 +709,7 @@ template <bool ENERGY, class V> __device__ __forceinline__ void hb_pair(const Pa
 // rows and list radii sit in device memory and are fetched with scalar loads (blockIdx.z is uniform).
 // pos4: [R][natoms] the coordinates once more as packed {x, y, z, -} records, written by cell_hb_prepare_kernel before every walk.  The
 // hydrogen-bond kernels gather up to six atoms per pair from all over the system; from the SoA arrays that is three cache lines per atom
-// and lane, and the kernel was bound by exactly that (48 vector-memory instructions per wave, 80 % of its cycles waiting on them).
+// and lane, from the records one (a third of the kernel's vector-memory instructions; what it waited for, though, were its atomics).
 template <class real> struct HbTerms { const BetaD<real>* beta; const PapD<real>* pap; const HbRows* rows; const real* rc2; int n_beta, n_pap; Rec<real>* pos4; };
 
 // Donor rows of one hydrogen-bond term: for every acceptor the donors whose screening atom lies inside the list radius (and whose table
@@ -957,8 +961,9 @@ template <class real> __device__ void cell_sort_body(const CellSys<real>& C, con
 template <class real> __global__ __launch_bounds__(256) void cell_sort_kernel(CellSys<real> C, const real* __restrict__ pos, int cur, int force) {
     cell_sort_body(C, pos, (int)blockIdx.y >> 1, (int)blockIdx.y & 1, (int)blockIdx.x, (int)gridDim.x, cur, force);
 }
-template <bool ENERGY, class real, class Desc> __device__ __forceinline__ void hb_eval_body(const Desc& d, const CellSys<real>& C, const HbRows& H, const real* __restrict__ pos, const Rec<real>* __restrict__ pos4, int rep) {
-    CellViewHb<real> L(cell_view_plain(C, pos, rep), pos4 + (size_t)rep * C.natoms);
+template <bool ENERGY, class real, class Desc> __device__ __forceinline__ void hb_eval_body(const Desc& d, const CellSys<real>& C, const HbRows& H, const real* __restrict__ pos, const Rec<real>* __restrict__ pos4, int rep, int* hb_key, u64* hb_acc) {
+    CellViewHb<real> L(cell_view_plain(C, pos, rep), pos4 + (size_t)rep * C.natoms, hb_key, hb_acc);
+    L.table_clear();
     const int sub = threadIdx.x & (AWSEM_ROW - 1);
     const unsigned* rows = H.rows + (size_t)rep * d.nacc * H.stride;
     const int* rc = H.row_count + (size_t)rep * d.nacc;
@@ -967,10 +972,9 @@ template <bool ENERGY, class real, class Desc> __device__ __forceinline__ void h
         const int cnt = rc[k];
         if (cnt == 0) continue;
         const Int4 A = d.acc[k];
-        L.begin_row(A.x, A.y, Desc::res_slot == 3 ? A.z : -1);   // (P-AP: two acceptor atoms, the third slot is the residue)
         for (int s = sub; s < cnt; s += AWSEM_ROW) hb_pair<ENERGY>(d, L, A, d.don[rows[(size_t)k * H.stride + s]], e);
-        L.end_row(sub);
     }
+    L.table_flush();
     flush_energy<ENERGY>(L, d.group, e);
 }
 template <bool ENERGY, class real> __global__ void cell_hb_eval_kernel(HbTerms<real> T, CellSys<real> C, const real* __restrict__ pos, unsigned mask,
@@ -978,14 +982,16 @@ template <bool ENERGY, class real> __global__ void cell_hb_eval_kernel(HbTerms<r
     const int rep = blockIdx.y, t = blockIdx.z;
     const HbRows H = T.rows[t];
     const bool build = rows_cur >= 0 && cell_rebuild(C, rep, rows_cur, rows_force);   // as in cell_density_excl_kernel
+    __shared__ int hb_key[AWSEM_HB_SLOTS];       // the workgroup's table of donor-side forces (CellViewHb)
+    __shared__ u64 hb_acc[3 * AWSEM_HB_SLOTS];
     if (t < T.n_beta) {
         const BetaD<real> d = T.beta[t];
         if (build) { hb_rows_body(d, C, H, T.pos4, T.rc2[t], rep); __syncthreads(); }
-        if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, T.pos4, rep);
+        if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, T.pos4, rep, hb_key, hb_acc);
     } else {
         const PapD<real> d = T.pap[t - T.n_beta];
         if (build) { hb_rows_body(d, C, H, T.pos4, T.rc2[t], rep); __syncthreads(); }
-        if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, T.pos4, rep);
+        if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, T.pos4, rep, hb_key, hb_acc);
     }
 }
 
