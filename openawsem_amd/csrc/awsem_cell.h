@@ -378,10 +378,21 @@ template <class real> __global__ void cell_rows_kernel(DevSys<real> S, CellSys<r
 template <class real> __device__ __forceinline__ void owner_add_force(const CellView<real>& L, int atom, u64 X, u64 Y, u64 Z) {
     L.fx[atom] += X; L.fy[atom] += Y; L.fz[atom] += Z;
 }
+// Workgroups go to the eight XCDs round robin (workgroup b to XCD b mod 8), and every XCD has an L2 of its own: with rows dealt to
+// workgroups in order, each XCD walked every eighth block of rows -- the whole system -- and pulled every member record, density and
+// switch value of the system into its L2, eight copies per pass.  xcd_block turns the index round so that XCD x gets a CONTIGUOUS
+// eighth of the blocks: rows are in cell order, so that is a slab of space, and an XCD's L2 holds the slab and its rim only.
+#ifndef AWSEM_XCDS
+#define AWSEM_XCDS 8
+#endif
+__device__ __forceinline__ int xcd_block(int b, int nb) {
+    const int q = nb / AWSEM_XCDS, r = nb - q * AWSEM_XCDS, x = b % AWSEM_XCDS, y = b / AWSEM_XCDS;
+    return x * q + (x < r ? x : r) + y;
+}
 #define AWSEM_ROW_LOOP(B, k)                                                                                              \
     const int sub = threadIdx.x & (AWSEM_ROW - 1);                                                                        \
     const int nrows_ = ((B).n + 3) & ~3;                                                                                  \
-    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows_; k += gridDim.x * blockDim.x / AWSEM_ROW)
+    for (int k = (xcd_block((int)blockIdx.x, (int)gridDim.x) * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows_; k += gridDim.x * blockDim.x / AWSEM_ROW)
 
 // Bonded terms, window by window: a workgroup stages the positions of AWSEM_WIN_SPAN consecutive atoms in LDS, runs
 // every item whose lowest atom lies in its window (the item lists are sorted by window at finalize) with LDS
@@ -455,7 +466,10 @@ template <bool ENERGY, bool WIN, class real> __global__ __launch_bounds__(256) v
         cell_window_body<ENERGY, true>(S, C, pos, wstart, nwin, mask, rep, (int)blockIdx.x);
         return;
     }
-    const int bx = (int)blockIdx.x - (WIN ? nwin : 0);
+    // (the index within the contact / excluded-volume range turned round for the XCDs: xcd_block.  The window blocks in front shift
+    // which XCD a block lands on by nwin mod 8 -- a rotation of the slabs, harmless.)
+    const int bx0 = (int)blockIdx.x - (WIN ? nwin : 0);
+    const int bx = bx0 < nb_contact ? xcd_block(bx0, nb_contact) : nb_contact + xcd_block(bx0 - nb_contact, nb_excl);
     const CellView<real> L = cell_view(S, C, pos, rep);
     Energy en;
     const bool build = rows_cur >= 0 && cell_rebuild(C, rep, rows_cur, rows_force);   // uniform over the replica
@@ -737,14 +751,14 @@ template <class real, class Desc> __device__ __forceinline__ void hb_spheres_bod
         if (vb && sub == 0) { sp[4 * b] = cx; sp[4 * b + 1] = cy; sp[4 * b + 2] = cz; sp[4 * b + 3] = sqrtf(r2); }
     }
 }
-template <class real, class Desc> __device__ __forceinline__ void hb_rows_body(const Desc& d, const CellSys<real>& C, const HbRows& H, const Rec<real>* __restrict__ pos4, real rc2, int rep) {
+template <class real, class Desc> __device__ __forceinline__ void hb_rows_body(const Desc& d, const CellSys<real>& C, const HbRows& H, const Rec<real>* __restrict__ pos4, real rc2, int rep, int bx) {
     const Rec<real>* p4 = pos4 + (size_t)rep * C.natoms;
     const float* sp = H.spheres + (size_t)rep * H.nblocks * 4;
     const int lane = threadIdx.x & 63, sub = threadIdx.x & (AWSEM_ROW - 1), row_in_wave = lane / AWSEM_ROW;
     const int nrows_total = (d.nacc + 3) & ~3;   // whole waves: the ballots are wave collectives
     const float reach = sqrtf((float)rc2) + 1e-3f;   // list radius plus a margin for the spheres' fp32 arithmetic
     unsigned* rows = H.rows + (size_t)rep * d.nacc * H.stride;
-    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows_total; k += gridDim.x * blockDim.x / AWSEM_ROW) {
+    for (int k = (bx * blockDim.x + threadIdx.x) / AWSEM_ROW; k < nrows_total; k += gridDim.x * blockDim.x / AWSEM_ROW) {
         const bool vi = k < d.nacc;
         const Int4 A = d.acc[vi ? k : 0];
         const int ares = Desc::res_slot == 3 ? A.w : A.z;
@@ -808,8 +822,8 @@ template <class real> __global__ void cell_hb_rows_kernel(HbTerms<real> T, CellS
     if (!cell_rebuild(C, rep, cur, force)) return;
     const HbRows H = T.rows[t];
     const real rc2 = T.rc2[t];
-    if (t < T.n_beta) { const BetaD<real> d = T.beta[t]; hb_rows_body(d, C, H, T.pos4, rc2, rep); }
-    else { const PapD<real> d = T.pap[t - T.n_beta]; hb_rows_body(d, C, H, T.pos4, rc2, rep); }
+    if (t < T.n_beta) { const BetaD<real> d = T.beta[t]; hb_rows_body(d, C, H, T.pos4, rc2, rep, (int)blockIdx.x); }
+    else { const PapD<real> d = T.pap[t - T.n_beta]; hb_rows_body(d, C, H, T.pos4, rc2, rep, (int)blockIdx.x); }
 }
 
 // ------------------------------------------------------------------ the rebuild without launches of its own (round 3)
@@ -961,14 +975,14 @@ template <class real> __device__ void cell_sort_body(const CellSys<real>& C, con
 template <class real> __global__ __launch_bounds__(256) void cell_sort_kernel(CellSys<real> C, const real* __restrict__ pos, int cur, int force) {
     cell_sort_body(C, pos, (int)blockIdx.y >> 1, (int)blockIdx.y & 1, (int)blockIdx.x, (int)gridDim.x, cur, force);
 }
-template <bool ENERGY, class real, class Desc> __device__ __forceinline__ void hb_eval_body(const Desc& d, const CellSys<real>& C, const HbRows& H, const real* __restrict__ pos, const Rec<real>* __restrict__ pos4, int rep, int* hb_key, u64* hb_acc) {
+template <bool ENERGY, class real, class Desc> __device__ __forceinline__ void hb_eval_body(const Desc& d, const CellSys<real>& C, const HbRows& H, const real* __restrict__ pos, const Rec<real>* __restrict__ pos4, int rep, int bx, int* hb_key, u64* hb_acc) {
     CellViewHb<real> L(cell_view_plain(C, pos, rep), pos4 + (size_t)rep * C.natoms, hb_key, hb_acc);
     L.table_clear();
     const int sub = threadIdx.x & (AWSEM_ROW - 1);
     const unsigned* rows = H.rows + (size_t)rep * d.nacc * H.stride;
     const int* rc = H.row_count + (size_t)rep * d.nacc;
     Energy e;
-    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / AWSEM_ROW; k < d.nacc; k += gridDim.x * blockDim.x / AWSEM_ROW) {
+    for (int k = (bx * blockDim.x + threadIdx.x) / AWSEM_ROW; k < d.nacc; k += gridDim.x * blockDim.x / AWSEM_ROW) {
         const int cnt = rc[k];
         if (cnt == 0) continue;
         const Int4 A = d.acc[k];
@@ -982,16 +996,17 @@ template <bool ENERGY, class real> __global__ void cell_hb_eval_kernel(HbTerms<r
     const int rep = blockIdx.y, t = blockIdx.z;
     const HbRows H = T.rows[t];
     const bool build = rows_cur >= 0 && cell_rebuild(C, rep, rows_cur, rows_force);   // as in cell_density_excl_kernel
-    __shared__ int hb_key[AWSEM_HB_SLOTS];       // the workgroup's table of donor-side forces (CellViewHb)
+    const int bx = xcd_block((int)blockIdx.x, (int)gridDim.x);   // acceptors are in chain order and a chain is a blob in space: a contiguous range per XCD
+    __shared__ int hb_key[AWSEM_HB_SLOTS];       // the workgroup's table of forces (CellViewHb)
     __shared__ u64 hb_acc[3 * AWSEM_HB_SLOTS];
     if (t < T.n_beta) {
         const BetaD<real> d = T.beta[t];
-        if (build) { hb_rows_body(d, C, H, T.pos4, T.rc2[t], rep); __syncthreads(); }
-        if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, T.pos4, rep, hb_key, hb_acc);
+        if (build) { hb_rows_body(d, C, H, T.pos4, T.rc2[t], rep, bx); __syncthreads(); }
+        if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, T.pos4, rep, bx, hb_key, hb_acc);
     } else {
         const PapD<real> d = T.pap[t - T.n_beta];
-        if (build) { hb_rows_body(d, C, H, T.pos4, T.rc2[t], rep); __syncthreads(); }
-        if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, T.pos4, rep, hb_key, hb_acc);
+        if (build) { hb_rows_body(d, C, H, T.pos4, T.rc2[t], rep, bx); __syncthreads(); }
+        if (AWSEM_ON(d)) hb_eval_body<ENERGY>(d, C, H, pos, T.pos4, rep, bx, hb_key, hb_acc);
     }
 }
 
