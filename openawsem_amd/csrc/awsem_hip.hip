@@ -246,7 +246,7 @@ public:
         if (cell_mode_) { cell_evaluate(true, mask, 0, e, nullptr); return; }
         const bool reuse = query_reuse();
         HIP_TRY(hipEventRecord(ev0_, stream_));
-        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, 0, (double*)nullptr);
+        launch_eval<true>(dim3(nrep_), stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, 0, (double*)nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1_, stream_));
         HIP_TRY(hipMemcpyAsync(e, dE_, sizeof(double) * nrep_ * AWSEM_NGROUPS, hipMemcpyDeviceToHost, stream_));
@@ -259,7 +259,7 @@ public:
         if (cell_mode_) { cell_evaluate(false, mask, redistribute, nullptr, f); return; }
         const bool reuse = query_reuse();
         HIP_TRY(hipEventRecord(ev0_, stream_));
-        hipLaunchKernelGGL((awsem_eval_kernel<false, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, redistribute, (double*)nullptr, dF_, (const double*)nullptr, (int)reuse, 0, (double*)nullptr);
+        launch_eval<false>(dim3(nrep_), stream_, reuse ? dsys_ : eval_sys(), pos_, mask, redistribute, (double*)nullptr, dF_, (const double*)nullptr, (int)reuse, 0, (double*)nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1_, stream_));
         HIP_TRY(hipMemcpyAsync(f, dF_, sizeof(double) * 3 * natoms_ * nrep_, hipMemcpyDeviceToHost, stream_));
@@ -315,7 +315,7 @@ public:
         }
         const bool reuse = query_reuse();
         // the sum over the masked groups comes out of the energy kernel itself (one launch fewer per exchange)
-        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep_), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, 0, out);
+        launch_eval<true>(dim3(nrep_), stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, 0, out);
         HIP_TRY(hipGetLastError());
     }
     void remd_sweep(const double* d_all, int64_t iteration) override {
@@ -488,7 +488,7 @@ public:
             const bool reuse = query_reuse();
             // one replica's energies (what StateDataReporter prints) are one workgroup; the other rows of the slot are left as NaN
             const int first = energy_replica >= 0 ? energy_replica : 0, count = energy_replica >= 0 ? 1 : nrep_;
-            hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(count), dim3(block_), lds_eval_, stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, first, (double*)nullptr);
+            launch_eval<true>(dim3(count), stream_, reuse ? dsys_ : eval_sys(), pos_, mask, 0, dE_, (double*)nullptr, (const double*)nullptr, (int)reuse, first, (double*)nullptr);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(sn.e + (size_t)first * AWSEM_NGROUPS, dE_ + (size_t)first * AWSEM_NGROUPS, sizeof(double) * count * AWSEM_NGROUPS, hipMemcpyDeviceToHost, stream_));
         }
@@ -565,7 +565,7 @@ public:
         S.status = (int*)base;
         S.lists = (unsigned*)(base + 256);
         HIP_TRY(hipMemsetAsync(base, 0, 256, stream));   // the status word must start at zero; the lists are written before they are read
-        hipLaunchKernelGGL((awsem_eval_kernel<true, real>), dim3(nrep), dim3(block_), lds_eval_, stream, S, (const real*)nullptr, 0xffffffffu, 0,
+        launch_eval<true>(dim3(nrep), stream, S, (const real*)nullptr, 0xffffffffu, 0,
                            d_energy, (double*)nullptr, d_xyz, 0, 0, (double*)nullptr);
         const hipError_t launched = hipGetLastError();
         if (caller_device != device_) (void)hipSetDevice(caller_device);
@@ -804,6 +804,15 @@ private:
     // in a buffer of their own (lists_eval_), so a reporter between two launches costs the dynamics nothing.  AWSEM_LIST_REUSE=0: off.
     bool lists_valid_ = false, list_reuse_ = true, query_reuse_ = true;
     int step_lean_ = 0;   // which instantiation of the step kernel runs (evaluate_terms: LEAN)
+    // every launch of the evaluation kernel: the same instantiation as the step kernel's (one code path per handle, whoever asks)
+    template <bool ENERGY, class... A> void launch_eval(dim3 grid, hipStream_t st, const DevSys<real>& S, A... args) {
+        switch (step_lean_) {
+        case 1: hipLaunchKernelGGL((awsem_eval_kernel<ENERGY, real, 1>), grid, dim3(block_), lds_eval_, st, S, args...); break;
+        case 2: hipLaunchKernelGGL((awsem_eval_kernel<ENERGY, real, 2>), grid, dim3(block_), lds_eval_, st, S, args...); break;
+        case 3: hipLaunchKernelGGL((awsem_eval_kernel<ENERGY, real, 3>), grid, dim3(block_), lds_eval_, st, S, args...); break;
+        default: hipLaunchKernelGGL((awsem_eval_kernel<ENERGY, real, 0>), grid, dim3(block_), lds_eval_, st, S, args...); break;
+        }
+    }
     std::mutex capture_mu_;   // graph capture on stream_ (cell_step) against event waits from another thread (snapshot_end)
     double lists_skin_ = 0;
     unsigned* lists_eval_ = nullptr;
@@ -1664,8 +1673,14 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     }
     // launch geometry: one workgroup per replica, LDS sized by the system
     step_ok_ = lds_step_ <= lds_max;   // energies/forces need less LDS than dynamics (no velocities, no list reference positions)
-    HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<true, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
-    HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<false, real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
+    HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<true, real, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
+    HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<false, real, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
+    HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<true, real, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
+    HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<false, real, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
+    HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<true, real, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
+    HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<false, real, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
+    HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<true, real, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
+    HIP_TRY(hipFuncSetAttribute((const void*)awsem_eval_kernel<false, real, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));

@@ -1531,7 +1531,8 @@ __device__ __forceinline__ void book_displacement(unsigned* flag, float m) {
 #define AWSEM_FP64_THREADS 512
 #endif
 #define AWSEM_BOUNDS(real) __launch_bounds__(sizeof(real) == 8 ? AWSEM_FP64_THREADS : 1024)
-template <bool ENERGY, class real>
+// LEAN: as for the step kernel (evaluate_terms): the instantiation without the code of the term shapes the system does not hold.
+template <bool ENERGY, class real, int LEAN = 0>
 __global__ AWSEM_BOUNDS(real) void awsem_eval_kernel(const DevSys<real> S, const real* __restrict__ pos, unsigned mask, int redistribute,
                                   double* __restrict__ e_out /* [R][32] or null */, double* __restrict__ f_out /* [R][natoms][3] or null */,
                                   const double* __restrict__ xyz_aos /* null, or [R][natoms][3] in the caller's atom order instead of `pos` */,
@@ -1540,7 +1541,8 @@ __global__ AWSEM_BOUNDS(real) void awsem_eval_kernel(const DevSys<real> S, const
                                   double* __restrict__ e_sum /* null, or [R]: the sum over the masked groups (what awsem_group_sum_kernel makes of e_out) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = (int)blockIdx.x + rep0;
-    Lds<real> L = carve_lds((real)0, smem, lds_shape(S), false);
+    typedef typename std::conditional<LEAN == 3, LdsLeanZ<real>, typename std::conditional<LEAN != 0, LdsLean<real>, Lds<real>>::type>::type View;
+    View L(carve_lds((real)0, smem, lds_shape(S), false));
     L.lists = S.lists + (size_t)rep * S.list_stride;
     if (xyz_aos) {   // uniform; awsem_energy_by_group_noalloc: the caller's device buffer, converted like the host does ((real) of the double)
         const double* x = xyz_aos + (size_t)rep * 3 * natoms;
@@ -1580,12 +1582,12 @@ __global__ AWSEM_BOUNDS(real) void awsem_eval_kernel(const DevSys<real> S, const
         }
     }
     if (build) {
-        build_lists(S, L, reuse ? 0xffffffffu : mask);
+        build_lists<LEAN != 0>(S, L, reuse ? 0xffffffffu : mask);
         __syncthreads();
         if (reuse && threadIdx.x < AWSEM_MAX_LISTS) S.list_counts[(size_t)rep * AWSEM_MAX_LISTS + threadIdx.x] = L.lcount[threadIdx.x];
     }
     AWSEM_STAMP_INIT;
-    evaluate_terms<ENERGY>(S, L, mask, false AWSEM_STAMP_PASS);
+    evaluate_terms<ENERGY, false, LEAN>(S, L, mask, false AWSEM_STAMP_PASS);
     if (f_out) {
         if (redistribute) { redistribute_forces(S, L); __syncthreads(); }
         double* f = f_out + (size_t)rep * 3 * natoms;
