@@ -307,7 +307,8 @@ def main():
         elapsed = float(t.item())
 
     # replica exchange: what one exchange costs with the launch's lists in place -- back-to-back sweeps on unchanged positions (energy
-    # kernel walking the lists the last launch left, group sum, [all-gather,] sweep kernel, velocity rescale), outside the timed region
+    # kernel walking the lists the last launch left, group sum, [all-gather,] sweep kernel; the velocity factors accumulate on the device for
+    # the next step launch to take in), outside the timed region
     exchange_us = None
     if remd is not None:
         barrier()
@@ -451,7 +452,7 @@ def main():
             out["remd_exchange_us"] = exchange_us
             out["remd_iteration_minus_step_kernel_us"] = (elapsed / args.steps - k_ms * 1e-3) * 1e6
             out["config"]["remd_exchange"] = ("per iteration: energy kernel + group sum into a device buffer, "
-                                              + ("one all_gather_into_tensor over RCCL, " if world > 1 else "") + "sweep kernel (Metropolis, ladder index swap), velocity rescale; no host copy")
+                                              + ("one all_gather_into_tensor over RCCL, " if world > 1 else "") + "sweep kernel (Metropolis, ladder index swap); the velocity rescale rides in the next step launch's velocity load; no host copy")
         if not args.no_cpu_baseline and world == 1 and args.workload == "1r69":
             out["cpu_baseline"] = cpu_baseline(oa, args.md_steps)
         print(json.dumps(out), flush=True)

@@ -331,6 +331,8 @@ int awsem_synchronize(awsem_handle h);
  *                        (i, i+1) with i of the parity of `iteration`, accepted when delta = (beta_i - beta_i+1)(U_a - U_b) >= 0
  *                        or u < exp(delta), u = Philox4x32-10(counter (i, iteration, 'REMD'), key seed) -- the stream
  *                        openawsem_amd/ensemble.py:counter_uniform reproduces on the host; then rescales the local velocities
+ *                        (as a factor per replica that the next step launch multiplies in when it loads them; every other call
+ *                        that reads or writes velocities applies it first, so callers always see the rescaled velocities)
  *   awsem_remd_set_mixing  0 (default): the neighbour sweep above.  1: openmmtools' DEFAULT scheme 'swap-all', which the reference gets by
  *                        passing no replica_mixing_scheme (scripts/mm_remd.py:133-140): n_total^3 attempts per iteration on uniformly
  *                        drawn replica pairs (i, j), each accepted when (beta_si - beta_sj)(U_i - U_j) >= 0 or ln u < that; draws from

@@ -205,6 +205,8 @@ template <class real> struct DevSys {
     int prio;                             // step kernel: how the replicas sharing a CU take turns at issue priority (0: hardware default, oldest wave first;
                                           // 1: rotating with the step count; 2: rotating with the clock; 3 | gain*16 << 8: rotation shifted by a
                                           // per-replica bias learnt from launch to launch, see pace_bias)
+    double* vel_scale;                    // step kernel: [R] factors the velocities are multiplied by as they are loaded, then set back to 1 (the rescale of a
+                                          // replica-exchange sweep, taken in by the next launch); nullptr: none pending
     int pace_group;                       // number of CUs: workgroups b, b + pace_group, ... of a one-wave grid share a CU
     int* status;                          // device error word: bit 0 = a pair list overflowed
     long long* prof;                      // 16 phase-cycle accumulators (written by -DAWSEM_PROF builds only)

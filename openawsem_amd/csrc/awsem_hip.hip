@@ -212,8 +212,8 @@ public:
 
     void set_positions(int rep, const double* xyz) override { set_state(pos_, rep, xyz); cell_stale_ = true; lists_valid_ = false; }
     void get_positions(int rep, double* xyz) override { get_state(pos_, rep, xyz); }
-    void set_velocities(int rep, const double* v) override { set_state(vel_, rep, v); }
-    void get_velocities(int rep, double* v) override { get_state(vel_, rep, v); }
+    void set_velocities(int rep, const double* v) override { set_state(vel(), rep, v); }
+    void get_velocities(int rep, double* v) override { get_state(vel(), rep, v); }
 
     void compute_virtual_sites() override {
         HIP_TRY(hipSetDevice(device_));
@@ -228,7 +228,7 @@ public:
         HIP_TRY(hipSetDevice(device_));
         synchronize();
         upload_T(T);
-        hipLaunchKernelGGL(awsem_maxwell_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, vel_, dT_, (unsigned long long)seed);
+        hipLaunchKernelGGL(awsem_maxwell_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, vel(), dT_, (unsigned long long)seed);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream_));
     }
@@ -237,7 +237,7 @@ public:
         synchronize();
         HIP_TRY(hipMemcpyAsync(dtmp_, scale, sizeof(double) * nrep_, hipMemcpyHostToDevice, stream_));   // not dT_: on a replica-exchange handle that holds the ladder's temperatures
         HIP_TRY(hipStreamSynchronize(stream_));   // scale is a caller-owned pageable buffer
-        hipLaunchKernelGGL(awsem_scale_velocities_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, vel_, dtmp_, 3 * natoms_);
+        hipLaunchKernelGGL(awsem_scale_velocities_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, vel(), dtmp_, 3 * natoms_);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream_));
     }
@@ -283,6 +283,8 @@ public:
         }
         remd_tmax_ = tmax;
         // a second set-up on the same handle (a new ladder, a restart) replaces the first one's buffers
+        (void)vel();   // (a rescale still pending from the ladder this one replaces)
+        synchronize();
         dfree(remd_ladder_); dfree(remd_slot_); dfree(remd_where_); dfree(remd_counts_); dfree(remd_U_); dfree(remd_scale_); dfree(remd_T_);
         remd_ladder_ = upload(std::vector<double>(ladder, ladder + n_total));
         remd_slot_ = const_cast<int*>(upload(slot));
@@ -291,11 +293,24 @@ public:
         HIP_TRY(hipMemset(remd_counts_, 0, 2 * (size_t)std::max(1, n_total - 1) * sizeof(unsigned long long)));
         remd_U_ = dalloc<double>(n_total);
         HIP_TRY(hipMemset(remd_U_, 0, n_total * sizeof(double)));
-        remd_scale_ = dalloc<double>(nrep_);
+        remd_scale_ = const_cast<double*>(upload(std::vector<double>(nrep_, 1.0)));
         // The temperatures the replicas run at.  A buffer of its own, written by this call and by the sweep kernel only: awsem_step(T) and
         // awsem_set_velocities_to_temperature(T) on the same handle go through dT_ and cannot disturb the ladder's assignment.
         remd_T_ = dalloc<double>(nrep_);
         HIP_TRY(hipMemcpy(remd_T_, ladder + local_start, sizeof(double) * nrep_, hipMemcpyHostToDevice));   // replica r starts at ladder[r]
+    }
+    // The velocities with every rescale applied.  All of the engine reads and writes them through here except the step launch, which
+    // applies a pending rescale itself.  `wait`: for the readers that copy on the null stream (stream_ does not order with it); the ones
+    // that queue behind it on stream_ pass false.
+    real* vel(bool wait = true) {
+        if (vel_scale_pending_) {
+            vel_scale_pending_ = false;
+            HIP_TRY(hipSetDevice(device_));
+            hipLaunchKernelGGL(awsem_take_scale_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, vel_raw_, remd_scale_, 3 * natoms_);
+            HIP_TRY(hipGetLastError());
+            if (wait) HIP_TRY(hipStreamSynchronize(stream_));
+        }
+        return vel_raw_;
     }
     void need_remd() const { if (!remd_n_) throw StateError{"replica exchange: call awsem_remd_setup first"}; }
     void step_remd(int nsteps, double dt, double friction, uint64_t seed, int64_t step0) override {
@@ -331,7 +346,9 @@ public:
         hipLaunchKernelGGL(awsem_remd_sweep_kernel, dim3(1), dim3(256), 2 * (size_t)N * sizeof(int), stream_, d_all ? d_all : (const double*)remd_U_, remd_where_,
                            remd_ladder_, remd_slot_, remd_counts_, remd_counts_ + std::max(1, N - 1), N, (long long)iteration, (unsigned long long)remd_seed_,
                            remd_start_, nrep_, remd_T_, remd_scale_);
-        hipLaunchKernelGGL(awsem_scale_velocities_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, vel_, (const double*)remd_scale_, 3 * natoms_);
+        // The velocity rescale is not a launch of its own: the factors stay in remd_scale_ (a later sweep multiplies into them) until the
+        // next step launch takes them in with its velocity load, or until somebody else asks for the velocities (vel()).
+        vel_scale_pending_ = true;
         HIP_TRY(hipGetLastError());
     }
     void remd_set_mixing(int scheme) override {
@@ -364,7 +381,7 @@ public:
     }
     // T == nullptr: the temperatures already on the device (replica exchange) drive the launch
     void step_impl(int nsteps, const double* T, double dt, double friction, uint64_t seed, int64_t step0, int nstages = 1) {
-        if (cell_mode_) { cell_step(nsteps, T, dt, friction, seed, step0); return; }
+        if (cell_mode_) { (void)vel(false); cell_step(nsteps, T, dt, friction, seed, step0); return; }   // (no rescale left to settle inside a graph capture)
         if (!step_ok_) {
             char msg[256];
             snprintf(msg, sizeof msg, "dynamics of %d atoms needs %zu bytes of LDS per replica in this precision; the replica-resident path is limited to %zu",
@@ -381,14 +398,17 @@ public:
         if ((dsys_.prio & 0xff) == 3 && place_every_ > 0 && launch_ > 0 && launch_ % place_every_ == 0 && nrep_ <= 8192)   // deal the replicas to the CUs anew
             hipLaunchKernelGGL(awsem_place_kernel, dim3(1), dim3(1024), (size_t)nrep_ * sizeof(int), stream_, dsys_.prof, nrep_, dsys_.pace_group);
         const bool reuse = list_reuse_ && lists_valid_ && skin_ <= lists_skin_;
+        dsys_.vel_scale = vel_scale_pending_ ? remd_scale_ : nullptr;   // the last sweep's rescale rides in this launch's velocity load
+        vel_scale_pending_ = false;
         auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_, step_T_, nsteps, dt, friction,
+            hipLaunchKernelGGL(kernel, dim3(nrep_), dim3(block_), lds_step_, stream_, dsys_, pos_, vel_raw_, step_T_, nsteps, dt, friction,
                                (unsigned long long)seed, (long long)step0, launch_++, (int)reuse, nsteps / nstages);
         };
         if (step_lean_ == 1) launch(awsem_step_kernel<real, 1>);
         else if (step_lean_ == 2) launch(awsem_step_kernel<real, 2>);
         else if (step_lean_ == 3) launch(awsem_step_kernel<real, 3>);
         else launch(awsem_step_kernel<real, 0>);
+        dsys_.vel_scale = nullptr;
         // the skin the lists counted after this launch were built under: lists carried in from the previous launch carry ITS skin
         const double built_skin = reuse ? std::max(skin_, lists_skin_) : skin_;
         lists_valid_ = nsteps > 0;
@@ -423,7 +443,7 @@ public:
     void kinetic_energy(double* ke) override {
         HIP_TRY(hipSetDevice(device_));
         synchronize();
-        hipLaunchKernelGGL(awsem_kinetic_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, vel_, dtmp_);
+        hipLaunchKernelGGL(awsem_kinetic_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, vel(), dtmp_);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(ke, dtmp_, sizeof(double) * nrep_, hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
@@ -439,7 +459,7 @@ public:
             if (!src) continue;
             for (int r = 0; r < nrep_; r++) for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++)
                 t[r * n3 + (size_t)k * natoms_ + in_(i)] = (real)src[r * n3 + 3 * (size_t)i + k];
-            HIP_TRY(hipMemcpy(pass ? vel_ : pos_, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(pass ? vel() : pos_, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
             if (!pass) cell_stale_ = true; lists_valid_ = false;
         }
     }
@@ -451,7 +471,7 @@ public:
         for (int pass = 0; pass < 2; pass++) {
             double* dst = pass ? v : xyz;
             if (!dst) continue;
-            HIP_TRY(hipMemcpy(t.data(), pass ? vel_ : pos_, t.size() * sizeof(real), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(t.data(), pass ? vel() : pos_, t.size() * sizeof(real), hipMemcpyDeviceToHost));
             for (int r = 0; r < nrep_; r++) for (int i = 0; i < natoms_; i++) for (int k = 0; k < 3; k++)
                 dst[r * n3 + 3 * (size_t)i + k] = (double)t[r * n3 + (size_t)k * natoms_ + in_(i)];
         }
@@ -493,13 +513,13 @@ public:
             HIP_TRY(hipMemcpyAsync(sn.e + (size_t)first * AWSEM_NGROUPS, dE_ + (size_t)first * AWSEM_NGROUPS, sizeof(double) * count * AWSEM_NGROUPS, hipMemcpyDeviceToHost, stream_));
         }
         sn.energy_replica = cell_mode_ ? -1 : energy_replica;
-        hipLaunchKernelGGL(awsem_kinetic_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, vel_, dtmp_);
+        hipLaunchKernelGGL(awsem_kinetic_kernel<real>, dim3(nrep_), dim3(256), 0, stream_, dsys_, vel(false), dtmp_);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(sn.ke, dtmp_, sizeof(double) * nrep_, hipMemcpyDeviceToHost, stream_));
         if (replica >= 0) HIP_TRY(hipMemcpyAsync(sn.x1, pos_ + (size_t)replica * n3, sizeof(real) * n3, hipMemcpyDeviceToHost, stream_));
         if (with_state) {
             HIP_TRY(hipMemcpyAsync(sn.xs, pos_, sizeof(real) * n3 * nrep_, hipMemcpyDeviceToHost, stream_));
-            HIP_TRY(hipMemcpyAsync(sn.vs, vel_, sizeof(real) * n3 * nrep_, hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipMemcpyAsync(sn.vs, vel(), sizeof(real) * n3 * nrep_, hipMemcpyDeviceToHost, stream_));
         }
         HIP_TRY(hipEventRecord(sn.ev, stream_));
         sn.busy = true;
@@ -732,7 +752,8 @@ private:
     int npend_ = 0;
     std::vector<void*> allocs_;
     DevSys<real> dsys_;
-    real *pos_ = nullptr, *vel_ = nullptr;
+    real *pos_ = nullptr, *vel_raw_ = nullptr;   // vel_raw_: through vel(), which settles a pending rescale first
+    bool vel_scale_pending_ = false;
     double *dT_ = nullptr, *dE_ = nullptr, *dF_ = nullptr;
     double* dtmp_ = nullptr;   // per-replica doubles for everything that is not a temperature (kinetic energies, velocity factors)
     const HostSystem* host_ = nullptr;   // the system as the kernels see it: the handle's, or hint_ when the atoms are renumbered
@@ -1660,9 +1681,9 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
 
     // replica state and outputs
     size_t nstate = (size_t)nrep_ * 3 * natoms_;
-    pos_ = dalloc<real>(nstate); vel_ = dalloc<real>(nstate);
+    pos_ = dalloc<real>(nstate); vel_raw_ = dalloc<real>(nstate);
     HIP_TRY(hipMemset(pos_, 0, nstate * sizeof(real)));
-    HIP_TRY(hipMemset(vel_, 0, nstate * sizeof(real)));
+    HIP_TRY(hipMemset(vel_raw_, 0, nstate * sizeof(real)));
     dT_ = dalloc<double>(nrep_); dtmp_ = dalloc<double>(nrep_); dE_ = dalloc<double>((size_t)nrep_ * AWSEM_NGROUPS); dF_ = dalloc<double>(nstate);
 
     if (cell_mode_) {   // the cell-list kernels use no dynamic LDS
@@ -2135,7 +2156,7 @@ template <class real> void Engine<real>::cell_one_step(double dt, double frictio
         cell_pre(true);
         cell_refresh(cell_);
         cell_forces_pass(false, 0xffffffffu);
-        hipLaunchKernelGGL(cell_integrate_kernel<real>, cell_grid(dsys_.nmassive), dim3(256), 0, stream_, dsys_, cell_, pos_, vel_, dT_, dt, friction,
+        hipLaunchKernelGGL(cell_integrate_kernel<real>, cell_grid(dsys_.nmassive), dim3(256), 0, stream_, dsys_, cell_, pos_, vel(), dT_, dt, friction,
                            (unsigned long long)seed, (const long long*)cell_step_base_, offset, -1, (u64*)nullptr);
         return;
     }
@@ -2168,7 +2189,7 @@ template <class real> void Engine<real>::cell_one_step(double dt, double frictio
         cell_refresh(C);
         cell_forces_pass(false, 0xffffffffu, &C, false);
     }
-    hipLaunchKernelGGL(cell_integrate_kernel<real>, cell_grid(dsys_.nmassive), dim3(256), 0, stream_, dsys_, C, pos_, vel_, dT_, dt, friction,
+    hipLaunchKernelGGL(cell_integrate_kernel<real>, cell_grid(dsys_.nmassive), dim3(256), 0, stream_, dsys_, C, pos_, vel(), dT_, dt, friction,
                        (unsigned long long)seed, (const long long*)cell_step_base_, offset, cur ^ 1, cell_.f + (size_t)(cur ^ 1) * fstride);
     cell_cur_ = cur ^ 1;
 }
@@ -2187,7 +2208,7 @@ template <class real> void Engine<real>::cell_replay_if_overflowed() {
         std::vector<PendingStep> pend;
         pend.swap(cell_pending_);
         HIP_TRY(hipMemcpy(pos_, cell_snap_pos_, nstate * sizeof(real), hipMemcpyDeviceToDevice));
-        HIP_TRY(hipMemcpy(vel_, cell_snap_vel_, nstate * sizeof(real), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(vel(), cell_snap_vel_, nstate * sizeof(real), hipMemcpyDeviceToDevice));
         cell_per_site_ *= 2;
         cell_alloc_lists();   // marks the rows stale: the first replayed launch sizes and rebuilds them from the snapshot
         if (getenv("AWSEM_VERBOSE")) fprintf(stderr, "[awsem] neighbour row overflow during dynamics: rows regrown to %d per contact site, replaying %zu launch(es)\n", cell_per_site_, pend.size());
@@ -2249,7 +2270,7 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
         const size_t nstate = (size_t)nrep_ * 3 * natoms_;
         if (!cell_snap_pos_) { cell_snap_pos_ = dalloc<real>(nstate); cell_snap_vel_ = dalloc<real>(nstate); }
         HIP_TRY(hipMemcpyAsync(cell_snap_pos_, pos_, nstate * sizeof(real), hipMemcpyDeviceToDevice, stream_));
-        HIP_TRY(hipMemcpyAsync(cell_snap_vel_, vel_, nstate * sizeof(real), hipMemcpyDeviceToDevice, stream_));
+        HIP_TRY(hipMemcpyAsync(cell_snap_vel_, vel(), nstate * sizeof(real), hipMemcpyDeviceToDevice, stream_));
     }
     if (T) cell_pending_.push_back(PendingStep{nsteps, std::vector<double>(T, T + nrep_), dt, friction, seed, step0});
     else cell_pending_.clear();   // device-resident temperatures (replica exchange): the sweeps in between are not recorded, so such a launch is not replayable
@@ -2261,7 +2282,7 @@ template <class real> void Engine<real>::cell_step(int nsteps, const double* T, 
     auto set_base = [&](long long v) { hipLaunchKernelGGL(cell_set_word_kernel<long long>, dim3(1), dim3(1), 0, stream_, cell_step_base_, v); };
     if (dsys_.remove_cm) {   // the momentum the first step removes (later steps get it from the integrator before them)
         set_base((long long)step0);
-        hipLaunchKernelGGL(cell_momentum_kernel<real>, cell_grid(dsys_.nmassive), dim3(256), 0, stream_, dsys_, cell_, vel_, (const long long*)cell_step_base_);
+        hipLaunchKernelGGL(cell_momentum_kernel<real>, cell_grid(dsys_.nmassive), dim3(256), 0, stream_, dsys_, cell_, vel(), (const long long*)cell_step_base_);
     }
     while (s < nsteps) {
         // the rows are rebuilt unconditionally (a host-side decision baked into the launch) right after the coordinates were set

@@ -1665,6 +1665,15 @@ __global__ void awsem_maxwell_kernel(const DevSys<real> S, real* __restrict__ ve
     }
 }
 
+// the pending factors of a replica-exchange sweep applied on their own (a consumer other than the step kernel asks for the velocities)
+template <class real>
+__global__ void awsem_take_scale_kernel(real* __restrict__ vel, double* __restrict__ scale, int n3) {
+    const real s = (real)scale[blockIdx.x];
+    real* v = vel + (size_t)blockIdx.x * n3;
+    for (int i = threadIdx.x; i < n3; i += blockDim.x) v[i] *= s;
+    __syncthreads();
+    if (threadIdx.x == 0) scale[blockIdx.x] = 1.0;
+}
 template <class real>
 __global__ void awsem_scale_velocities_kernel(real* __restrict__ vel, const double* __restrict__ scale, int n3) {
     real* v = vel + (size_t)blockIdx.x * n3;
@@ -1715,7 +1724,7 @@ __global__ void awsem_remd_sweep_kernel(const double* __restrict__ U /* gathered
         const int r = local_start + k;
         const double Tn = ladder[slot[r]], To = ladder[old[r]];
         T_local[k] = Tn;
-        scale_local[k] = ::sqrt(Tn / To);
+        scale_local[k] *= ::sqrt(Tn / To);   // (1 unless an earlier sweep's factor has not been taken in yet: Engine::vel)
     }
 }
 
@@ -1784,7 +1793,7 @@ __global__ void awsem_remd_mix_all_kernel(const double* __restrict__ U, const in
         const int r = local_start + k;
         const double Tn = ladder[s[r]], To = ladder[old[r]];
         T_local[k] = Tn;
-        scale_local[k] = ::sqrt(Tn / To);
+        scale_local[k] *= ::sqrt(Tn / To);   // (1 unless an earlier sweep's factor has not been taken in yet: Engine::vel)
     }
 }
 
@@ -1948,9 +1957,12 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
     real* gp = pos + (size_t)rep * 3 * natoms;
     real* gv = vel + (size_t)rep * 3 * natoms;
     load_positions(gp, L, natoms);
+    // a replica-exchange sweep leaves the factor its new temperature asks for here instead of spending a launch on it: the product is
+    // what awsem_take_scale_kernel would have stored, and the word goes back to 1 behind the next barrier
+    const real vsc = S.vel_scale ? (real)S.vel_scale[rep] : (real)1;
     for (int k = threadIdx.x; k < S.nmassive; k += L.nthr) {   // velocities live in LDS for the massive particles only, by massive index
         const int i = S.massive[k].atom;
-        L.set_vel(k, R3<real>{gv[i], gv[natoms + i], gv[2 * natoms + i]});
+        L.set_vel(k, R3<real>{gv[i] * vsc, gv[natoms + i] * vsc, gv[2 * natoms + i] * vsc});
     }
     for (int i = threadIdx.x; i < S.max_contact_sites; i += L.nthr) L.rho[i] = 0;
     const double a_d = ::exp(-friction * dt);
@@ -1967,6 +1979,7 @@ __global__ AWSEM_STEP_ATTR AWSEM_BOUNDS(real) void awsem_step_kernel(const DevSy
     const unsigned pace_cu = paced ? pace_cu_key() : 0;
     if (paced && threadIdx.x == 0) L.flag[3] = __float_as_uint(pace_bias(S, rep, (int)gridDim.x, launch, pace_cu));
     __syncthreads();
+    if (S.vel_scale && threadIdx.x == 0) S.vel_scale[rep] = 1.0;
     const int prio_slot = uniform((int)L.flag[2]);
     const float prio_bias = paced ? __uint_as_float(uniform((int)L.flag[3])) : 0.f;
     compute_virtual_sites(S, L);

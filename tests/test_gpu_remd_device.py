@@ -107,6 +107,53 @@ def test_queries_between_sweeps_leave_the_ladder_temperatures_alone():
     gpu.close(); twin.close()
 
 
+@pytest.mark.parametrize("precision", [0, 1])
+def test_the_rescale_of_a_sweep_is_the_same_whoever_takes_it_in(precision):
+    """A sweep leaves its velocity factors on the device; the next step launch multiplies them in as it loads the velocities, and any
+    other reader of the velocities (a state query, the kinetic energy, a snapshot) settles them with a launch first.  Both ways give the
+    same bits, a query sees the rescaled velocities at once, and two sweeps in a row leave the product of their factors."""
+    oa, traj, _ = golden_system("1ubq")
+    n = 8
+    T = np.linspace(300.0, 314.0, n)
+    runs = []
+    for query in (False, True):
+        rex = ensemble.ReplicaExchange(T, seed=5)
+        gpu = _start(oa, traj, n, precision)
+        gpu.set_velocities_to_temperature(rex.local_temperatures(), 3)
+        rex.attach(gpu)
+        seen = []
+        for it in range(6):
+            gpu.step_remd(25, 0.002, 1.0, 9)
+            before = gpu.get_state()[1]
+            T_before = gpu.remd_state()[3].copy()
+            rex.exchange_on_device()
+            if query:
+                ke = gpu.kinetic_energy()
+                v = gpu.get_state()[1]
+                T_after = gpu.remd_state()[3]
+                f = np.sqrt(T_after / T_before)
+                real = np.float32 if precision == 0 else np.float64
+                want = (before.astype(real) * f.astype(real)[:, None, None]).astype(np.float64)
+                assert np.array_equal(v, want)
+                assert np.all(ke > 0)
+                seen.append(np.any(f != 1.0))
+        if query:
+            assert any(seen)          # (some sweep did move a temperature)
+        runs.append(gpu.get_state())
+        if query:   # two sweeps with no launch between them: the factors multiply (one rounding instead of two)
+            v0 = gpu.get_state()[1]
+            T0 = gpu.remd_state()[3].copy()
+            rex.exchange_on_device()
+            rex.exchange_on_device()
+            v2 = gpu.get_state()[1]
+            f = np.sqrt(gpu.remd_state()[3] / T0)
+            assert np.allclose(v2, v0 * f[:, None, None], rtol=3e-7 if precision == 0 else 1e-15, atol=0)
+            # ... and nothing is applied twice: a further query returns the same velocities, a launch starts from them
+            assert np.array_equal(gpu.get_state()[1], v2)
+        gpu.close()
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+
+
 def test_sharded_ladder_with_a_gather_index_takes_the_same_decisions():
     """Two handles play two ranks inside one process: each holds a block of the ladder (4 + 3 replicas) and writes its energies into
     its padded block of one shared device buffer, as two ranks would through the all-gather (shards padded to 4: replica r of rank 1
