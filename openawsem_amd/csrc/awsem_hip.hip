@@ -1765,8 +1765,10 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         const int flavour = dsys_.n_memb || zdep ? 3 : dsys_.n_helical ? 2 : 1;
         if (flavour == 3) lean = lean && zdep && dsys_.n_memb == 1 && dsys_.n_helical == 0;
         else for (int t = 0; t < dsys_.n_contact; t++) lean = lean && dsys_.contact[t].flags == 0;
-        for (int t = 0; t < dsys_.n_beta; t++) lean = lean && dsys_.beta[t].scan_mode == 0 && !dsys_.beta[t].fn;         // every term scans for itself, dense tables
-        for (int t = 0; t < dsys_.n_pap; t++) lean = lean && dsys_.pap[t].scan_mode == 0 && !dsys_.pap[t].fn;
+        // every term scans for itself, dense tables, and a wave's share of the donors fits the 64-bit survivor mask of build_hbond<LEAN>
+        // (the evaluation kernel runs at the same block size or a larger one)
+        for (int t = 0; t < dsys_.n_beta; t++) lean = lean && dsys_.beta[t].scan_mode == 0 && !dsys_.beta[t].fn && dsys_.beta[t].ndon <= block_;
+        for (int t = 0; t < dsys_.n_pap; t++) lean = lean && dsys_.pap[t].scan_mode == 0 && !dsys_.pap[t].fn && dsys_.pap[t].ndon <= block_;
         lean = lean && dsys_.fuse_vs == 1 && dsys_.nmassive <= 2 * block_ && (dsys_.prio & 0xff) != 2 && dsys_.remove_cm != 0;
         // one term of a kind (the harmonic terms merged into one list), the beta / P-AP terms behind one shared list each, owned by the first
         lean = lean && dsys_.n_harm <= 1 && dsys_.n_chi <= 1 && dsys_.n_fm <= 1 && dsys_.n_dh <= 1 && dsys_.n_excl <= 1 && dsys_.n_beta <= 3 && dsys_.n_pap <= 2;

@@ -1044,6 +1044,50 @@ template <bool LEAN = false, class V, class Desc> __device__ __forceinline__ voi
         nz = sm;
     }
     __syncthreads();
+    // LEAN (host: every term's ndon <= 64 waves' worth, dense tables): two passes per chunk of acceptors.  The first tests distance, zero
+    // band and the table's non-zero bit from LDS alone and keeps the survivors as bits of a 64-bit mask in a register; the second walks
+    // the set bits -- a handful per lane -- and only there touches global memory (coefficient, atom records, the list).  The one-pass
+    // loop below pays that round trip in nearly every iteration, because some lane of the 64 nearly always has a pair in range: 2xov's
+    // five scans of 276 x 276 candidates were 23 % of its run time that way.
+    if (LEAN) {
+        for (int a0 = 0; a0 < d.nacc; a0 += 64) {
+            const int ia = a0 + lane;
+            const bool va = ia < d.nacc;
+            const unsigned A = sa[va ? ia : 0];
+            const R3<real> pa = L.pos((int)(A & 0xffffu));
+            const int ares = (int)(A >> 16);
+            const int q0 = (va ? ia : 0) % d.ndon;
+            u64 mm = 0;
+            for (int dd = wave, k = 0; dd < d.ndon; dd += nw, k++) {
+                const int t = q0 + dd, q = t >= d.ndon ? t - d.ndon : t;
+                const unsigned D = sd[q];
+                const int dres = (int)(D >> 16), dq = dres - ares;
+                if (va && dist2(pa - L.pos((int)(D & 0xffffu))) < d.list_rc2 && (dq <= d.band_lo || dq >= d.band_hi)) {
+                    const unsigned bit = (unsigned)(dres * d.nres + ares);
+                    if ((nz[bit >> 5] >> (bit & 31)) & 1u) mm |= 1ull << k;
+                }
+            }
+            while (__ballot(mm != 0) != 0) {
+                const bool pass = mm != 0;
+                const int k = pass ? __ffsll((long long)mm) - 1 : 0;
+                mm &= mm - 1;
+                const int t = q0 + wave + k * nw, q = t >= d.ndon ? t - d.ndon : t;
+                HbEntry<real> ent;
+                ent.w0 = ent.w1 = ent.w2 = 0u; ent.c = (real)0;
+                if (pass) {
+                    const int dres = (int)(sd[q] >> 16);
+                    ent.c = d.table()[(size_t)dres * d.nres + ares];
+                    const Int4 Aq = d.acc[ia], Dn = d.don[q];
+                    ent.w0 = (unsigned)Aq.x | (d.entry_flag() << 15) | ((unsigned)Dn.x << 16);
+                    if (resw == 3) { ent.w1 = ((unsigned)Aq.y & 0xffffu) | ((unsigned)Aq.z << 16); ent.w2 = ((unsigned)Dn.y & 0xffffu) | ((unsigned)Dn.z << 16); }
+                    else { ent.w1 = (unsigned)Aq.y & 0xffffu; ent.w2 = (unsigned)Dn.y & 0xffffu; }
+                }
+                list_append_entry(e, cnt, d.ls.list_cap, status, pass, ent);
+            }
+        }
+        __syncthreads();
+        return;
+    }
     for (int a0 = 0; a0 < d.nacc; a0 += 64) {
         const int ia = a0 + lane;
         const bool va = ia < d.nacc;
