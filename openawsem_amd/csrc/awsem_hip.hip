@@ -1772,6 +1772,9 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
         lean = lean && dsys_.fuse_vs == 1 && dsys_.nmassive <= 2 * block_ && (dsys_.prio & 0xff) != 2 && dsys_.remove_cm != 0;
         // one term of a kind (the harmonic terms merged into one list), the beta / P-AP terms behind one shared list each, owned by the first
         lean = lean && dsys_.n_harm <= 1 && dsys_.n_chi <= 1 && dsys_.n_fm <= 1 && dsys_.n_dh <= 1 && dsys_.n_excl <= 1 && dsys_.n_beta <= 3 && dsys_.n_pap <= 2;
+        // the lean list builders stage a position + word record per site in the accumulators' memory (SiteRec: 16 B, 32 B in fp64)
+        const size_t rec = sizeof(real) == 4 ? 16 : 32, room = (size_t)natoms_ * (sizeof(real) == 4 ? 16 : 24);
+        for (int t = 0; t < dsys_.n_excl; t++) lean = lean && (size_t)dsys_.excl[t].nsites * rec <= room;
         for (int t = 1; t < dsys_.n_beta; t++) lean = lean && !dsys_.beta[t].list_owner;
         for (int t = 1; t < dsys_.n_pap; t++) lean = lean && !dsys_.pap[t].list_owner;
         step_lean_ = lean && !(getenv("AWSEM_STEP_LEAN") && atoi(getenv("AWSEM_STEP_LEAN")) == 0) ? flavour : 0;
