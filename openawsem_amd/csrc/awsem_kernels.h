@@ -741,17 +741,14 @@ template <bool LEAN = false, class V> __device__ __forceinline__ void build_excl
                 const bool vi = i < n;
                 const SiteRec<real> Ri = rec[base + (vi ? i : 0)];
                 const bool low = 2 * i < n;   // (i < n / 2 for even n)
+                const Int4 p = d.partners[base + (vi ? i : 0)];   // the lane's bonded partners: once per site, not per survivor
                 for (int dd = 1 + wave; dd <= half; dd += nw) {
                     int j = i + dd;
                     j = j >= n ? j - n : j;
                     const SiteRec<real> Rj = rec[base + (vi ? j : 0)];
-                    bool pass = vi && dist2(Ri.x - Rj.x, Ri.y - Rj.y, Ri.z - Rj.z) < d.list_rc2 && (2 * dd != n || low);
-                    if (__ballot(pass) == 0) continue;
-                    if (pass) {
-                        const Int4 p = d.partners[base + i];
-                        const int b = (int)Rj.w;
-                        pass = p.x != b && p.y != b && p.z != b && p.w != b;
-                    }
+                    const int b = (int)Rj.w;
+                    const bool pass = vi && dist2(Ri.x - Rj.x, Ri.y - Rj.y, Ri.z - Rj.z) < d.list_rc2 && (2 * dd != n || low) &&
+                                      p.x != b && p.y != b && p.z != b && p.w != b;
                     list_append(e, cnt, d.ls.list_cap, status, pass, (Ri.w << 16) | Rj.w);
                 }
             }
