@@ -1707,7 +1707,8 @@ template <class real> void Engine<real>::finalize(const HostSystem& H0) {
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_step_kernel<real, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
     if (step_ok_) HIP_TRY(hipFuncSetAttribute((const void*)awsem_minimize_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step_));
-    HIP_TRY(hipFuncSetAttribute((const void*)awsem_list_kernel<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
+    HIP_TRY(hipFuncSetAttribute((const void*)awsem_list_kernel<real, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
+    HIP_TRY(hipFuncSetAttribute((const void*)awsem_list_kernel<real, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_));
     // Workgroup size: the waves a CU can hold at this kernel's register budget (16) divided among the replicas whose LDS
     // images fit one CU -- four small replicas share a CU with 4 waves each (more waves per replica were measured slower
     // there: 1r69, 320 / 384 threads), a replica that has the CU to itself (2xov: 104 KB) takes all 16 (measured +45 %
@@ -1828,7 +1829,8 @@ template <class real> int Engine<real>::neighbors(int rep, int kind, int index, 
         break;
     default: throw std::string("neighbors: kind must be AWSEM_LIST_EXCL, _CONTACT, _BETA or _PAP");
     }
-    hipLaunchKernelGGL(awsem_list_kernel<real>, dim3(nrep_), dim3(block_), lds_eval_, stream_, S, pos_, 1u << group, dcounts_);
+    if (step_lean_) hipLaunchKernelGGL((awsem_list_kernel<real, true>), dim3(nrep_), dim3(block_), lds_eval_, stream_, S, pos_, 1u << group, dcounts_);
+    else hipLaunchKernelGGL((awsem_list_kernel<real, false>), dim3(nrep_), dim3(block_), lds_eval_, stream_, S, pos_, 1u << group, dcounts_);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream_));
     check_status();

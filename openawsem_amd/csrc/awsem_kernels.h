@@ -1681,8 +1681,9 @@ __global__ AWSEM_BOUNDS(real) void awsem_eval_kernel(const DevSys<real> S, const
     }
 }
 
-// Pair-list dump for awsem_neighbors: builds the lists of the terms in `mask` and writes the per-list counts.
-template <class real>
+// Pair-list dump for awsem_neighbors: builds the lists of the terms in `mask` and writes the per-list counts.  LEAN: with the builders
+// of the lean step / evaluation kernels, for the handles that run those (the list-parity tests then pin the builders that are used).
+template <class real, bool LEAN = false>
 __global__ AWSEM_BOUNDS(real) void awsem_list_kernel(const DevSys<real> S, const real* __restrict__ pos, unsigned mask, unsigned* __restrict__ counts /* [R][AWSEM_MAX_LISTS] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int natoms = S.natoms, rep = blockIdx.x;
@@ -1692,7 +1693,7 @@ __global__ AWSEM_BOUNDS(real) void awsem_list_kernel(const DevSys<real> S, const
     if (threadIdx.x < AWSEM_MAX_LISTS) L.lcount[threadIdx.x] = 0;
     stage_tables(S, L);
     __syncthreads();
-    build_lists(S, L, mask);
+    build_lists<LEAN>(S, L, mask);
     __syncthreads();
     if (threadIdx.x < AWSEM_MAX_LISTS) counts[(size_t)rep * AWSEM_MAX_LISTS + threadIdx.x] = L.lcount[threadIdx.x];
 }
