@@ -164,12 +164,17 @@ def test_bad_arguments_are_rejected_with_messages():
         ctx.add_harmonic_bonds(20, [(0, 1)], [0.1], [1.0])
 
 
+@pytest.mark.parametrize("builders", ["lean", "full"])
 @pytest.mark.parametrize("precision", [FP32, FP64])
 @pytest.mark.parametrize("protein", ["1brs", "2lyz"])
-def test_pair_lists_equal_brute_force_bit_exactly(protein, precision):
-    """The engine's list builder (diagonal enumeration + wave compaction) against the oracle's O(N^2) scan with the
-    distance screen evaluated in the same precision and operation order: identical sorted pair sets, with and
-    without a skin.  The reference keeps OpenMM's neighbour lists private, so there is no fixture: parity unpinned."""
+def test_pair_lists_equal_brute_force_bit_exactly(protein, precision, builders, monkeypatch):
+    """The engine's list builders against the oracle's O(N^2) scan with the distance screen evaluated in the same precision and
+    operation order: identical sorted pair sets, with and without a skin.  Both families: the ones the lean step / evaluation kernels
+    carry (two-pass hydrogen-bond scan, excluded-volume scan with the lane's site in registers; awsem_neighbors uses them on a handle
+    that runs the lean kernels) and the diagonal enumeration of the full kernel (AWSEM_STEP_LEAN=0).  The reference keeps OpenMM's
+    neighbour lists private, so there is no fixture: parity unpinned."""
+    if builders == "full":
+        monkeypatch.setenv("AWSEM_STEP_LEAN", "0")
     oa, traj, _ = golden_system(protein)
     gpu = _gpu(oa, 2, precision)
     cpu = _capi.Context(awsem_oracle.load(), oa.natoms, 2, precision=precision)
