@@ -155,6 +155,7 @@ def _launch_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", str(max(1, 16 // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    print(f"[bench] started {len(procs)} ranks (rendezvous 127.0.0.1:{port})", file=sys.stderr, flush=True)
     worst = 0
     try:
         live = list(procs)

@@ -201,7 +201,10 @@ def test_bench_launches_its_own_ranks_when_asked_for_several_gpus():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0"],
                          env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 1
-    assert res.stderr.count("bench.py needs a GPU") == 3
+    assert "[bench] started 3 ranks" in res.stderr
+    # (the launcher ends the other ranks as soon as one has failed -- they would wait in a collective for ever -- so a slow one may be
+    # gone before it has printed its own message)
+    assert 1 <= res.stderr.count("bench.py needs a GPU") <= 3
 
 
 def test_swap_all_mixing_samples_the_boltzmann_distribution_over_assignments():
