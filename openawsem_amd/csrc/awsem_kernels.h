@@ -1081,7 +1081,7 @@ template <bool LEAN = false, class V, class Desc> __device__ __forceinline__ voi
     // the set bits -- a handful per lane -- and only there touches global memory (coefficient, atom records, the list).  The one-pass
     // loop below pays that round trip in nearly every iteration, because some lane of the 64 nearly always has a pair in range: 2xov's
     // five scans of 276 x 276 candidates were 23 % of its run time that way.
-    if (LEAN) {
+    if (LEAN || (!d.fn && d.ndon <= 64 * nw)) {   // (the full kernel: when the term qualifies, uniform)
         for (int a0 = 0; a0 < d.nacc; a0 += 64) {
             const int ia = a0 + lane;
             const bool va = ia < d.nacc;
