@@ -722,7 +722,7 @@ template <class V> __device__ __forceinline__ ListView list_view(const V& L, con
 // site records of the lean builders: position and a word (atom, or site info) side by side, so that a candidate costs ONE conflict-free
 // 16-byte LDS read (the site -> atom table and a float4 at a stride of six atoms were two dependent reads, the second on shared banks)
 template <class real> struct __attribute__((aligned(16))) SiteRec { real x, y, z; unsigned w; };
-template <bool LEAN = false, class V> __device__ __forceinline__ void build_excl(const ExclD<typename V::real_t>& d, const V& L, int* status) {
+template <bool LEAN = false, class V> __device__ __forceinline__ void build_excl(const ExclD<typename V::real_t>& d, const V& L, int* status, int natoms) {
     typedef typename V::real_t real;
     AWSEM_WAVE_VARS;
     unsigned* e = L.lists + d.ls.list_off;
@@ -730,7 +730,7 @@ template <bool LEAN = false, class V> __device__ __forceinline__ void build_excl
     // LEAN (host: the records fit the staging area): a lane keeps site i of the class in registers and meets j = i + dd (mod n), dd = 1 ..
     // n/2 dealt to the waves: every unordered pair once (for even n the last dd would come twice: its second half is skipped), the
     // entries of one append still pairwise distinct in both members, and one LDS read per candidate instead of four.
-    if (LEAN) {
+    if (LEAN || (sizeof(real) == 4 && d.nsites <= natoms)) {   // (the full fp32 kernel: when the 16-byte records fit the accumulators' 16 bytes per atom, uniform)
         SiteRec<real>* rec = (SiteRec<real>*)L.scratch();
         for (int i = threadIdx.x; i < d.nsites; i += L.nthr) { const int a = d.atom[i]; const R3<real> p = L.pos(a); rec[i] = SiteRec<real>{p.x, p.y, p.z, (unsigned)a}; }
         __syncthreads();
@@ -1386,7 +1386,7 @@ template <class V> __device__ __forceinline__ void stage_tables(const DevSys<typ
 // before (and synchronises), and synchronises after.
 template <bool LEAN = false, class V> __device__ __forceinline__ void build_lists(const DevSys<typename V::real_t>& S, const V& L, unsigned mask) {
     for (int t = 0; t < (LEAN ? (S.n_contact < 1 ? S.n_contact : 1) : S.n_contact); t++) if (AWSEM_ON(S.contact[t])) build_contact(S.contact[t], L, L.satom + t * S.max_contact_sites, S.status);
-    for (int t = 0; t < (LEAN ? (S.n_excl < 1 ? S.n_excl : 1) : S.n_excl); t++) if (AWSEM_ON(S.excl[t])) build_excl<LEAN>(S.excl[t], L, S.status);
+    for (int t = 0; t < (LEAN ? (S.n_excl < 1 ? S.n_excl : 1) : S.n_excl); t++) if (AWSEM_ON(S.excl[t])) build_excl<LEAN>(S.excl[t], L, S.status, S.natoms);
     for (int t = 0; t < (LEAN ? (S.n_beta < 3 ? S.n_beta : 3) : S.n_beta); t++) if (AWSEM_ON(S.beta[t])) {
         if (LEAN || !S.beta[t].scan_mode) build_hbond<LEAN>(S.beta[t], L, S.status);   // (LEAN: chosen only for systems whose terms scan for themselves, dense tables)
         else if (S.beta[t].list_owner) build_hbond_group(S.beta[t], S.beta_dev, t, S.n_beta, L, S.status);
@@ -1404,7 +1404,7 @@ template <bool LEAN = false, class V> __device__ __forceinline__ void build_list
 template <bool LEAN = false, class V> __device__ __forceinline__ void build_lists_prof(const DevSys<typename V::real_t>& S, const V& L, unsigned mask, AwsemProf& awsem_prof) {
     for (int t = 0; t < S.n_contact; t++) if (AWSEM_ON(S.contact[t])) build_contact(S.contact[t], L, L.satom + t * S.max_contact_sites, S.status);
     AWSEM_ARRIVE(1);
-    for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) build_excl<LEAN>(S.excl[t], L, S.status);
+    for (int t = 0; t < S.n_excl; t++) if (AWSEM_ON(S.excl[t])) build_excl<LEAN>(S.excl[t], L, S.status, S.natoms);
     AWSEM_ARRIVE(3);
     for (int t = 0; t < S.n_beta; t++) if (AWSEM_ON(S.beta[t])) {
         if (LEAN || !S.beta[t].scan_mode) build_hbond<LEAN>(S.beta[t], L, S.status);
